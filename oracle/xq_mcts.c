@@ -1,0 +1,235 @@
+/*
+ * xq_mcts.c -- CPU ORACLE (test infrastructure, NOT the product). See xq_oracle.h.
+ *
+ * Sequential PUCT search restating reference mcts.py:7-233, including the NumPy (>=2, NEP 50)
+ * dtype behaviour of its arithmetic, which decides visit counts bit for bit:
+ *   - Node.value starts as Python int 0; a backup with the net's ndarray(1,1) float32 value makes
+ *     it float32 and every later update runs in float32; a node that only ever receives terminal
+ *     values (Python floats) keeps a Python double (mcts.py:63-78).
+ *   - puct_value (mcts.py:41-52): `c_puct * prob` is float32 (int * np.float32), np.sqrt(int) is
+ *     float64, so the product, the quotient and the final sum are float64.
+ *   - select (mcts.py:54-61): Python max() keeps the FIRST maximal child in insertion order;
+ *     unvisited children score +inf.
+ */
+#include "xq_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+enum { V_INT0 = 0, V_PYFLOAT = 1, V_F32 = 2 };
+
+typedef struct node {
+    struct node *parent;
+    int nchild;
+    int32_t *act;
+    struct node **child;
+    int visits;
+    int vkind;
+    double vd; /* value when V_PYFLOAT */
+    float vf;  /* value when V_F32     */
+    float prob;
+} node;
+
+struct xq_mcts {
+    node *root;
+    int c_puct;
+    int n_playout;
+    node *cur_leaf; /* set by xq_mcts_select */
+    int64_t live_nodes;
+};
+
+static node *node_new(xq_mcts *t, node *parent, float prob)
+{
+    node *n = (node *)calloc(1, sizeof *n);
+    if (!n) abort();
+    n->parent = parent;
+    n->prob = prob;
+    t->live_nodes++;
+    return n;
+}
+
+static void node_free(xq_mcts *t, node *n)
+{
+    int i;
+    if (!n) return;
+    for (i = 0; i < n->nchild; i++) node_free(t, n->child[i]);
+    free(n->act);
+    free(n->child);
+    free(n);
+    t->live_nodes--;
+}
+
+xq_mcts *xq_mcts_new(int c_puct, int n_playout)
+{
+    xq_mcts *t = (xq_mcts *)calloc(1, sizeof *t);
+    if (!t) abort();
+    xq_table_init();
+    t->c_puct = c_puct;
+    t->n_playout = n_playout;
+    t->root = node_new(t, NULL, 1.0f); /* Node(None, 1.0)  mcts.py:94 */
+    return t;
+}
+
+void xq_mcts_free(xq_mcts *t)
+{
+    if (!t) return;
+    node_free(t, t->root);
+    free(t);
+}
+
+/* Node.puct_value  mcts.py:41-52 */
+static double puct_value(const node *n, int c_puct)
+{
+    float cp;
+    double u, q;
+    if (n->visits == 0) return INFINITY;
+    cp = (float)c_puct * n->prob;                                   /* int * np.float32 -> float32 */
+    u = (double)cp * sqrt((double)n->parent->visits) / (double)(1 + n->visits); /* float64        */
+    q = n->vkind == V_F32 ? (double)n->vf : (n->vkind == V_PYFLOAT ? n->vd : 0.0);
+    return q + u;
+}
+
+/* Node.update  mcts.py:63-71 ; leaf value is either an ndarray float32 (is_f32) or a Python float */
+static void node_update(node *n, int is_f32, float lf, double ld)
+{
+    n->visits += 1;
+    if (is_f32 || n->vkind == V_F32) {
+        /* any float32 ndarray operand makes the whole expression float32 (Python scalars are weak) */
+        float v = is_f32 ? lf : (float)ld;
+        float cur = n->vkind == V_F32 ? n->vf : (n->vkind == V_PYFLOAT ? (float)n->vd : 0.0f);
+        float delta = v - cur;
+        delta = 1.0f * delta;
+        delta = delta / (float)n->visits;
+        n->vf = cur + delta;
+        n->vkind = V_F32;
+    } else {
+        double cur = n->vkind == V_PYFLOAT ? n->vd : 0.0;
+        n->vd = cur + 1.0 * (ld - cur) / (double)n->visits;
+        n->vkind = V_PYFLOAT;
+    }
+}
+
+/* Node.update_recursive  mcts.py:73-78 : parent first, with the negated value */
+static void node_update_recursive(node *n, int is_f32, float lf, double ld)
+{
+    if (n->parent) node_update_recursive(n->parent, is_f32, -lf, -ld);
+    node_update(n, is_f32, lf, ld);
+}
+
+/* descend from the root pushing moves (mcts.py:105-111); returns the leaf */
+int xq_mcts_select(xq_mcts *t, const xq_board *root_board, xq_board *leaf_out, int *depth_out)
+{
+    node *n = t->root;
+    int depth = 0;
+    *leaf_out = *root_board; /* board.copy()  mcts.py:151 */
+    while (n->nchild != 0) {
+        int i, best = 0;
+        double bestv = puct_value(n->child[0], t->c_puct);
+        for (i = 1; i < n->nchild; i++) {
+            double v = puct_value(n->child[i], t->c_puct);
+            if (v > bestv) { bestv = v; best = i; } /* strict: first maximum wins */
+        }
+        xq_push(leaf_out, xq_move_from(n->act[best]), xq_move_to(n->act[best]));
+        n = n->child[best];
+        depth++;
+    }
+    t->cur_leaf = n;
+    if (depth_out) *depth_out = depth;
+    return 0;
+}
+
+/* second half of playout (mcts.py:113-129) for the leaf chosen by xq_mcts_select */
+void xq_mcts_expand_backup(xq_mcts *t, const xq_board *leaf, int k, const uint16_t *ids,
+                           const float *prob, float value)
+{
+    node *n = t->cur_leaf;
+    int end = xq_is_game_over(leaf, k), tie = xq_is_tie(leaf, k);
+    if (!end && !tie) {
+        int i;
+        /* Node.expand  mcts.py:31-39 : one child per (action, prob), evaluator order */
+        n->act = (int32_t *)malloc(sizeof(int32_t) * (size_t)k);
+        n->child = (node **)malloc(sizeof(node *) * (size_t)k);
+        if (!n->act || !n->child) abort();
+        for (i = 0; i < k; i++) {
+            n->act[i] = ids[i];
+            n->child[i] = node_new(t, n, prob[i]);
+        }
+        n->nchild = k;
+        node_update_recursive(n, 1, -value, 0.0);
+    } else if (end && tie) {
+        node_update_recursive(n, 0, 0.0f, -0.0); /* leaf_value = 0.0 */
+    } else {
+        /* winner = RED if outcome().winner else BLACK ; +1 if winner == board.turn  (mcts.py:125-126) */
+        int w = xq_outcome_winner(leaf, k);
+        int winner = (w == 1) ? XQ_RED : XQ_BLACK; /* None is falsy -> BLACK */
+        double lv = winner == leaf->pos.turn ? 1.0 : -1.0;
+        node_update_recursive(n, 0, 0.0f, -lv);
+    }
+    t->cur_leaf = NULL;
+}
+
+void xq_mcts_playout(xq_mcts *t, const xq_board *root_board, xq_eval_fn fn, void *user)
+{
+    xq_board leaf;
+    uint16_t ids[XQ_MAX_LEGAL];
+    float prob[XQ_MAX_LEGAL];
+    float value = 0.0f;
+    int k, depth;
+    xq_mcts_select(t, root_board, &leaf, &depth);
+    k = xq_legal_ids(&leaf, ids);
+    /* the reference evaluates the net on terminal leaves too and discards the result (mcts.py:114);
+       that is results-neutral, so the evaluator is only called where its output is used */
+    if (!xq_is_game_over(&leaf, k) && !xq_is_tie(&leaf, k)) value = fn(user, &leaf, k, ids, prob);
+    xq_mcts_expand_backup(t, &leaf, k, ids, prob, value);
+}
+
+int xq_mcts_root_children(const xq_mcts *t, int32_t *acts, int32_t *visits, float *q, float *p)
+{
+    int i;
+    for (i = 0; i < t->root->nchild; i++) {
+        const node *c = t->root->child[i];
+        if (acts) acts[i] = t->root->act[i];
+        if (visits) visits[i] = c->visits;
+        if (q) q[i] = c->vkind == V_F32 ? c->vf : (c->vkind == V_PYFLOAT ? (float)c->vd : 0.0f);
+        if (p) p[i] = c->prob;
+    }
+    return t->root->nchild;
+}
+
+int xq_mcts_root_visits(const xq_mcts *t) { return t->root->visits; }
+int64_t xq_mcts_node_count(const xq_mcts *t) { return t->live_nodes; }
+
+/* MCTS.get_move_probs  mcts.py:131-166 */
+int xq_mcts_get_move_probs(xq_mcts *t, const xq_board *b, double temp, xq_eval_fn fn, void *user,
+                           int32_t *acts, int32_t *visits, double *probs)
+{
+    int i, k;
+    double mx = -INFINITY, sum = 0.0;
+    for (i = 0; i < t->n_playout; i++) xq_mcts_playout(t, b, fn, user);
+    k = xq_mcts_root_children(t, acts, visits, NULL, NULL);
+    /* softmax(1.0/temp * np.log(np.array(visits) + 1e-10))  (mcts.py:165, tools.py:126-129) */
+    for (i = 0; i < k; i++) {
+        probs[i] = 1.0 / temp * log((double)visits[i] + 1e-10);
+        if (probs[i] > mx) mx = probs[i];
+    }
+    for (i = 0; i < k; i++) { probs[i] = exp(probs[i] - mx); sum += probs[i]; }
+    for (i = 0; i < k; i++) probs[i] /= sum;
+    return k;
+}
+
+/* MCTS.update_with_move  mcts.py:168-178 */
+void xq_mcts_update_with_move(xq_mcts *t, int move_id)
+{
+    node *r = t->root, *keep = NULL;
+    int i;
+    for (i = 0; i < r->nchild; i++)
+        if (r->act[i] == move_id) { keep = r->child[i]; r->child[i] = NULL; }
+    node_free(t, r);
+    if (keep) {
+        keep->parent = NULL;
+        t->root = keep;
+    } else {
+        t->root = node_new(t, NULL, 1.0f);
+    }
+}

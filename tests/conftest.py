@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long-running CPU check")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import json
+
+    import numpy as np
+
+    g = os.path.join(ROOT, "tests", "golden")
+    data = dict(np.load(os.path.join(g, "reference_search.npz")))
+    with open(os.path.join(g, "reference_search.json")) as f:
+        meta = json.load(f)
+    with open(os.path.join(g, "action_table.txt")) as f:
+        table = f.read().split()
+    return {"data": data, "meta": meta, "table": table}

@@ -1,0 +1,40 @@
+"""Start positions of the golden search traces (data mirrored from tests/golden/make_golden.py)."""
+import numpy as np
+
+
+def sq(name: str) -> int:
+    return (ord(name[0]) - 97) + 9 * int(name[1])
+
+
+def _place(spec):
+    b = np.zeros(90, dtype=np.uint8)
+    for name, pc in spec.items():
+        b[sq(name)] = pc
+    return b
+
+
+STARTS = {
+    "two_rooks": _place({"d0": 7, "a7": 3, "b8": 3, "e9": 15}),
+    "capture_to_bare": _place({"e0": 7, "d0": 6, "e1": 9, "d9": 15, "c9": 13}),
+    "rook_knight": _place({"e0": 7, "e1": 6, "c2": 4, "h4": 3, "d9": 15, "e8": 14, "a5": 11, "g6": 9}),
+}
+
+START_ROWS = ["RNBAKABNR", ".........", ".C.....C.", "P.P.P.P.P", ".........",
+              ".........", "p.p.p.p.p", ".c.....c.", ".........", "rnbakabnr"]
+_PC = {"p": 1, "c": 2, "r": 3, "n": 4, "b": 5, "a": 6, "k": 7}
+
+
+def start_position() -> np.ndarray:
+    b = np.zeros(90, dtype=np.uint8)
+    for r, row in enumerate(START_ROWS):
+        for f, ch in enumerate(row):
+            if ch != ".":
+                b[f + 9 * r] = _PC[ch.lower()] + (0 if ch.isupper() else 8)
+    return b
+
+
+def case_start(case):
+    """(squares uint8[90], turn, halfmove) of a golden case."""
+    if case["start"] == "start":
+        return start_position(), 1, 0
+    return STARTS[case["start"]].copy(), case["turn"], case["halfmove"]

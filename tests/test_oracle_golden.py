@@ -1,0 +1,112 @@
+"""CPU: the C oracle against the golden vectors produced by executing the reference's own code."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import OracleBoard, OracleMCTS
+from oracle.evaluators import EVALUATORS
+
+from golden_cases import case_start
+
+
+def test_action_table_matches_reference(golden):
+    t = oracle.move_table()
+    assert t == golden["table"]
+    assert hashlib.sha256(",".join(t).encode()).hexdigest() == golden["meta"]["table_sha256"]
+    L = oracle.lib()
+    for i, s in enumerate(t):
+        fr, to = L.xq_move_from(i), L.xq_move_to(i)
+        assert s == "abcdefghi"[fr % 9] + str(fr // 9) + "abcdefghi"[to % 9] + str(to // 9)
+        assert L.xq_move_id(fr, to) == i
+
+
+def test_flip_map_matches_reference(golden):
+    fm = oracle.flip_map()
+    assert np.array_equal(fm, golden["data"]["flip_map"])
+    assert np.array_equal(fm[fm], np.arange(2086))  # involution
+    assert int((fm == np.arange(2086)).sum()) == 90
+
+
+def test_dtype_facts(golden):
+    f = golden["meta"]["dtype_facts"]
+    # the promotion rules the oracle's V_F32 / V_PYFLOAT state machine restates (mcts.py:41-78)
+    assert f["q_dtype_after_net_backup"] == "float32"
+    assert f["puct_dtype"] == "float64"
+    assert f["cpuct_times_prob_dtype"] == "float32"
+    assert f["sqrt_int_dtype"] == "float64"
+    assert f["q_type_terminal_only"] == "float"
+    assert f["q_dtype_mixed"] == "float32"
+    assert f["unvisited_is_inf"] is True
+
+
+def test_pi_from_visits(golden):
+    d = golden["data"]
+    L = oracle.lib()
+    for i in range(golden["meta"]["n_pi"]):
+        visits, temp, ref = d[f"pi{i}_visits"], float(d[f"pi{i}_temp"]), d[f"pi{i}_pi"]
+        # libm restatement of softmax(1/temp*log(N+1e-10))
+        x = 1.0 / temp * np.log(visits.astype(np.int64) + 1e-10)
+        e = np.exp(x - x.max())
+        assert np.allclose(e / e.sum(), ref, rtol=0, atol=1e-15)
+        # deterministic (device-mode) twin stays within 1e-12 of the reference
+        assert np.allclose(oracle.det_pi(visits, temp), ref, rtol=0, atol=1e-12)
+
+
+def _make_eval(name):
+    ev = EVALUATORS[name]
+
+    def f(board, ids):
+        p, v = ev(board.squares()[None, :], np.array([1 if board.turn else 0]))
+        return p[0][ids], v[0]
+
+    return f
+
+
+@pytest.mark.parametrize("idx", range(11))
+def test_search_trace_matches_reference(golden, idx):
+    """Visit counts, Q, priors bit-exact; pi to 1e-12; sampled moves identical under np.random.seed."""
+    case = golden["meta"]["cases"][idx]
+    d = golden["data"]
+    name = case["name"]
+    sqs, turn, half = case_start(case)
+    board = OracleBoard.from_array(sqs, turn, half) if case["start"] != "start" else OracleBoard()
+    mcts = OracleMCTS(_make_eval(case["ev"]), c_puct=5, n_playout=case["n"])
+    rs = np.random.RandomState(case["seed"])
+    for ply in range(case["plies_done"]):
+        acts, visits, probs = mcts.get_move_probs(board, case["temps"][ply])
+        a2, v2, q, prior = mcts.root_children()
+        assert np.array_equal(acts, d[f"{name}_p{ply}_acts"]), (name, ply)
+        assert np.array_equal(visits, d[f"{name}_p{ply}_visits"]), (name, ply)
+        assert np.array_equal(q.view(np.uint32), d[f"{name}_p{ply}_q"].view(np.uint32)), (name, ply)
+        assert np.array_equal(prior.view(np.uint32), d[f"{name}_p{ply}_prior"].view(np.uint32))
+        assert mcts.root_visits() == int(d[f"{name}_p{ply}_rootvisits"])
+        assert np.allclose(probs, d[f"{name}_p{ply}_pi"], rtol=0, atol=1e-12)
+        # reference-exact sampling: mcts.py:216-229 on the golden pi
+        pi = d[f"{name}_p{ply}_pi"]
+        if case["selfplay"]:
+            mixed = 0.75 * pi + 0.25 * rs.dirichlet(0.2 * np.ones(len(pi)))
+            assert np.array_equal(mixed, d[f"{name}_p{ply}_mixed"])
+            move = int(rs.choice(acts, p=mixed))
+            mcts.update_with_move(move)
+        else:
+            move = int(rs.choice(acts, p=pi))
+            mcts.update_with_move(-1)
+        assert move == int(d[f"{name}_p{ply}_move"])
+        board.push_id(move)
+    assert np.array_equal(board.squares(), d[f"{name}_final_sq"])
+
+
+def test_terminal_values_reached_in_traces(golden):
+    """The endgame cases must actually exercise terminal leaves (fewer evaluator calls than playouts)."""
+    ev_hit = {c["name"]: c["evals"] for c in golden["meta"]["cases"]}
+    # the reference calls the evaluator on every playout incl. terminal leaves
+    for c in golden["meta"]["cases"]:
+        assert ev_hit[c["name"]] == c["n"] * c["plies_done"]
+    case = [c for c in golden["meta"]["cases"] if c["name"] == "rooks_sixty_n300"][0]
+    sqs, turn, half = case_start(case)
+    board = OracleBoard.from_array(sqs, turn, half)
+    mcts = OracleMCTS(_make_eval(case["ev"]), c_puct=5, n_playout=case["n"])
+    mcts.get_move_probs(board, 1.0)
+    assert mcts.n_evals < case["n"]  # the oracle skips the evaluator on terminal leaves (results-neutral)
