@@ -1,0 +1,106 @@
+"""ctypes binding of libcczero.so (C ABI: include/cczero.h). No fallback: import fails loudly.
+
+``torch`` is imported first on purpose: PyTorch-ROCm ships its own HIP runtime with the same
+soname as the system one; loading it first makes libcczero.so share that single runtime, so
+streams and device pointers can be passed across the boundary.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcczero.so")
+
+NSQ = 90
+SQ_STRIDE = 96
+NMOVES = 2086
+MAX_LEGAL = 128
+MASK_WORDS = 66
+PLANES = 10710
+
+FLAG_REFERENCE_QUIRKS = 1
+FLAG_NO_MIRROR = 2
+LEAF_EXPAND, LEAF_DRAW, LEAF_LOSS, LEAF_SKIP = 0, 1, 2, 3
+
+ERR_BITS = {1: "node pool exhausted (raise max_nodes)", 2: "selection depth / history chain overflow",
+            4: "more than 128 legal moves or pseudo-move overflow", 8: "pi record arena overflow",
+            16: "forced move is not a child of the root / root not expanded", 32: "NaN priors"}
+
+
+class CczError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("n_boards", C.c_int32), ("n_playout", C.c_int32), ("c_puct", C.c_float), ("eps", C.c_float),
+        ("alpha", C.c_float), ("temp", C.c_float), ("max_nodes", C.c_int32), ("max_depth", C.c_int32),
+        ("max_plies", C.c_int32), ("flags", C.c_uint32), ("seed", C.c_uint64), ("board_id_base", C.c_uint64),
+        ("device", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("sims", C.c_int64), ("moves", C.c_int64), ("games", C.c_int64), ("truncated_games", C.c_int64),
+        ("nodes_peak", C.c_int64), ("depth_peak", C.c_int64), ("sum_depth", C.c_int64), ("sum_children", C.c_int64),
+        ("expansions", C.c_int64), ("terminal_leaves", C.c_int64), ("error_flags", C.c_int32), ("reserved", C.c_int32),
+        ("hbm_bytes", C.c_int64),
+    ]
+
+
+# every symbol include/cczero.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+PROTOTYPES = {
+    "ccz_abi_version": (C.c_int, []),
+    "ccz_last_error": (C.c_char_p, []),
+    "ccz_device_count": (C.c_int, []),
+    "ccz_action_table": (C.c_int, [_P, _P, _P]),
+    "ccz_flip_map": (C.c_int, [_P]),
+    "ccz_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
+    "ccz_destroy": (C.c_int, [_P]),
+    "ccz_reset": (C.c_int, [_P, _P, _P]),
+    "ccz_set_position": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32]),
+    "ccz_select_leaves": (C.c_int, [_P, _P, _P]),
+    "ccz_zero_leaf_input": (C.c_int, [_P, _P, _P]),
+    "ccz_expand_backup": (C.c_int, [_P, _P, _P, _P]),
+    "ccz_finish_move": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32]),
+    "ccz_root_children": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "ccz_root_pi": (C.c_int, [_P, _P, _P, _P]),
+    "ccz_game_status": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "ccz_root_positions": (C.c_int, [_P, _P, _P]),
+    "ccz_leaf_info": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "ccz_harvest_rows": (C.c_int, [_P, _P, C.POINTER(C.c_int64)]),
+    "ccz_harvest": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "ccz_get_stats": (C.c_int, [_P, _P, C.POINTER(Stats)]),
+    "ccz_legal_moves": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    "ccz_apply_moves": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CczError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). The engine has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if L.ccz_abi_version() != 1:
+            raise CczError("libcczero.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise CczError(f"libcczero error {rc}: {lib().ccz_last_error().decode(errors='replace')}")

@@ -1,0 +1,451 @@
+// cczero.hip -- C ABI (include/cczero.h) of the gfx950 lockstep self-play rollout engine.
+//
+// Host side: memory layout in HBM, launches on the caller's stream, error reporting. There is no
+// CPU fallback anywhere in this file: without a usable HIP device every compute entry point fails.
+#include "../../include/cczero.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "cczero_kernels.h"
+
+using namespace ccz;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess) return fail(-2, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr Tables h_tab = make_tables();
+
+template <typename T>
+hipError_t dalloc(T **p, size_t n, std::vector<void *> &owned, size_t &total)
+{
+    void *q = nullptr;
+    const size_t bytes = n * sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes ? bytes : 16);
+    if (e != hipSuccess) return e;
+    e = hipMemset(q, 0, bytes ? bytes : 16);
+    if (e != hipSuccess) return e;
+    owned.push_back(q);
+    total += bytes;
+    *p = (T *)q;
+    return hipSuccess;
+}
+
+} // namespace
+
+struct ccz_engine {
+    ccz_config cfg;
+    Dev d;
+    std::vector<void *> owned;
+    size_t bytes = 0;
+    // staging (device) for the sync'ing accessors
+    int32_t *st_k = nullptr, *st_visits = nullptr, *st_rootn = nullptr;
+    uint16_t *st_acts = nullptr;
+    float *st_q = nullptr, *st_p = nullptr;
+    double *st_pi = nullptr, *st_temps = nullptr;
+    long long *st_rowbase = nullptr;
+    uint8_t *st_mask = nullptr, *st_sq = nullptr;
+    std::vector<BoardMeta> h_meta;
+};
+
+extern "C" {
+
+int ccz_abi_version(void) { return CCZ_ABI_VERSION; }
+const char *ccz_last_error(void) { return g_err; }
+
+int ccz_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ccz_action_table(char *uci, uint8_t *from, uint8_t *to)
+{
+    for (int i = 0; i < kNMoves; ++i) {
+        const int fr = h_tab.from[i], t = h_tab.to[i];
+        if (uci) {
+            uci[i * 5 + 0] = (char)('a' + fr % 9);
+            uci[i * 5 + 1] = (char)('0' + fr / 9);
+            uci[i * 5 + 2] = (char)('a' + t % 9);
+            uci[i * 5 + 3] = (char)('0' + t / 9);
+            uci[i * 5 + 4] = 0;
+        }
+        if (from) from[i] = (uint8_t)fr;
+        if (to) to[i] = (uint8_t)t;
+    }
+    return 0;
+}
+
+int ccz_flip_map(int32_t *flip)
+{
+    if (!flip) return fail(-1, "ccz_flip_map: null output");
+    for (int i = 0; i < kNMoves; ++i) flip[i] = h_tab.flip[i];
+    return 0;
+}
+
+int ccz_create(const ccz_config *cfg, ccz_engine **out)
+{
+    if (!cfg || !out) return fail(-1, "ccz_create: null argument");
+    if (cfg->n_boards <= 0) return fail(-1, "ccz_create: n_boards must be > 0");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(-3, "ccz_create: no HIP device available (the engine has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(-1, "ccz_create: device %d out of range (%d devices)", cfg->device, ndev);
+    HIP_TRY(hipSetDevice(cfg->device));
+    ccz_engine *e = new (std::nothrow) ccz_engine();
+    if (!e) return fail(-4, "ccz_create: out of host memory");
+    e->cfg = *cfg;
+    Dev &d = e->d;
+    d.B = cfg->n_boards;
+    // nodes per pool half: every playout creates <= ~k children; the retained subtree adds to it
+    const int n_play = cfg->n_playout > 0 ? cfg->n_playout : 400;
+    d.cap = cfg->max_nodes > 0 ? cfg->max_nodes : (n_play + 64) * 112;
+    d.maxd = cfg->max_depth > 0 ? cfg->max_depth : 512;
+    d.max_plies = cfg->max_plies > 0 ? cfg->max_plies : 2048;
+    d.pi_cap = d.max_plies * 48;
+    d.c_puct = cfg->c_puct;
+    d.eps = (double)cfg->eps;
+    d.alpha = (double)cfg->alpha;
+    d.temp = (double)cfg->temp;
+    d.flags = cfg->flags;
+    d.seed = cfg->seed;
+    d.board_id_base = cfg->board_id_base;
+    const size_t B = (size_t)d.B;
+    hipError_t he = hipSuccess;
+#define ALLOC(ptr, n)                                                        \
+    if (he == hipSuccess) he = dalloc(&(ptr), (size_t)(n), e->owned, e->bytes)
+    ALLOC(d.nodeA, B * 2 * d.cap);
+    ALLOC(d.nodeB, B * 2 * d.cap);
+    ALLOC(d.meta, B);
+    ALLOC(d.root_sq, B * 96);
+    ALLOC(d.chain, B * kChainCap);
+    ALLOC(d.path, B * d.maxd);
+    ALLOC(d.path_len, B);
+    ALLOC(d.leaf_ids, B * kMaxLegal);
+    ALLOC(d.leaf_k, B);
+    ALLOC(d.leaf_status, B);
+    ALLOC(d.rec_sq, B * d.max_plies * 96);
+    ALLOC(d.rec_turn, B * d.max_plies);
+    ALLOC(d.rec_k, B * d.max_plies);
+    ALLOC(d.rec_off, B * d.max_plies);
+    ALLOC(d.rec_ids, B * d.pi_cap);
+    ALLOC(d.rec_pi, B * d.pi_cap);
+    ALLOC(d.stats, B);
+    ALLOC(d.err, 4);
+    ALLOC(e->st_k, B);
+    ALLOC(e->st_visits, B * kMaxLegal);
+    ALLOC(e->st_rootn, B);
+    ALLOC(e->st_acts, B * kMaxLegal);
+    ALLOC(e->st_q, B * kMaxLegal);
+    ALLOC(e->st_p, B * kMaxLegal);
+    ALLOC(e->st_pi, B * kMaxLegal);
+    ALLOC(e->st_temps, B);
+    ALLOC(e->st_rowbase, B);
+    ALLOC(e->st_mask, B);
+    ALLOC(e->st_sq, 96);
+#undef ALLOC
+    if (he != hipSuccess) {
+        for (void *p : e->owned) (void)hipFree(p);
+        const size_t got = e->bytes;
+        delete e;
+        return fail(-2, "ccz_create: device allocation failed after %zu bytes: %s", got, hipGetErrorString(he));
+    }
+    e->h_meta.resize(B);
+    hipLaunchKernelGGL(k_reset, dim3(d.B), dim3(64), 0, 0, d, (const uint8_t *)nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    *out = e;
+    return 0;
+}
+
+int ccz_destroy(ccz_engine *e)
+{
+    if (!e) return 0;
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (void *p : e->owned) (void)hipFree(p);
+    delete e;
+    return 0;
+}
+
+#define NEED(e) do { if (!(e)) return fail(-1, "%s: null engine", __func__); } while (0)
+
+int ccz_reset(ccz_engine *e, void *stream, const uint8_t *mask_host)
+{
+    NEED(e);
+    hipStream_t s = (hipStream_t)stream;
+    const uint8_t *mask = nullptr;
+    if (mask_host) {
+        HIP_TRY(hipMemcpyAsync(e->st_mask, mask_host, (size_t)e->d.B, hipMemcpyHostToDevice, s));
+        mask = e->st_mask;
+    }
+    hipLaunchKernelGGL(k_reset, dim3(e->d.B), dim3(64), 0, s, e->d, mask);
+    HIP_TRY(hipGetLastError());
+    if (mask_host) HIP_TRY(hipStreamSynchronize(s)); // st_mask is reused by the next call
+    return 0;
+}
+
+int ccz_set_position(ccz_engine *e, void *stream, int32_t board, const uint8_t *sq_host, int32_t turn, int32_t halfmove)
+{
+    NEED(e);
+    if (board < 0 || board >= e->d.B || !sq_host) return fail(-1, "ccz_set_position: bad board index or null squares");
+    int kings[2] = {0, 0};
+    for (int i = 0; i < 90; ++i) {
+        const int pc = sq_host[i];
+        if (pc > 15 || pc == 8) return fail(-1, "ccz_set_position: bad piece code %d on square %d", pc, i);
+        if ((pc & 7) == KING && pc) kings[pc >> 3]++;
+    }
+    if (kings[0] != 1 || kings[1] != 1) return fail(-1, "ccz_set_position: each side needs exactly one king");
+    if (halfmove < 0) return fail(-1, "ccz_set_position: negative halfmove clock");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(e->st_sq, sq_host, 90, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_set_position, dim3(1), dim3(64), 0, s, e->d, board, (const uint8_t *)e->st_sq, turn ? 1 : 0, halfmove);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+int ccz_zero_leaf_input(ccz_engine *e, void *stream, void *leaf_input_f16_dev)
+{
+    NEED(e);
+    if (!leaf_input_f16_dev) return fail(-1, "ccz_zero_leaf_input: null buffer");
+    HIP_TRY(hipMemsetAsync(leaf_input_f16_dev, 0, (size_t)e->d.B * CCZ_PLANES * 2, (hipStream_t)stream));
+    return 0;
+}
+
+int ccz_select_leaves(ccz_engine *e, void *stream, void *leaf_input_f16_dev)
+{
+    NEED(e);
+    hipLaunchKernelGGL(k_select, dim3(e->d.B), dim3(64), 0, (hipStream_t)stream, e->d, (uint16_t *)leaf_input_f16_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ccz_expand_backup(ccz_engine *e, void *stream, const float *prob_dev, const float *value_dev)
+{
+    NEED(e);
+    if (!prob_dev || !value_dev) return fail(-1, "ccz_expand_backup: null prob/value");
+    hipLaunchKernelGGL(k_expand_backup, dim3(e->d.B), dim3(64), 0, (hipStream_t)stream, e->d, prob_dev, value_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ccz_finish_move(ccz_engine *e, void *stream, const int32_t *forced_moves_dev, const double *temps_dev,
+                    int32_t *moves_out_dev, int32_t keep_tree)
+{
+    NEED(e);
+    hipLaunchKernelGGL(k_finish_move, dim3(e->d.B), dim3(64), 0, (hipStream_t)stream, e->d, forced_moves_dev, temps_dev,
+                       moves_out_dev, keep_tree ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ccz_root_children(ccz_engine *e, void *stream, int32_t *k_host, uint16_t *acts_host, int32_t *visits_host,
+                      float *q_host, float *prior_host, int32_t *root_visits_host)
+{
+    NEED(e);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t B = (size_t)e->d.B;
+    hipLaunchKernelGGL(k_root_children, dim3(e->d.B), dim3(64), 0, s, e->d, e->st_k, e->st_acts, e->st_visits, e->st_q, e->st_p,
+                       e->st_rootn, (const double *)nullptr, (double *)nullptr);
+    HIP_TRY(hipGetLastError());
+    if (k_host) HIP_TRY(hipMemcpyAsync(k_host, e->st_k, B * 4, hipMemcpyDeviceToHost, s));
+    if (acts_host) HIP_TRY(hipMemcpyAsync(acts_host, e->st_acts, B * kMaxLegal * 2, hipMemcpyDeviceToHost, s));
+    if (visits_host) HIP_TRY(hipMemcpyAsync(visits_host, e->st_visits, B * kMaxLegal * 4, hipMemcpyDeviceToHost, s));
+    if (q_host) HIP_TRY(hipMemcpyAsync(q_host, e->st_q, B * kMaxLegal * 4, hipMemcpyDeviceToHost, s));
+    if (prior_host) HIP_TRY(hipMemcpyAsync(prior_host, e->st_p, B * kMaxLegal * 4, hipMemcpyDeviceToHost, s));
+    if (root_visits_host) HIP_TRY(hipMemcpyAsync(root_visits_host, e->st_rootn, B * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+int ccz_root_pi(ccz_engine *e, void *stream, const double *temps_host, double *pi_host)
+{
+    NEED(e);
+    if (!pi_host) return fail(-1, "ccz_root_pi: null output");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t B = (size_t)e->d.B;
+    const double *temps = nullptr;
+    if (temps_host) {
+        HIP_TRY(hipMemcpyAsync(e->st_temps, temps_host, B * 8, hipMemcpyHostToDevice, s));
+        temps = e->st_temps;
+    }
+    hipLaunchKernelGGL(k_root_children, dim3(e->d.B), dim3(64), 0, s, e->d, (int32_t *)nullptr, (uint16_t *)nullptr,
+                       (int32_t *)nullptr, (float *)nullptr, (float *)nullptr, (int32_t *)nullptr, temps, e->st_pi);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(pi_host, e->st_pi, B * kMaxLegal * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+static int fetch_meta(ccz_engine *e, hipStream_t s)
+{
+    HIP_TRY(hipMemcpyAsync(e->h_meta.data(), e->d.meta, (size_t)e->d.B * sizeof(BoardMeta), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+int ccz_game_status(ccz_engine *e, void *stream, uint8_t *over_host, int8_t *winner_host, int32_t *plies_host, uint8_t *turn_host)
+{
+    NEED(e);
+    const int rc = fetch_meta(e, (hipStream_t)stream);
+    if (rc) return rc;
+    for (int b = 0; b < e->d.B; ++b) {
+        const BoardMeta &m = e->h_meta[b];
+        if (over_host) over_host[b] = m.over;
+        if (winner_host) winner_host[b] = m.winner;
+        if (plies_host) plies_host[b] = m.ply;
+        if (turn_host) turn_host[b] = m.turn;
+    }
+    return 0;
+}
+
+int ccz_root_positions(ccz_engine *e, void *stream, uint8_t *sq_host)
+{
+    NEED(e);
+    if (!sq_host) return fail(-1, "ccz_root_positions: null output");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(sq_host, e->d.root_sq, (size_t)e->d.B * 96, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+int ccz_leaf_info(ccz_engine *e, void *stream, uint8_t *status_host, int32_t *k_host, uint16_t *ids_host, int32_t *depth_host)
+{
+    NEED(e);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t B = (size_t)e->d.B;
+    if (status_host) HIP_TRY(hipMemcpyAsync(status_host, e->d.leaf_status, B, hipMemcpyDeviceToHost, s));
+    if (k_host) HIP_TRY(hipMemcpyAsync(k_host, e->d.leaf_k, B * 4, hipMemcpyDeviceToHost, s));
+    if (ids_host) HIP_TRY(hipMemcpyAsync(ids_host, e->d.leaf_ids, B * kMaxLegal * 2, hipMemcpyDeviceToHost, s));
+    if (depth_host) HIP_TRY(hipMemcpyAsync(depth_host, e->d.path_len, B * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+int ccz_harvest_rows(ccz_engine *e, void *stream, int64_t *rows_host)
+{
+    NEED(e);
+    if (!rows_host) return fail(-1, "ccz_harvest_rows: null output");
+    const int rc = fetch_meta(e, (hipStream_t)stream);
+    if (rc) return rc;
+    const int mul = (e->d.flags & CCZ_FLAG_NO_MIRROR) ? 1 : 2;
+    int64_t rows = 0;
+    for (int b = 0; b < e->d.B; ++b)
+        if (e->h_meta[b].over) rows += (int64_t)e->h_meta[b].ply * mul;
+    *rows_host = rows;
+    return 0;
+}
+
+int ccz_harvest(ccz_engine *e, void *stream, void *states_f16_dev, float *pi_dev, float *z_dev, int64_t capacity_rows,
+                int64_t *rows_host)
+{
+    NEED(e);
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = fetch_meta(e, s);
+    if (rc) return rc;
+    const int B = e->d.B;
+    const int mul = (e->d.flags & CCZ_FLAG_NO_MIRROR) ? 1 : 2;
+    std::vector<long long> base((size_t)B, -1);
+    std::vector<uint8_t> mask((size_t)B, 0);
+    int64_t rows = 0;
+    for (int b = 0; b < B; ++b)
+        if (e->h_meta[b].over) {
+            base[b] = rows;
+            mask[b] = 1;
+            rows += (int64_t)e->h_meta[b].ply * mul;
+        }
+    if (rows_host) *rows_host = rows;
+    if (rows == 0) {
+        // finished games without records (cannot happen in self-play) are simply restarted
+        bool any = false;
+        for (int b = 0; b < B; ++b) any = any || mask[b];
+        if (!any) return 0;
+    }
+    if (rows > capacity_rows) return fail(-5, "ccz_harvest: %lld rows needed, capacity %lld", (long long)rows, (long long)capacity_rows);
+    if (rows > 0 && (!states_f16_dev || !pi_dev || !z_dev)) return fail(-1, "ccz_harvest: null output buffer");
+    if (rows > 0) {
+        HIP_TRY(hipMemcpyAsync(e->st_rowbase, base.data(), (size_t)B * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_harvest, dim3(B), dim3(256), 0, s, e->d, (const long long *)e->st_rowbase,
+                           (uint16_t *)states_f16_dev, pi_dev, z_dev);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemcpyAsync(e->st_mask, mask.data(), (size_t)B, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_reset, dim3(B), dim3(64), 0, s, e->d, (const uint8_t *)e->st_mask);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+int ccz_get_stats(ccz_engine *e, void *stream, ccz_stats *out)
+{
+    NEED(e);
+    if (!out) return fail(-1, "ccz_get_stats: null output");
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<BoardStats> st((size_t)e->d.B);
+    int32_t err = 0;
+    HIP_TRY(hipMemcpyAsync(st.data(), e->d.stats, st.size() * sizeof(BoardStats), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&err, e->d.err, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    memset(out, 0, sizeof *out);
+    for (const BoardStats &b : st) {
+        out->sims += (int64_t)b.sims;
+        out->moves += (int64_t)b.moves;
+        out->games += (int64_t)b.games;
+        out->truncated_games += (int64_t)b.truncated;
+        out->sum_depth += (int64_t)b.sum_depth;
+        out->sum_children += (int64_t)b.sum_children;
+        out->expansions += (int64_t)b.expansions;
+        out->terminal_leaves += (int64_t)b.terminal;
+        if (b.nodes_peak > out->nodes_peak) out->nodes_peak = b.nodes_peak;
+        if (b.depth_peak > out->depth_peak) out->depth_peak = b.depth_peak;
+    }
+    out->error_flags = err;
+    out->hbm_bytes = (int64_t)e->bytes;
+    return 0;
+}
+
+int ccz_legal_moves(void *stream, int32_t n, const uint8_t *sq_dev, const uint8_t *turn_dev, const int32_t *halfmove_dev,
+                    uint32_t *mask_dev, int32_t *count_dev, uint8_t *flags_dev)
+{
+    if (n < 0 || !sq_dev || !turn_dev) return fail(-1, "ccz_legal_moves: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_legal_moves, dim3(n), dim3(64), 0, (hipStream_t)stream, n, sq_dev, turn_dev, halfmove_dev, mask_dev,
+                       count_dev, flags_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ccz_apply_moves(void *stream, int32_t n, uint8_t *sq_dev, uint8_t *turn_dev, const int32_t *move_ids_dev, uint8_t *captured_dev)
+{
+    if (n < 0 || !sq_dev || !turn_dev || !move_ids_dev) return fail(-1, "ccz_apply_moves: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_apply_moves, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, sq_dev, turn_dev, move_ids_dev,
+                       captured_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+} // extern "C"

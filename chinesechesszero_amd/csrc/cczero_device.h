@@ -1,0 +1,402 @@
+// cczero_device.h -- device-side building blocks of the gfx950 lockstep engine.
+//
+// One 64-lane wavefront owns one board; every workgroup is exactly one wavefront, so
+// __syncthreads() is a wave-level LDS fence and is legal in any wave-uniform control flow.
+// All floating-point code here is contraction-free (-ffp-contract=off) and uses only IEEE
+// + - * / sqrt, so it reproduces the reference's NumPy arithmetic (PUCT, incremental mean) and the
+// deterministic sampler bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cczero_tables.h"
+
+namespace ccz {
+
+__constant__ Tables c_tab = make_tables();
+
+enum : int { PAWN = 1, CANNON = 2, ROOK = 3, KNIGHT = 4, BISHOP = 5, ADVISOR = 6, KING = 7 };
+
+constexpr int kMaxLegal = 128;
+constexpr int kMaskWords = 66;
+constexpr int kChainCap = 128;
+constexpr int kPseudoCap = 256;
+constexpr uint64_t kTurnKey = 0x9D39247E33776D41ull;
+
+struct __align__(16) NodeA { // 16 B: what PUCT select reads per child in one dwordx4 load
+    int32_t N;  // visits           (mcts.py:16)
+    float Q;    // value, float32   (mcts.py:15; NumPy float32 arithmetic, mcts.py:63-71)
+    float P;    // prior, float32   (mcts.py:17)
+    int32_t fc; // pool index of the first child, -1 while unexpanded
+};
+// nodeB word: move id (low 16 bits) | number of children (high 16 bits)
+
+struct __align__(8) BoardMeta {
+    uint64_t key;          // Zobrist key of the root position (incl. side to move)
+    int32_t halfmove;      // plies since the last capture
+    int32_t chain_len;     // keys since the last capture, incl. the root position
+    int32_t ply;           // plies played in the current game == records stored
+    uint32_t move_counter; // moves ever played on this slot (RNG counter)
+    int32_t n_nodes;       // nodes in use in the active pool half
+    uint8_t turn;          // 1 RED, 0 BLACK
+    uint8_t over;          // 1: game finished, waiting for harvest
+    int8_t winner;         // 1 RED, 0 BLACK, -1 draw
+    uint8_t half;          // active pool half
+    uint32_t pi_used;      // entries used in the pi record arena
+    uint32_t game_no;
+};
+
+struct BoardStats {
+    unsigned long long sims, moves, games, truncated, sum_depth, sum_children, expansions, terminal;
+    int32_t nodes_peak, depth_peak;
+};
+
+struct Dev {
+    int32_t B, cap, maxd, max_plies, pi_cap;
+    float c_puct;
+    double eps, alpha, temp;
+    uint32_t flags;
+    uint64_t seed, board_id_base;
+    NodeA *nodeA;      // [B][2][cap]
+    uint32_t *nodeB;   // [B][2][cap]
+    BoardMeta *meta;   // [B]
+    uint8_t *root_sq;  // [B][96]
+    uint64_t *chain;   // [B][128]
+    int32_t *path;     // [B][maxd]
+    int32_t *path_len; // [B] depth of the leaf (path holds depth+1 nodes)
+    uint16_t *leaf_ids;   // [B][128]
+    int32_t *leaf_k;      // [B]
+    uint8_t *leaf_status; // [B]
+    uint8_t *rec_sq;   // [B][max_plies][96] root position before each move
+    uint8_t *rec_turn; // [B][max_plies]
+    uint8_t *rec_k;    // [B][max_plies]
+    uint32_t *rec_off; // [B][max_plies] offset into the pi arena
+    uint16_t *rec_ids; // [B][pi_cap]
+    float *rec_pi;     // [B][pi_cap]
+    BoardStats *stats; // [B]
+    int32_t *err;      // [1] sticky error bits
+};
+
+#define CCZ_LEAF_SKIP 3
+
+// ------------------------------------------------------------------ small helpers
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint64_t zob(int pc, int sq)
+{
+    return mix64(0x9E3779B97F4A7C15ull * (uint64_t)(pc * 90 + sq + 1));
+}
+__device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------ rules
+struct GenScratch {
+    uint8_t plist[16];
+    uint8_t cand[64 * 10];
+    uint16_t list[kPseudoCap];
+    uint32_t mask[kMaskWords + 2];
+};
+
+// Is the king of the side `turn` (1 RED / 0 BLACK), standing on ksq, attacked on the board that
+// results from moving `mover` from `from` to `to` (from < 0: the board as it is)? Includes the
+// facing-kings rule. Reverse rays from the king square.
+__device__ inline bool king_attacked(const uint8_t *sq, int ksq, int from, int to, int mover, int turn)
+{
+    const int eb = turn ? 8 : 0; // enemy piece-code base
+    const int eR = eb + ROOK, eC = eb + CANNON, eK = eb + KING, eN = eb + KNIGHT, eP = eb + PAWN;
+    const int r = ksq / 9, f = ksq - 9 * r;
+#define AT(S) ((S) == from ? 0 : ((S) == to ? mover : (int)sq[S]))
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int dr = (d == 0) - (d == 1), df = (d == 2) - (d == 3);
+        int r2 = r + dr, f2 = f + df;
+        bool seen = false;
+        while ((unsigned)r2 < 10u && (unsigned)f2 < 9u) {
+            const int s2 = f2 + 9 * r2;
+            const int q = AT(s2);
+            if (q) {
+                if (!seen) {
+                    if (q == eR || (q == eK && df == 0)) return true;
+                    seen = true;
+                } else {
+                    if (q == eC) return true;
+                    break;
+                }
+            }
+            r2 += dr; f2 += df;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { // a knight's leg is the king's diagonal neighbour
+        const int a = (d & 2) ? -1 : 1, b = (d & 1) ? -1 : 1;
+        const int rl = r + a, fl = f + b;
+        if ((unsigned)rl >= 10u || (unsigned)fl >= 9u) continue;
+        const int sl = fl + 9 * rl;
+        if (AT(sl)) continue;
+        const int r2 = rl + a, f3 = fl + b;
+        if ((unsigned)r2 < 10u) { const int s2 = fl + 9 * r2; if (AT(s2) == eN) return true; }
+        if ((unsigned)f3 < 9u) { const int s3 = f3 + 9 * rl; if (AT(s3) == eN) return true; }
+    }
+    {
+        const int fw = turn ? -1 : 1; // direction of travel of the ENEMY pawns
+        const int rp = r - fw;
+        if ((unsigned)rp < 10u) { const int s2 = f + 9 * rp; if (AT(s2) == eP) return true; }
+        const bool crossed = turn ? (r <= 4) : (r >= 5); // enemy pawn on the king's rank is over the river
+        if (crossed) {
+            if (f > 0) { const int s2 = ksq - 1; if (AT(s2) == eP) return true; }
+            if (f < 8) { const int s2 = ksq + 1; if (AT(s2) == eP) return true; }
+        }
+    }
+#undef AT
+    return false;
+}
+
+struct GenResult {
+    int n_legal;
+    int ksq;
+    bool insufficient;
+    bool overflow;
+};
+
+// Legal moves of the side to move as a bitmask over the 2086 action ids (S.mask) and, if ids_out
+// is non-null, as an ascending id list (the canonical `board.legal_moves` order).
+// Lane 4p+d generates direction d of piece p; lane j then tests pseudo-move j for king safety.
+// Must be called by all 64 lanes of the wave.
+__device__ inline GenResult gen_legal(const uint8_t *sq, int turn, GenScratch &S, uint16_t *ids_out, int lane)
+{
+    GenResult R;
+    const int ownbit = turn ? 0 : 1;
+#define OWN(q) ((q) != 0 && (((q) >> 3) == ownbit))
+    const int p0 = sq[lane];
+    const int p1 = lane < 26 ? sq[64 + lane] : 0;
+    const bool o0 = OWN(p0), o1 = OWN(p1);
+    const uint64_t m0 = __ballot(o0), m1 = __ballot(o1);
+    const int n0 = __popcll(m0);
+    int npieces = n0 + __popcll(m1);
+    {
+        const int i0 = __popcll(m0 & lanemask_lt(lane)), i1 = n0 + __popcll(m1 & lanemask_lt(lane));
+        if (o0 && i0 < 16) S.plist[i0] = (uint8_t)lane;
+        if (o1 && i1 < 16) S.plist[i1] = (uint8_t)(64 + lane);
+    }
+    R.overflow = npieces > 16;
+    if (npieces > 16) npieces = 16;
+    const int kc = turn ? KING : KING + 8;
+    const uint64_t k0 = __ballot(p0 == kc), k1 = __ballot(p1 == kc);
+    R.ksq = k0 ? (__ffsll((long long)k0) - 1) : (k1 ? 64 + (__ffsll((long long)k1) - 1) : -1);
+    {
+        const int t0 = p0 & 7, t1 = p1 & 7;
+        const bool a0 = p0 != 0 && t0 >= PAWN && t0 <= KNIGHT, a1 = p1 != 0 && t1 >= PAWN && t1 <= KNIGHT;
+        R.insufficient = (__ballot(a0) | __ballot(a1)) == 0ull;
+    }
+    for (int w = lane; w < kMaskWords + 2; w += 64) S.mask[w] = 0u;
+    __syncthreads();
+
+    // ---- phase B: pseudo-legal generation, lane = 4*piece + direction
+    int cnt = 0, from = 0;
+    uint8_t *out = S.cand + lane * 10;
+    const int p = lane >> 2, d = lane & 3;
+    if (p < npieces) {
+        from = S.plist[p];
+        const int pc = sq[from], t = pc & 7;
+        const int r = from / 9, f = from - 9 * r;
+        const int dr = (d == 0) - (d == 1), df = (d == 2) - (d == 3); // orthogonal step
+        const int a = (d & 2) ? -1 : 1, b = (d & 1) ? -1 : 1;         // diagonal step
+        if (t == ROOK || t == CANNON) {
+            int r2 = r + dr, f2 = f + df;
+            bool jumped = false;
+            while ((unsigned)r2 < 10u && (unsigned)f2 < 9u) {
+                const int s2 = f2 + 9 * r2, q = sq[s2];
+                if (!jumped) {
+                    if (!q) out[cnt++] = (uint8_t)s2;
+                    else {
+                        if (t == ROOK) { if (!OWN(q)) out[cnt++] = (uint8_t)s2; break; }
+                        jumped = true; // the cannon's screen
+                    }
+                } else if (q) {
+                    if (!OWN(q)) out[cnt++] = (uint8_t)s2;
+                    break;
+                }
+                r2 += dr; f2 += df;
+            }
+        } else if (t == KNIGHT) {
+            const int rl = r + dr, fl = f + df;
+            if ((unsigned)rl < 10u && (unsigned)fl < 9u && sq[fl + 9 * rl] == 0) {
+#pragma unroll
+                for (int j = -1; j <= 1; j += 2) {
+                    const int r2 = r + 2 * dr + (dr ? 0 : j), f2 = f + 2 * df + (df ? 0 : j);
+                    if ((unsigned)r2 < 10u && (unsigned)f2 < 9u) {
+                        const int s2 = f2 + 9 * r2, q = sq[s2];
+                        if (!OWN(q)) out[cnt++] = (uint8_t)s2;
+                    }
+                }
+            }
+        } else if (t == BISHOP) {
+            const int r2 = r + 2 * a, f2 = f + 2 * b;
+            if ((unsigned)r2 < 10u && (unsigned)f2 < 9u && (turn ? r2 <= 4 : r2 >= 5) && sq[(f + b) + 9 * (r + a)] == 0) {
+                const int s2 = f2 + 9 * r2, q = sq[s2];
+                if (!OWN(q)) out[cnt++] = (uint8_t)s2;
+            }
+        } else if (t == ADVISOR || t == KING) {
+            const int r2 = t == KING ? r + dr : r + a, f2 = t == KING ? f + df : f + b;
+            const bool palace = f2 >= 3 && f2 <= 5 && (turn ? (r2 >= 0 && r2 <= 2) : (r2 >= 7 && r2 <= 9));
+            if (palace) {
+                const int s2 = f2 + 9 * r2, q = sq[s2];
+                if (!OWN(q)) out[cnt++] = (uint8_t)s2;
+            }
+        } else if (t == PAWN) {
+            const int fw = turn ? 1 : -1;
+            const bool crossed = turn ? r >= 5 : r <= 4;
+            int r2 = -1, f2 = -1;
+            if (d == 0) { r2 = r + fw; f2 = f; }
+            else if (d == 1 && crossed) { r2 = r; f2 = f - 1; }
+            else if (d == 2 && crossed) { r2 = r; f2 = f + 1; }
+            if ((unsigned)r2 < 10u && (unsigned)f2 < 9u) {
+                const int s2 = f2 + 9 * r2, q = sq[s2];
+                if (!OWN(q)) out[cnt++] = (uint8_t)s2;
+            }
+        }
+    }
+    const int incl = wave_incl_scan(cnt, lane);
+    int npseudo = __shfl(incl, 63);
+    const int excl = incl - cnt;
+    if (npseudo > kPseudoCap) { R.overflow = true; npseudo = kPseudoCap; }
+    for (int i = 0; i < cnt; ++i)
+        if (excl + i < kPseudoCap) S.list[excl + i] = (uint16_t)((from << 8) | out[i]);
+    __syncthreads();
+
+    // ---- phase C: king safety, lane per pseudo-move
+    for (int j = lane; j < npseudo; j += 64) {
+        const int fr = S.list[j] >> 8, to = S.list[j] & 0xff;
+        const int mover = sq[fr];
+        const int ksq = (mover & 7) == KING ? to : R.ksq;
+        if (ksq >= 0 && !king_attacked(sq, ksq, fr, to, mover, turn)) {
+            const uint32_t id = c_tab.inv[fr * 90 + to];
+            if (id < (uint32_t)kNMoves) atomicOr(&S.mask[id >> 5], 1u << (id & 31));
+        }
+    }
+    __syncthreads();
+
+    // ---- phase D: count and list in ascending id order
+    const uint32_t w0 = S.mask[lane];
+    const uint32_t w1 = lane < 2 ? S.mask[64 + lane] : 0u;
+    const int c0 = __popc(w0), c1 = __popc(w1);
+    const int incl0 = wave_incl_scan(c0, lane);
+    const int total0 = __shfl(incl0, 63);
+    const int c64 = __shfl(c1, 0), c65 = __shfl(c1, 1);
+    R.n_legal = total0 + c64 + c65;
+    if (R.n_legal > kMaxLegal) R.overflow = true;
+    if (ids_out) {
+        int o = incl0 - c0;
+        uint32_t w = w0;
+        while (w) {
+            const int bit = __ffs((int)w) - 1;
+            w &= w - 1;
+            if (o < kMaxLegal) ids_out[o] = (uint16_t)(lane * 32 + bit);
+            ++o;
+        }
+        if (lane < 2) {
+            o = total0 + (lane ? c64 : 0);
+            w = w1;
+            while (w) {
+                const int bit = __ffs((int)w) - 1;
+                w &= w - 1;
+                if (o < kMaxLegal) ids_out[o] = (uint16_t)((64 + lane) * 32 + bit);
+                ++o;
+            }
+        }
+    }
+#undef OWN
+    return R;
+}
+
+// ------------------------------------------------------------------ deterministic math (twin of oracle/xq_sample.c)
+__device__ inline double det_log(double x)
+{
+    const uint64_t u = (uint64_t)__double_as_longlong(x);
+    int e = (int)((u >> 52) & 0x7ff) - 1023;
+    double m = __longlong_as_double((long long)((u & 0x000fffffffffffffull) | 0x3ff0000000000000ull));
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double s = (m - 1.0) / (m + 1.0);
+    const double s2 = s * s;
+    double acc = 1.0 / 27.0;
+    for (int i = 25; i >= 1; i -= 2) acc = acc * s2 + 1.0 / (double)i;
+    return (double)e * 0.6931471805599453 + 2.0 * s * acc;
+}
+
+__device__ inline double det_exp(double x)
+{
+    if (x < -708.0) return 0.0;
+    const double t = x * 1.4426950408889634 + 0.5;
+    const double n = floor(t);
+    const double r = x - n * 0.693147180369123816490 - n * 1.90821492927058770002e-10;
+    double acc = 1.0;
+    for (int i = 14; i >= 1; --i) acc = acc * r / (double)i + 1.0;
+    const int ni = (int)n;
+    if (ni < -1022) return 0.0;
+    return acc * __longlong_as_double((long long)((uint64_t)(ni + 1023) << 52));
+}
+
+__device__ inline void philox4x32(uint64_t key, uint64_t ctr_hi, uint64_t ctr_lo, uint32_t o[4])
+{
+    uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32), c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
+    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+__device__ inline void uniform2(uint64_t seed, uint64_t board, uint64_t move_no, uint32_t child, uint32_t draw, double &ua, double &ub)
+{
+    uint32_t o[4];
+    const uint64_t lo = (move_no << 32) | ((uint64_t)(child & 0xfffu) << 20) | (uint64_t)(draw & 0xfffffu);
+    philox4x32(seed, board, lo, o);
+    ua = (double)(2 * ((((uint64_t)o[0] << 32) | o[1]) >> 12) + 1) * 1.1102230246251565e-16;
+    ub = (double)(2 * ((((uint64_t)o[2] << 32) | o[3]) >> 12) + 1) * 1.1102230246251565e-16;
+}
+
+// Gamma(alpha,1), alpha < 1 (Dirichlet component of mcts.py:220): Marsaglia-Tsang on alpha+1 with
+// polar normals and the U^(1/alpha) boost; bounded loop so that every wave terminates.
+__device__ inline double det_gamma(uint64_t seed, uint64_t board, uint64_t move_no, uint32_t child, double alpha)
+{
+    const double d = (alpha + 1.0) - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    double ua, ub;
+    uint32_t j = 0;
+    while (j < 0xffff0u) {
+        double x1, x2, s;
+        for (;;) {
+            uniform2(seed, board, move_no, child, j++, ua, ub);
+            x1 = 2.0 * ua - 1.0; x2 = 2.0 * ub - 1.0;
+            s = x1 * x1 + x2 * x2;
+            if ((s < 1.0 && s > 0.0) || j >= 0xffff0u) break;
+        }
+        const double z = x1 * sqrt(-2.0 * det_log(s) / s);
+        double v = 1.0 + c * z;
+        if (v <= 0.0) continue;
+        v = v * v * v;
+        uniform2(seed, board, move_no, child, j++, ua, ub);
+        if (det_log(ua) < 0.5 * z * z + d - d * v + d * det_log(v))
+            return d * v * det_exp(det_log(ub) / alpha);
+    }
+    return 0.0;
+}
+
+} // namespace ccz

@@ -1,0 +1,628 @@
+// cczero_kernels.h -- the gfx950 kernels of the lockstep self-play engine (one wave per board).
+#pragma once
+#include "cczero_device.h"
+
+namespace ccz {
+
+constexpr uint16_t kHalfOne = 0x3C00; // fp16 1.0
+
+__device__ __forceinline__ void set_err(const Dev &D, int bit) { atomicOr(D.err, bit); }
+
+// ------------------------------------------------------------------ new game / set position
+// Start position: rank 0 = RNBAKABNR (red), rank 2 cannons b,h, rank 3 pawns a,c,e,g,i; black mirrored.
+__device__ __forceinline__ int start_piece(int s)
+{
+    const int r = s / 9, f = s - 9 * r;
+    const int rr = r <= 4 ? r : 9 - r; // distance from the own back rank
+    const int add = r <= 4 ? 0 : 8;
+    int t = 0;
+    if (rr == 0) {
+        const int ff = f <= 4 ? f : 8 - f;
+        t = ff == 0 ? ROOK : ff == 1 ? KNIGHT : ff == 2 ? BISHOP : ff == 3 ? ADVISOR : KING;
+    } else if (rr == 2) {
+        t = (f == 1 || f == 7) ? CANNON : 0;
+    } else if (rr == 3) {
+        t = (f & 1) ? 0 : PAWN;
+    }
+    return t ? t + add : 0;
+}
+
+// (re)initialise board b from D.root_sq[b] / the given turn+halfmove: key, chain, fresh tree, empty record
+__device__ inline void init_board(const Dev &D, int b, int lane, int turn, int halfmove, bool new_game_no)
+{
+    const uint8_t *sq = D.root_sq + (size_t)b * 96;
+    uint64_t k = 0;
+    for (int s = lane; s < 90; s += 64) {
+        const int pc = sq[s];
+        if (pc) k ^= zob(pc, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) k ^= __shfl_xor(k, o);
+    if (turn) k ^= kTurnKey;
+    if (lane == 0) {
+        BoardMeta m = D.meta[b];
+        m.key = k;
+        m.halfmove = halfmove;
+        m.chain_len = 1;
+        m.ply = 0;
+        m.n_nodes = 1;
+        m.turn = (uint8_t)turn;
+        m.over = 0;
+        m.winner = -1;
+        m.pi_used = 0;
+        if (new_game_no) m.game_no += 1;
+        D.meta[b] = m;
+        D.chain[(size_t)b * kChainCap] = k;
+        const size_t base = ((size_t)b * 2 + m.half) * (size_t)D.cap;
+        D.nodeA[base] = NodeA{0, 0.0f, 1.0f, -1}; // Node(None, 1.0)  mcts.py:94
+        D.nodeB[base] = 0u;
+        D.path_len[b] = 0;
+        D.leaf_status[b] = CCZ_LEAF_SKIP;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_reset(Dev D, const uint8_t *mask)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (mask && !mask[b]) return;
+    uint8_t *sq = D.root_sq + (size_t)b * 96;
+    for (int s = lane; s < 96; s += 64) sq[s] = s < 90 ? (uint8_t)start_piece(s) : 0;
+    __syncthreads();
+    init_board(D, b, lane, 1, 0, true);
+}
+
+__global__ __launch_bounds__(64) void k_set_position(Dev D, int b, const uint8_t *sq_in, int turn, int halfmove)
+{
+    const int lane = threadIdx.x;
+    uint8_t *sq = D.root_sq + (size_t)b * 96;
+    for (int s = lane; s < 96; s += 64) sq[s] = s < 90 ? sq_in[s] : 0;
+    __syncthreads();
+    init_board(D, b, lane, turn, halfmove, true);
+}
+
+// ------------------------------------------------------------------ leaf evaluation shared by select and finish_move
+struct LeafEval {
+    int n_legal;
+    int status; // CCZ_LEAF_*
+    bool tie;
+};
+
+// s_chain[0..chain_len) holds the keys since the last capture incl. the current position (last)
+__device__ inline LeafEval eval_position(const uint8_t *s_sq, int turn, int halfmove, uint64_t key,
+                                         const uint64_t *s_chain, int chain_len, GenScratch &S,
+                                         uint16_t *ids_out, int lane, bool &overflow)
+{
+    const GenResult g = gen_legal(s_sq, turn, S, ids_out, lane);
+    overflow = g.overflow;
+    int rep = 0;
+    for (int i0 = 0; i0 < chain_len; i0 += 64) {
+        const int i = i0 + lane;
+        rep += __popcll(__ballot(i < chain_len && s_chain[i] == key));
+    }
+    // tools.py:109-123 is_tie = insufficient material or fourfold repetition or sixty moves
+    const bool sixty = halfmove >= 120 && g.n_legal > 0;
+    LeafEval L;
+    L.n_legal = g.n_legal;
+    L.tie = g.insufficient || rep >= 4 || sixty;
+    // mcts.py:116-126: not end and not tie -> expand ; end and tie -> 0.0 ; else side to move lost
+    if (g.n_legal == 0) L.status = L.tie ? CCZ_LEAF_DRAW : CCZ_LEAF_LOSS;
+    else L.status = L.tie ? CCZ_LEAF_DRAW : CCZ_LEAF_EXPAND;
+    return L;
+}
+
+// ------------------------------------------------------------------ K1: select + make-move + movegen + terminal + encode
+__global__ __launch_bounds__(64) void k_select(Dev D, uint16_t *leaf_in)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    __shared__ __align__(16) uint8_t s_sq[96];
+    __shared__ uint64_t s_chain[kChainCap];
+    __shared__ GenScratch S;
+
+    const BoardMeta m = D.meta[b];
+    if (m.over) {
+        if (lane == 0) D.leaf_status[b] = CCZ_LEAF_SKIP;
+        return;
+    }
+    if (lane < 24) ((uint32_t *)s_sq)[lane] = ((const uint32_t *)(D.root_sq + (size_t)b * 96))[lane];
+    for (int i = lane; i < m.chain_len; i += 64) s_chain[i] = D.chain[(size_t)b * kChainCap + i];
+    __syncthreads();
+
+    const size_t base = ((size_t)b * 2 + m.half) * (size_t)D.cap;
+    const NodeA *A = D.nodeA + base;
+    const uint32_t *Bn = D.nodeB + base;
+    int32_t *path = D.path + (size_t)b * D.maxd;
+    int node = 0, depth = 0, turn = m.turn, halfmove = m.halfmove, chain_len = m.chain_len;
+    uint64_t key = m.key;
+    bool bad = false;
+    if (lane == 0) path[0] = 0;
+
+    // ---- PUCT descent (mcts.py:105-111, 41-61)
+    for (;;) {
+        const int nc = (int)(Bn[node] >> 16);
+        if (nc == 0) break;
+        const NodeA pa = A[node];
+        const double sqrtNp = sqrt((double)pa.N); // np.sqrt(parent.visits): float64
+        double best = -__builtin_huge_val();
+        int besti = 0x7fffffff;
+        for (int c0 = 0; c0 < nc; c0 += 64) {
+            const int i = c0 + lane;
+            if (i < nc) {
+                const NodeA c = A[pa.fc + i];
+                // value + c_puct*prob*sqrt(N_parent)/(1+N): float32 product, float64 elsewhere; inf if unvisited
+                const double sc = c.N == 0 ? __builtin_huge_val()
+                                           : (double)c.Q + (double)(D.c_puct * c.P) * sqrtNp / (double)(1 + c.N);
+                if (sc > best) { best = sc; besti = i; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { // first maximum in insertion order wins (Python max())
+            const double ob = __shfl_xor(best, o);
+            const int oi = __shfl_xor(besti, o);
+            if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+        }
+        if (besti >= nc) { bad = true; set_err(D, 32); break; } // NaN priors: no comparable child
+        const int child = pa.fc + besti;
+        const int mv = (int)(Bn[child] & 0xffffu);
+        // board.push(move)  (mcts.py:111)
+        const int from = c_tab.from[mv], to = c_tab.to[mv];
+        const int pc = s_sq[from], cap = s_sq[to];
+        __syncthreads();
+        if (lane == 0) { s_sq[to] = (uint8_t)pc; s_sq[from] = 0; }
+        key ^= zob(pc, from) ^ zob(pc, to) ^ kTurnKey;
+        if (cap) key ^= zob(cap, to);
+        turn ^= 1;
+        if (cap) { halfmove = 0; chain_len = 0; } else ++halfmove;
+        if (chain_len >= kChainCap) { bad = true; set_err(D, 2); break; }
+        if (lane == 0) s_chain[chain_len] = key;
+        ++chain_len;
+        ++depth;
+        if (depth >= D.maxd) { bad = true; set_err(D, 2); break; }
+        if (lane == 0) path[depth] = child;
+        node = child;
+        __syncthreads();
+    }
+    __syncthreads();
+    if (bad) {
+        if (lane == 0) D.leaf_status[b] = CCZ_LEAF_SKIP;
+        return;
+    }
+
+    // ---- leaf: legal moves (net.py:154-157), game end (mcts.py:116-117)
+    bool overflow;
+    const LeafEval L = eval_position(s_sq, turn, halfmove, key, s_chain, chain_len, S,
+                                     D.leaf_ids + (size_t)b * kMaxLegal, lane, overflow);
+    if (overflow) set_err(D, 4);
+    if (lane == 0) {
+        D.path_len[b] = depth;
+        D.leaf_k[b] = L.n_legal > kMaxLegal ? kMaxLegal : L.n_legal;
+        D.leaf_status[b] = (uint8_t)L.status;
+        BoardStats &st = D.stats[b];
+        st.sum_depth += (unsigned long long)depth;
+        if (depth > st.depth_peak) st.depth_peak = depth;
+    }
+
+    // ---- evaluator input (net.py:160-177): groups 7 (red now), 15 (black now), 16 (side to move)
+    if (leaf_in) {
+        uint32_t *row = (uint32_t *)(leaf_in + (size_t)b * 10710);
+        for (int i = lane; i < 945; i += 64) {
+            const int region = i / 315, w = i - region * 315;
+            uint32_t v;
+            if (region == 2) {
+                v = turn ? 0x3C003C00u : 0u;
+            } else {
+                const int add = region ? 8 : 0;
+                const int j0 = 2 * w, j1 = j0 + 1;
+                const int ch0 = j0 / 90, s0 = j0 - 90 * ch0, ch1 = j1 / 90, s1 = j1 - 90 * ch1;
+                v = (s_sq[s0] == ch0 + 1 + add ? 0x3C00u : 0u) | (s_sq[s1] == ch1 + 1 + add ? 0x3C000000u : 0u);
+            }
+            const int off = (region == 0 ? 2205 : region == 1 ? 4725 : 5040) + w;
+            row[off] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ K2: expand + backup
+__global__ __launch_bounds__(64) void k_expand_backup(Dev D, const float *prob, const float *value)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int status = D.leaf_status[b];
+    if (status == CCZ_LEAF_SKIP) return;
+    BoardMeta *mp = D.meta + b;
+    const int half = mp->half;
+    const size_t base = ((size_t)b * 2 + half) * (size_t)D.cap;
+    NodeA *A = D.nodeA + base;
+    uint32_t *Bn = D.nodeB + base;
+    const int32_t *path = D.path + (size_t)b * D.maxd;
+    const int d = D.path_len[b];
+    const int leaf = path[d];
+    float v;
+    if (status == CCZ_LEAF_EXPAND) {
+        // Node.expand (mcts.py:31-39): one child per legal id, ascending id order
+        const int k = D.leaf_k[b];
+        const int n0 = mp->n_nodes;
+        v = value[b];
+        if (n0 + k > D.cap) {
+            set_err(D, 1); // pool exhausted: the leaf stays unexpanded, the value is still backed up
+        } else {
+            const uint16_t *ids = D.leaf_ids + (size_t)b * kMaxLegal;
+            const float *pr = prob + (size_t)b * kNMoves;
+            for (int i = lane; i < k; i += 64) {
+                const int id = ids[i];
+                A[n0 + i] = NodeA{0, 0.0f, pr[id], -1};
+                Bn[n0 + i] = (uint32_t)id;
+            }
+            if (lane == 0) {
+                A[leaf].fc = n0;
+                Bn[leaf] = (Bn[leaf] & 0xffffu) | ((uint32_t)k << 16);
+                mp->n_nodes = n0 + k;
+                BoardStats &st = D.stats[b];
+                st.sum_children += (unsigned long long)k;
+                st.expansions += 1;
+                if (n0 + k > st.nodes_peak) st.nodes_peak = n0 + k;
+            }
+        }
+    } else {
+        v = status == CCZ_LEAF_DRAW ? 0.0f : -1.0f; // mcts.py:120-126
+        if (lane == 0) D.stats[b].terminal += 1;
+    }
+    if (lane == 0) D.stats[b].sims += 1;
+    // Node.update_recursive(-leaf_value) (mcts.py:73-78,129): leaf gets -v, its parent +v, ...
+    for (int j = lane; j <= d; j += 64) {
+        const int node = path[j];
+        const float val = ((d - j) & 1) ? v : -v;
+        int32_t *np_ = &A[node].N;
+        float *qp = &A[node].Q;
+        const int n = *np_ + 1;
+        const float q = *qp;
+        // visits += 1 ; value += 1.0*(leaf_value - value)/visits   in float32 (mcts.py:68-71)
+        float delta = val - q;
+        delta = delta / (float)n;
+        *np_ = n;
+        *qp = q + delta;
+    }
+}
+
+// ------------------------------------------------------------------ pi from root visits (mcts.py:162-166)
+// s_vis[k] -> s_pi[k] ; softmax(1/temp * log(N + 1e-10)) with the deterministic log/exp; the
+// normalising sum is accumulated sequentially (index order) to match the CPU twin bit for bit.
+__device__ inline void root_pi(const int32_t *s_vis, double *s_pi, int k, double temp, int lane)
+{
+    const double it = 1.0 / temp;
+    double mx = -__builtin_huge_val();
+    for (int i = lane; i < k; i += 64) {
+        const double x = it * det_log((double)s_vis[i] + 1e-10);
+        s_pi[i] = x;
+        if (x > mx) mx = x;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(mx, o); if (t > mx) mx = t; }
+    for (int i = lane; i < k; i += 64) s_pi[i] = det_exp(s_pi[i] - mx);
+    __syncthreads();
+    double sum = 0.0;
+    if (lane == 0) for (int i = 0; i < k; ++i) sum += s_pi[i];
+    sum = __shfl(sum, 0);
+    __syncthreads();
+    for (int i = lane; i < k; i += 64) s_pi[i] = s_pi[i] / sum;
+    __syncthreads();
+}
+
+__device__ __forceinline__ double board_temp(const Dev &D, const BoardMeta &m, const double *temps, int b)
+{
+    if (temps) return temps[b];
+    // game.py:157-159: move_count = ply+1 ; temp if move_count <= 30 else max(0.1, temp*0.5)
+    const double half = D.temp * 0.5;
+    return (m.ply + 1) <= 30 ? D.temp : (half > 0.1 ? half : 0.1);
+}
+
+__global__ __launch_bounds__(64) void k_root_children(Dev D, int32_t *k_out, uint16_t *acts, int32_t *visits,
+                                                        float *q, float *prior, int32_t *root_visits,
+                                                        const double *temps, double *pi_out)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    __shared__ int32_t s_vis[kMaxLegal];
+    __shared__ double s_pi[kMaxLegal];
+    const BoardMeta m = D.meta[b];
+    const size_t base = ((size_t)b * 2 + m.half) * (size_t)D.cap;
+    const NodeA *A = D.nodeA + base;
+    const uint32_t *Bn = D.nodeB + base;
+    const NodeA root = A[0];
+    int k = (int)(Bn[0] >> 16);
+    if (k > kMaxLegal) k = kMaxLegal;
+    if (lane == 0) {
+        if (k_out) k_out[b] = k;
+        if (root_visits) root_visits[b] = root.N;
+    }
+    for (int i = lane; i < kMaxLegal; i += 64) {
+        NodeA c = NodeA{0, 0.0f, 0.0f, -1};
+        uint32_t w = 0;
+        if (i < k) { c = A[root.fc + i]; w = Bn[root.fc + i]; }
+        s_vis[i] = c.N;
+        const size_t o = (size_t)b * kMaxLegal + i;
+        if (acts) acts[o] = (uint16_t)(w & 0xffffu);
+        if (visits) visits[o] = c.N;
+        if (q) q[o] = c.Q;
+        if (prior) prior[o] = c.P;
+    }
+    __syncthreads();
+    if (pi_out) {
+        if (k > 0) root_pi(s_vis, s_pi, k, board_temp(D, m, temps, b), lane);
+        for (int i = lane; i < kMaxLegal; i += 64) pi_out[(size_t)b * kMaxLegal + i] = i < k ? s_pi[i] : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------ K3: once per move
+__global__ __launch_bounds__(64) void k_finish_move(Dev D, const int32_t *forced, const double *temps,
+                                                      int32_t *moves_out, int keep_tree)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    __shared__ __align__(16) uint8_t s_sq[96];
+    __shared__ uint64_t s_chain[kChainCap];
+    __shared__ GenScratch S;
+    __shared__ int32_t s_vis[kMaxLegal];
+    __shared__ uint16_t s_act[kMaxLegal];
+    __shared__ double s_pi[kMaxLegal];
+    __shared__ double s_g[kMaxLegal];
+    __shared__ int32_t s_src[64], s_dst[64], s_cnt[64];
+    __shared__ int s_choice;
+
+    BoardMeta m = D.meta[b];
+    if (moves_out && lane == 0) moves_out[b] = -1;
+    if (m.over) return;
+    const size_t baseOld = ((size_t)b * 2 + m.half) * (size_t)D.cap;
+    const NodeA *A = D.nodeA + baseOld;
+    const uint32_t *Bn = D.nodeB + baseOld;
+    const NodeA root = A[0];
+    int k = (int)(Bn[0] >> 16);
+    if (k == 0 || k > kMaxLegal) { if (lane == 0) set_err(D, 16); return; }
+
+    if (lane < 24) ((uint32_t *)s_sq)[lane] = ((const uint32_t *)(D.root_sq + (size_t)b * 96))[lane];
+    for (int i = lane; i < k; i += 64) {
+        s_vis[i] = A[root.fc + i].N;
+        s_act[i] = (uint16_t)(Bn[root.fc + i] & 0xffffu);
+    }
+    __syncthreads();
+
+    // ---- pi (mcts.py:162-166) and the training record (game.py:195-198)
+    root_pi(s_vis, s_pi, k, board_temp(D, m, temps, b), lane);
+    if (m.ply >= D.max_plies || m.pi_used + (uint32_t)k > (uint32_t)D.pi_cap) {
+        // documented cap: the game is adjudicated a draw, its records so far stay valid
+        if (lane == 0) {
+            if (m.ply < D.max_plies) set_err(D, 8);
+            m.over = 1; m.winner = -1;
+            D.meta[b] = m;
+            D.stats[b].truncated += 1;
+            D.stats[b].games += 1;
+        }
+        return;
+    }
+    {
+        const size_t r = (size_t)b * D.max_plies + m.ply;
+        if (lane < 24) ((uint32_t *)(D.rec_sq + r * 96))[lane] = ((const uint32_t *)s_sq)[lane];
+        if (lane == 0) { D.rec_turn[r] = m.turn; D.rec_k[r] = (uint8_t)k; D.rec_off[r] = m.pi_used; }
+        const size_t po = (size_t)b * D.pi_cap + m.pi_used;
+        for (int i = lane; i < k; i += 64) { D.rec_ids[po + i] = s_act[i]; D.rec_pi[po + i] = (float)s_pi[i]; }
+    }
+
+    // ---- move choice (mcts.py:216-229)
+    const int want = forced ? forced[b] : -1;
+    if (want >= 0) {
+        int found = -1;
+        for (int i0 = 0; i0 < k; i0 += 64) {
+            const int i = i0 + lane;
+            const uint64_t hit = __ballot(i < k && s_act[i] == want);
+            if (hit && found < 0) found = i0 + __ffsll((long long)hit) - 1;
+        }
+        if (found < 0) { if (lane == 0) set_err(D, 16); return; }
+        if (lane == 0) s_choice = found;
+    } else {
+        // move ~ Categorical((1-EPS)*pi + EPS*Dirichlet(ALPHA)) on the board's Philox stream
+        const uint64_t gid = D.board_id_base + (uint64_t)b;
+        for (int i = lane; i < k; i += 64) s_g[i] = det_gamma(D.seed, gid, m.move_counter, (uint32_t)i, D.alpha);
+        __syncthreads();
+        if (lane == 0) {
+            double gs = 0.0, acc = 0.0, ua, ub;
+            for (int i = 0; i < k; ++i) gs += s_g[i];
+            for (int i = 0; i < k; ++i) {
+                const double dir = gs > 0.0 ? s_g[i] / gs : s_pi[i];
+                acc += (1.0 - D.eps) * s_pi[i] + D.eps * dir;
+                s_g[i] = acc; // cdf
+            }
+            uniform2(D.seed, gid, m.move_counter, 0xfffu, 0, ua, ub);
+            int idx = 0;
+            for (int i = 0; i < k; ++i) if (s_g[i] / acc <= ua) idx = i + 1; // searchsorted(side="right")
+            s_choice = idx < k ? idx : k - 1;
+        }
+    }
+    __syncthreads();
+    const int ci = s_choice;
+    const int mv = s_act[ci];
+    if (moves_out && lane == 0) moves_out[b] = mv;
+
+    // ---- MCTS.update_with_move (mcts.py:168-178): re-root on the chosen child, subtree copied
+    // breadth-first into the other pool half (children of a node stay contiguous)
+    const int nh = m.half ^ 1;
+    const size_t baseNew = ((size_t)b * 2 + nh) * (size_t)D.cap;
+    NodeA *NA = D.nodeA + baseNew;
+    uint32_t *NB = D.nodeB + baseNew;
+    int n_new = 1;
+    if (keep_tree) {
+        if (lane == 0) { NA[0] = A[root.fc + ci]; NB[0] = Bn[root.fc + ci]; }
+        __syncthreads();
+        int head = 0;
+        bool fail = false;
+        while (head < n_new) {
+            const int i = head + lane;
+            const bool valid = i < n_new;
+            NodeA rec = NodeA{0, 0.0f, 0.0f, -1};
+            int nc = 0;
+            if (valid) { rec = NA[i]; nc = (int)(NB[i] >> 16); }
+            const int incl = wave_incl_scan(nc, lane);
+            const int total = __shfl(incl, 63);
+            if (n_new + total > D.cap) { fail = true; break; }
+            const int dst = n_new + incl - nc;
+            s_cnt[lane] = nc;
+            if (nc > 0) { s_src[lane] = rec.fc; s_dst[lane] = dst; NA[i].fc = dst; }
+            __syncthreads();
+            uint64_t todo = __ballot(nc > 0);
+            while (todo) {
+                const int L = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int src = s_src[L], dd = s_dst[L], cn = s_cnt[L];
+                for (int j = lane; j < cn; j += 64) { NA[dd + j] = A[src + j]; NB[dd + j] = Bn[src + j]; }
+            }
+            const int nbatch = n_new - head < 64 ? n_new - head : 64;
+            head += nbatch;
+            n_new += total;
+            __syncthreads();
+        }
+        if (fail) { // cannot happen when cap >= the source pool; fall back to a fresh root loudly
+            if (lane == 0) set_err(D, 1);
+            n_new = 0;
+        }
+    }
+    if (!keep_tree || n_new == 0) {
+        if (lane == 0) { NA[0] = NodeA{0, 0.0f, 1.0f, -1}; NB[0] = 0u; }
+        n_new = 1;
+    }
+
+    // ---- board.push(move) on the root (game.py:201) and its history
+    const int from = c_tab.from[mv], to = c_tab.to[mv];
+    const int pc = s_sq[from], cap = s_sq[to];
+    __syncthreads();
+    if (lane == 0) { s_sq[to] = (uint8_t)pc; s_sq[from] = 0; }
+    uint64_t key = m.key ^ zob(pc, from) ^ zob(pc, to) ^ kTurnKey;
+    if (cap) key ^= zob(cap, to);
+    const int turn = m.turn ^ 1;
+    int halfmove = cap ? 0 : m.halfmove + 1;
+    int chain_len = cap ? 0 : m.chain_len;
+    if (chain_len >= kChainCap) { chain_len = kChainCap - 1; set_err(D, 2); }
+    for (int i = lane; i < chain_len; i += 64) s_chain[i] = D.chain[(size_t)b * kChainCap + i];
+    if (lane == 0) { s_chain[chain_len] = key; D.chain[(size_t)b * kChainCap + chain_len] = key; }
+    ++chain_len;
+    __syncthreads();
+    if (lane < 24) ((uint32_t *)(D.root_sq + (size_t)b * 96))[lane] = ((const uint32_t *)s_sq)[lane];
+
+    // ---- game end (game.py:208-219): is_game_over() or is_tie(); winner from outcome()
+    bool overflow;
+    const LeafEval L = eval_position(s_sq, turn, halfmove, key, s_chain, chain_len, S, nullptr, lane, overflow);
+    if (overflow) set_err(D, 4);
+    if (lane == 0) {
+        m.key = key;
+        m.halfmove = halfmove;
+        m.chain_len = chain_len;
+        m.ply += 1;
+        m.move_counter += 1;
+        m.n_nodes = n_new;
+        m.turn = (uint8_t)turn;
+        m.half = (uint8_t)nh;
+        m.pi_used += (uint32_t)k;
+        BoardStats &st = D.stats[b];
+        st.moves += 1;
+        if (L.status != CCZ_LEAF_EXPAND) {
+            m.over = 1;
+            m.winner = L.n_legal == 0 ? (int8_t)(turn ^ 1) : (int8_t)-1; // no legal move: side to move loses
+            st.games += 1;
+        }
+        D.meta[b] = m;
+        D.leaf_status[b] = CCZ_LEAF_SKIP;
+    }
+}
+
+// ------------------------------------------------------------------ harvest: finished games -> training rows
+// rows of board b start at row_base[b] (< 0: board not harvested). Per game: T samples then, unless
+// CCZ_FLAG_NO_MIRROR, their T mirror images (collect.py:112-131: data + data_flip).
+__global__ __launch_bounds__(256) void k_harvest(Dev D, const long long *row_base, uint16_t *states, float *pi, float *z)
+{
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const long long rb = row_base[b];
+    if (rb < 0) return;
+    const BoardMeta m = D.meta[b];
+    const int T = m.ply;
+    const bool quirks = (D.flags & 1u) != 0, mirror = (D.flags & 2u) == 0;
+    const uint8_t *rsq = D.rec_sq + (size_t)b * D.max_plies * 96;
+    for (int t = 0; t < T; ++t) {
+        const size_t r = (size_t)b * D.max_plies + t;
+        // game.py:23-44: index i of the 8-deep history holds the position i plies back (start position
+        // before that); reference quirk: every sample aliases the history at the LAST recorded ply
+        const int te = quirks ? T - 1 : t;
+        const int turn_plane = quirks ? 1 : D.rec_turn[r]; // collect.py:78 reads a board that never advances
+        for (int pass = 0; pass < (mirror ? 2 : 1); ++pass) {
+            const long long row = rb + (pass ? T : 0) + t;
+            uint32_t *srow = (uint32_t *)(states + (size_t)row * 10710);
+            for (int i = tid; i < 5355; i += 256) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int e = 2 * i + h;
+                    const int g = e / 630, w = e - g * 630;
+                    bool on;
+                    if (g == 16) on = turn_plane != 0;
+                    else {
+                        const int ch = w / 90, s = w - 90 * ch;
+                        const int ss = pass ? (s - s % 9) + (8 - s % 9) : s; // np.flip(axis=2): file mirror
+                        int tp = te - (g & 7);
+                        if (tp < 0) tp = 0;
+                        on = rsq[(size_t)tp * 96 + ss] == ch + 1 + (g >= 8 ? 8 : 0);
+                    }
+                    if (on) v |= (uint32_t)kHalfOne << (16 * h);
+                }
+                srow[i] = v;
+            }
+            float *prow = pi + (size_t)row * kNMoves;
+            for (int i = tid; i < kNMoves; i += 256) prow[i] = 0.0f;
+            __syncthreads();
+            const int k = D.rec_k[r];
+            const size_t po = (size_t)b * D.pi_cap + D.rec_off[r];
+            for (int i = tid; i < k; i += 256) {
+                const int id = D.rec_ids[po + i];
+                prow[pass ? c_tab.flip[id] : id] = D.rec_pi[po + i]; // mcts_prob[flip_map]
+            }
+            if (tid == 0) // game.py:213-219
+                z[row] = m.winner < 0 ? 0.0f : (D.rec_turn[r] == (uint8_t)m.winner ? 1.0f : -1.0f);
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------ stateless batch rules
+__global__ __launch_bounds__(64) void k_legal_moves(int n, const uint8_t *sq, const uint8_t *turn, const int32_t *halfmove,
+                                                      uint32_t *mask, int32_t *count, uint8_t *flags)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= n) return;
+    __shared__ __align__(16) uint8_t s_sq[96];
+    __shared__ GenScratch S;
+    if (lane < 24) ((uint32_t *)s_sq)[lane] = ((const uint32_t *)(sq + (size_t)b * 96))[lane];
+    __syncthreads();
+    const int t = turn[b] ? 1 : 0;
+    const GenResult g = gen_legal(s_sq, t, S, nullptr, lane);
+    __syncthreads();
+    if (mask) for (int w = lane; w < kMaskWords; w += 64) mask[(size_t)b * kMaskWords + w] = S.mask[w];
+    if (lane == 0) {
+        if (count) count[b] = g.n_legal;
+        if (flags) {
+            uint8_t f = 0;
+            if (g.ksq >= 0 && king_attacked(s_sq, g.ksq, -1, -1, 0, t)) f |= 1;
+            if (g.insufficient) f |= 2;
+            if (halfmove && halfmove[b] >= 120 && g.n_legal > 0) f |= 4;
+            if (g.overflow) f |= 128;
+            flags[b] = f;
+        }
+    }
+}
+
+__global__ void k_apply_moves(int n, uint8_t *sq, uint8_t *turn, const int32_t *ids, uint8_t *captured)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int id = ids[i];
+    if (id < 0 || id >= kNMoves) return;
+    uint8_t *s = sq + (size_t)i * 96;
+    const int from = c_tab.from[id], to = c_tab.to[id];
+    if (captured) captured[i] = s[to];
+    s[to] = s[from];
+    s[from] = 0;
+    turn[i] ^= 1;
+}
+
+} // namespace ccz

@@ -1,0 +1,217 @@
+"""SelfPlayEngine -- thin Python handle on the gfx950 lockstep engine (libcczero.so).
+
+B boards advance in lockstep; one simulation of every board is
+``select_leaves() -> evaluator (PyTorch-ROCm, same stream) -> expand_backup()`` and one move is
+``finish_move()``. PyTorch is only used for device memory and the stream.
+Replaces, for all boards at once, reference mcts.py:101-178 + the cchess calls of SURVEY a17.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import MAX_LEGAL, NMOVES, SQ_STRIDE, CczError, Config, Stats, check
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, torch.Tensor):
+        return C.c_void_p(t.data_ptr())
+    if isinstance(t, np.ndarray):
+        return C.c_void_p(t.ctypes.data)
+    raise TypeError(type(t))
+
+
+class SelfPlayEngine:
+    def __init__(self, n_boards: int, n_playout: int = 400, c_puct: float = 5, eps: float = 0.25,
+                 alpha: float = 0.2, temp: float = 1.0, seed: int = 0, board_id_base: int = 0,
+                 device: int = 0, max_nodes: int = 0, max_depth: int = 0, max_plies: int = 0,
+                 reference_quirks: bool = False, mirror: bool = True):
+        self.L = _lib.lib()
+        if not torch.cuda.is_available():
+            raise CczError("no GPU visible to PyTorch-ROCm; the engine has no CPU fallback")
+        self.device = torch.device("cuda", device)
+        self.B = int(n_boards)
+        self.n_playout = int(n_playout)
+        flags = (_lib.FLAG_REFERENCE_QUIRKS if reference_quirks else 0) | (0 if mirror else _lib.FLAG_NO_MIRROR)
+        self.mirror = mirror
+        cfg = Config(n_boards=self.B, n_playout=self.n_playout, c_puct=float(c_puct), eps=float(eps),
+                     alpha=float(alpha), temp=float(temp), max_nodes=int(max_nodes), max_depth=int(max_depth),
+                     max_plies=int(max_plies), flags=flags, seed=int(seed) & (2**64 - 1),
+                     board_id_base=int(board_id_base), device=int(device), reserved=0)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.L.ccz_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        # torch-owned boundary buffers (evaluator input / outputs, move buffers)
+        self.leaf_input = torch.zeros((self.B, 17, 7, 10, 9), dtype=torch.float16, device=self.device)
+        self.moves_out = torch.full((self.B,), -1, dtype=torch.int32, device=self.device)
+        self._forced = torch.full((self.B,), -1, dtype=torch.int32, device=self.device)
+        self._temps = torch.ones((self.B,), dtype=torch.float64, device=self.device)
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.L.ccz_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------ games
+    def reset(self, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        check(self.L.ccz_reset(self.h, self._stream(), _ptr(m)))
+
+    def set_position(self, board: int, squares, turn: int, halfmove: int = 0):
+        sq = np.ascontiguousarray(squares, dtype=np.uint8)
+        assert sq.shape == (90,)
+        check(self.L.ccz_set_position(self.h, self._stream(), int(board), _ptr(sq), int(turn), int(halfmove)))
+
+    # ------------------------------------------------------------------ one simulation
+    def select_leaves(self) -> torch.Tensor:
+        """PUCT descent + leaf rules + evaluator input for all boards; returns [B,17,7,10,9] fp16."""
+        check(self.L.ccz_select_leaves(self.h, self._stream(), _ptr(self.leaf_input)))
+        return self.leaf_input
+
+    def expand_backup(self, prob: torch.Tensor, value: torch.Tensor):
+        """prob float32 [B,2086] (= exp(log_act_probs)), value float32 [B]."""
+        if prob.dtype != torch.float32 or value.dtype != torch.float32:
+            raise TypeError("prob and value must be float32")
+        if tuple(prob.shape) != (self.B, NMOVES) or value.numel() != self.B:
+            raise ValueError(f"prob must be [{self.B},{NMOVES}] and value [{self.B}]")
+        if not (prob.is_cuda and value.is_cuda and prob.is_contiguous() and value.is_contiguous()):
+            raise ValueError("prob/value must be contiguous device tensors")
+        check(self.L.ccz_expand_backup(self.h, self._stream(), _ptr(prob), _ptr(value)))
+
+    # ------------------------------------------------------------------ once per move
+    def finish_move(self, forced_moves=None, temps=None, keep_tree: bool = True) -> torch.Tensor:
+        """Record pi, choose (or accept) the move, re-root, push, detect game end. Returns moves int32[B] (device)."""
+        f = t = None
+        if forced_moves is not None:
+            self._forced.copy_(torch.as_tensor(np.asarray(forced_moves, dtype=np.int32)) if not isinstance(forced_moves, torch.Tensor) else forced_moves)
+            f = self._forced
+        if temps is not None:
+            self._temps.copy_(torch.as_tensor(np.asarray(temps, dtype=np.float64)) if not isinstance(temps, torch.Tensor) else temps)
+            t = self._temps
+        check(self.L.ccz_finish_move(self.h, self._stream(), _ptr(f), _ptr(t), _ptr(self.moves_out), 1 if keep_tree else 0))
+        return self.moves_out
+
+    # ------------------------------------------------------------------ inspection (sync)
+    def root_children(self):
+        B = self.B
+        k = np.zeros(B, np.int32)
+        acts = np.zeros((B, MAX_LEGAL), np.uint16)
+        visits = np.zeros((B, MAX_LEGAL), np.int32)
+        q = np.zeros((B, MAX_LEGAL), np.float32)
+        p = np.zeros((B, MAX_LEGAL), np.float32)
+        rn = np.zeros(B, np.int32)
+        check(self.L.ccz_root_children(self.h, self._stream(), _ptr(k), _ptr(acts), _ptr(visits), _ptr(q), _ptr(p), _ptr(rn)))
+        return {"k": k, "acts": acts, "visits": visits, "q": q, "prior": p, "root_visits": rn}
+
+    def root_pi(self, temps=None) -> np.ndarray:
+        pi = np.zeros((self.B, MAX_LEGAL), np.float64)
+        t = None if temps is None else np.ascontiguousarray(np.broadcast_to(np.asarray(temps, np.float64), (self.B,)))
+        check(self.L.ccz_root_pi(self.h, self._stream(), _ptr(t), _ptr(pi)))
+        return pi
+
+    def game_status(self):
+        B = self.B
+        over = np.zeros(B, np.uint8)
+        winner = np.zeros(B, np.int8)
+        plies = np.zeros(B, np.int32)
+        turn = np.zeros(B, np.uint8)
+        check(self.L.ccz_game_status(self.h, self._stream(), _ptr(over), _ptr(winner), _ptr(plies), _ptr(turn)))
+        return {"over": over, "winner": winner, "plies": plies, "turn": turn}
+
+    def root_positions(self) -> np.ndarray:
+        sq = np.zeros((self.B, SQ_STRIDE), np.uint8)
+        check(self.L.ccz_root_positions(self.h, self._stream(), _ptr(sq)))
+        return sq[:, :90].copy()
+
+    def leaf_info(self):
+        B = self.B
+        status = np.zeros(B, np.uint8)
+        k = np.zeros(B, np.int32)
+        ids = np.zeros((B, MAX_LEGAL), np.uint16)
+        depth = np.zeros(B, np.int32)
+        check(self.L.ccz_leaf_info(self.h, self._stream(), _ptr(status), _ptr(k), _ptr(ids), _ptr(depth)))
+        return {"status": status, "k": k, "ids": ids, "depth": depth}
+
+    def stats(self) -> dict:
+        s = Stats()
+        check(self.L.ccz_get_stats(self.h, self._stream(), C.byref(s)))
+        d = {f: getattr(s, f) for f, _ in Stats._fields_ if f != "reserved"}
+        return d
+
+    def check_healthy(self):
+        e = self.stats()["error_flags"]
+        if e:
+            msgs = [m for bit, m in _lib.ERR_BITS.items() if e & bit]
+            raise CczError(f"engine error flags {e}: " + "; ".join(msgs))
+
+    # ------------------------------------------------------------------ training tuples
+    def harvest(self):
+        """Tuples of all finished games -> (states fp16 [R,17,7,10,9], pi f32 [R,2086], z f32 [R]); restarts those boards."""
+        rows = C.c_int64(0)
+        check(self.L.ccz_harvest_rows(self.h, self._stream(), C.byref(rows)))
+        R = int(rows.value)
+        states = torch.empty((R, 17, 7, 10, 9), dtype=torch.float16, device=self.device)
+        pi = torch.empty((R, NMOVES), dtype=torch.float32, device=self.device)
+        z = torch.empty((R,), dtype=torch.float32, device=self.device)
+        got = C.c_int64(0)
+        check(self.L.ccz_harvest(self.h, self._stream(), _ptr(states) if R else None, _ptr(pi) if R else None,
+                                 _ptr(z) if R else None, R, C.byref(got)))
+        assert got.value == R
+        return states, pi, z
+
+
+# ---------------------------------------------------------------------- stateless batch rules
+def legal_moves(squares, turn, halfmove=None, device: int = 0):
+    """Legal-move bitmask / count / flags of n positions on the GPU (replaces cchess legal_moves).
+
+    squares uint8 [n,90], turn [n]. Returns (mask bool [n,2086], count int32 [n], flags uint8 [n]).
+    """
+    L = _lib.lib()
+    if not torch.cuda.is_available():
+        raise CczError("no GPU visible to PyTorch-ROCm; the engine has no CPU fallback")
+    dev = torch.device("cuda", device)
+    sq = np.zeros((len(squares), SQ_STRIDE), np.uint8)
+    sq[:, :90] = np.asarray(squares, np.uint8)
+    n = sq.shape[0]
+    d_sq = torch.from_numpy(sq).to(dev)
+    d_turn = torch.from_numpy(np.ascontiguousarray(turn, dtype=np.uint8)).to(dev)
+    d_half = None if halfmove is None else torch.from_numpy(np.ascontiguousarray(halfmove, dtype=np.int32)).to(dev)
+    d_mask = torch.zeros((n, _lib.MASK_WORDS), dtype=torch.int32, device=dev)
+    d_cnt = torch.zeros((n,), dtype=torch.int32, device=dev)
+    d_flags = torch.zeros((n,), dtype=torch.uint8, device=dev)
+    s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    check(L.ccz_legal_moves(s, n, _ptr(d_sq), _ptr(d_turn), _ptr(d_half), _ptr(d_mask), _ptr(d_cnt), _ptr(d_flags)))
+    words = d_mask.cpu().numpy().view(np.uint32)
+    bits = np.unpackbits(words.view(np.uint8), axis=1, bitorder="little")[:, :NMOVES].astype(bool)
+    return bits, d_cnt.cpu().numpy(), d_flags.cpu().numpy()
+
+
+def apply_moves(squares, turn, move_ids, device: int = 0):
+    L = _lib.lib()
+    dev = torch.device("cuda", device)
+    sq = np.zeros((len(squares), SQ_STRIDE), np.uint8)
+    sq[:, :90] = np.asarray(squares, np.uint8)
+    n = sq.shape[0]
+    d_sq = torch.from_numpy(sq).to(dev)
+    d_turn = torch.from_numpy(np.ascontiguousarray(turn, dtype=np.uint8)).to(dev)
+    d_ids = torch.from_numpy(np.ascontiguousarray(move_ids, dtype=np.int32)).to(dev)
+    d_cap = torch.zeros((n,), dtype=torch.uint8, device=dev)
+    s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    check(L.ccz_apply_moves(s, n, _ptr(d_sq), _ptr(d_turn), _ptr(d_ids), _ptr(d_cap)))
+    return d_sq.cpu().numpy()[:, :90], d_turn.cpu().numpy(), d_cap.cpu().numpy()

@@ -1,0 +1,96 @@
+"""Host mirror of reference tools.py for the rollout path: action tables, flip, softmax, decode_board, is_tie.
+
+Same names and argument meaning as the reference (tools.py:74-272) so callers and tests read alike.
+The tables come from libcczero.so (``ccz_action_table`` / ``ccz_flip_map``), i.e. from the same
+compile-time table the kernels index.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+
+import numpy as np
+
+from . import _lib
+
+_log = logging.getLogger("chinesechesszero_amd")
+
+
+def log(message: str, level: str = "INFO", log_path: str | None = None):
+    """reference tools.py:12-71 prints with rich and appends to logs/<script>.log; stdlib logging here."""
+    _log.log(getattr(logging, (level or "INFO").upper(), logging.INFO), message)
+
+
+def _load_tables():
+    L = _lib.lib()
+    uci = C.create_string_buffer(_lib.NMOVES * 5)
+    fr = (C.c_uint8 * _lib.NMOVES)()
+    to = (C.c_uint8 * _lib.NMOVES)()
+    _lib.check(L.ccz_action_table(uci, fr, to))
+    raw = uci.raw
+    names = [raw[i * 5:i * 5 + 4].decode() for i in range(_lib.NMOVES)]
+    fm = (C.c_int32 * _lib.NMOVES)()
+    _lib.check(L.ccz_flip_map(fm))
+    return names, np.frombuffer(fr, np.uint8).copy(), np.frombuffer(to, np.uint8).copy(), np.frombuffer(fm, np.int32).copy()
+
+
+def get_all_legal_moves():
+    """(move_id2move_action, move_action2move_id) -- reference tools.py:172-269."""
+    names, _, _, _ = _load_tables()
+    return {i: s for i, s in enumerate(names)}, {s: i for i, s in enumerate(names)}
+
+
+_names, MOVE_FROM, MOVE_TO, _FLIP = _load_tables()
+move_id2move_action = {i: s for i, s in enumerate(_names)}
+move_action2move_id = {s: i for i, s in enumerate(_names)}
+
+
+def flip_map() -> np.ndarray:
+    """int32[2086]: id -> id of the file-mirrored move (collect.py:118-123)."""
+    return _FLIP.copy()
+
+
+_FLIP_FILE = {"a": "i", "b": "h", "c": "g", "d": "f", "e": "e", "f": "d", "g": "c", "h": "b", "i": "a"}
+
+
+def flip(string: str) -> str:
+    """Mirror a UCI move string left-right (reference tools.py:133-166)."""
+    return _FLIP_FILE[string[0]] + string[1] + _FLIP_FILE[string[2]] + string[3]
+
+
+def softmax(x):
+    """reference tools.py:126-129."""
+    probs = np.exp(x - np.max(x))
+    probs /= np.sum(probs)
+    return probs
+
+
+def decode_board(board):
+    """Board -> (red int8[7,10,9], black int8[7,10,9]) one-hot planes (reference tools.py:74-106).
+
+    ``board`` is anything with ``piece_at(square)`` returning an object with ``piece_type`` (1..7)
+    and ``color`` (True = RED), or a :class:`chinesechesszero_amd.game.Board`.
+    """
+    sq = getattr(board, "squares", None)
+    if callable(sq):
+        s = np.asarray(sq(), dtype=np.uint8)
+        red = np.zeros((7, 90), np.int8)
+        black = np.zeros((7, 90), np.int8)
+        occ = np.nonzero(s)[0]
+        for i in occ:
+            pc = int(s[i])
+            (black if pc & 8 else red)[(pc & 7) - 1, i] = 1
+        return red.reshape(7, 10, 9), black.reshape(7, 10, 9)
+    red_state = np.zeros((7, 10, 9), dtype=np.int8)
+    black_state = np.zeros((7, 10, 9), dtype=np.int8)
+    for i in range(10):
+        for j in range(9):
+            piece = board.piece_at(j + i * 9)
+            if piece:
+                (red_state if piece.color else black_state)[piece.piece_type - 1, i, j] = 1
+    return red_state, black_state
+
+
+def is_tie(board) -> bool:
+    """reference tools.py:109-123."""
+    return board.is_insufficient_material() or board.is_fourfold_repetition() or board.is_sixty_moves()

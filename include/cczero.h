@@ -1,0 +1,201 @@
+/*
+ * cczero.h -- C ABI of libcczero.so: the MI355X (gfx950) lockstep self-play rollout engine.
+ *
+ * Drop-in boundary for the ONE hot path of Symb0x76/ChineseChessZero:
+ * per-move MCTS select / expand / backup (reference mcts.py:101-178), the rules the reference
+ * takes from `cchess` (move generation, make-move, game-end and draw predicates; call sites
+ * mcts.py:111-126, net.py:154-157, game.py:201-216, tools.py:109-123), leaf encoding for the
+ * evaluator (net.py:160-177, tools.py:74-106), pi / Dirichlet-mixed move choice
+ * (mcts.py:163-166,216-224), tree reuse (mcts.py:168-178) and the self-play bookkeeping of
+ * game.py:133-237 + collect.py:64-131 (training tuples, mirror augmentation).
+ *
+ * The reference is pure Python and has no FFI; what it has is a call surface
+ * (policy_value_fn / MCTS_AI / Game.start_self_play / CollectPipeline). The Python mirror of
+ * that surface (chinesechesszero_amd/{mcts,game,collect,net,tools}.py) binds these entry points
+ * with ctypes; INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - B boards advance in lockstep; one 64-lane wavefront owns one board.
+ *   - every function returns 0 on success, <0 on error (ccz_last_error() has the text); nothing
+ *     throws across the ABI.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); all
+ *     device work is enqueued on it; functions documented "syncs" wait for that stream.
+ *   - pointers named *_dev are device pointers owned by the caller (torch tensors); *_host are
+ *     host pointers. Everything else is owned by the engine.
+ *   - single caller thread per engine, no re-entrancy (same as the reference).
+ *   - there is NO CPU fallback: every entry point that computes fails if no gfx950 device is
+ *     usable.
+ */
+#ifndef CCZERO_H
+#define CCZERO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCZ_ABI_VERSION 1
+#define CCZ_NSQ 90
+#define CCZ_SQ_STRIDE 96            /* mailbox row stride in bytes (90 squares + 6 pad)         */
+#define CCZ_NMOVES 2086             /* action space, reference tools.py:172-272                 */
+#define CCZ_MAX_LEGAL 128           /* upper bound on legal moves of one position               */
+#define CCZ_MASK_WORDS 66           /* ceil(2086/32): legal-move bitmask words                  */
+#define CCZ_PLANES 10710            /* 17*7*10*9 evaluator input elements, net.py:174-177       */
+
+/* piece codes in the mailbox: 0 empty, red = type, black = type + 8;
+ * types PAWN=1 CANNON=2 ROOK=3 KNIGHT=4 BISHOP=5 ADVISOR=6 KING=7 (channel = type-1, tools.py:100)
+ * colours as in cchess: RED = 1 (True), BLACK = 0 (False). square = file + 9*rank (tools.py:91). */
+
+/* flags for ccz_config.flags */
+#define CCZ_FLAG_REFERENCE_QUIRKS 1u /* harvest(): reproduce game.py:234-237 (all samples carry the
+                                        final 8-ply history) and collect.py:78 (turn plane all ones) */
+#define CCZ_FLAG_NO_MIRROR 2u        /* harvest(): do not append collect.py:112-131 mirror samples  */
+
+/* leaf status written by ccz_select_leaves */
+#define CCZ_LEAF_EXPAND 0 /* non-terminal: children are created from the evaluator's priors */
+#define CCZ_LEAF_DRAW 1   /* game over and is_tie(): leaf value 0.0   (mcts.py:120-122)   */
+#define CCZ_LEAF_LOSS 2   /* side to move has no legal move: leaf value -1.0 (mcts.py:123-126) */
+
+typedef struct ccz_engine ccz_engine;
+
+typedef struct ccz_config {
+    int32_t n_boards;      /* B: concurrent boards on this GPU                                   */
+    int32_t n_playout;     /* simulations per move (parameters.py:14 PLAYOUT; informational)    */
+    float c_puct;          /* parameters.py:8  C_PUCT = 5                                        */
+    float eps;             /* parameters.py:10 EPS   = 0.25 (Dirichlet mixing weight)            */
+    float alpha;           /* parameters.py:12 ALPHA = 0.2                                       */
+    float temp;            /* game.py:133 temp=1.0 ; schedule of game.py:159 applied per board   */
+    int32_t max_nodes;     /* tree nodes per board per pool half (0 = derive from n_playout)     */
+    int32_t max_depth;     /* selection path capacity (0 = 512)                                  */
+    int32_t max_plies;     /* recorded plies per game before adjudicating a draw (0 = 2048)      */
+    uint32_t flags;        /* CCZ_FLAG_*                                                         */
+    uint64_t seed;         /* device-mode sampling: Philox key                                   */
+    uint64_t board_id_base;/* global id of board 0 (rank * n_boards): RNG streams independent of GPU count */
+    int32_t device;        /* HIP device ordinal                                                 */
+    int32_t reserved;
+} ccz_config;
+
+typedef struct ccz_stats {
+    int64_t sims;            /* playouts completed since create                                  */
+    int64_t moves;           /* moves played                                                     */
+    int64_t games;           /* games finished                                                   */
+    int64_t truncated_games; /* games adjudicated at max_plies                                   */
+    int64_t nodes_peak;      /* max nodes in use on any board                                    */
+    int64_t depth_peak;      /* max selection depth seen                                         */
+    int64_t sum_depth;       /* sum of leaf depths (for d-bar)                                   */
+    int64_t sum_children;    /* sum of children created (for k-bar)                              */
+    int64_t expansions;      /* leaves expanded                                                  */
+    int64_t terminal_leaves; /* terminal leaves backed up                                        */
+    int32_t error_flags;     /* sticky device error bits (CCZ_ERR_*), 0 = healthy                */
+    int32_t reserved;
+    int64_t hbm_bytes;       /* device memory held by the engine                                 */
+} ccz_stats;
+
+#define CCZ_ERR_NODE_POOL 1   /* a board ran out of tree nodes (raise max_nodes)                 */
+#define CCZ_ERR_DEPTH 2       /* a selection path exceeded max_depth                             */
+#define CCZ_ERR_MOVES 4       /* more than CCZ_MAX_LEGAL legal moves / pseudo-move overflow       */
+#define CCZ_ERR_RECORD 8      /* pi record arena overflow (game adjudicated)                     */
+#define CCZ_ERR_BAD_MOVE 16   /* a forced move is not a child of the root                        */
+
+/* ---- library ---------------------------------------------------------------------------- */
+int ccz_abi_version(void);
+const char *ccz_last_error(void);
+/* number of usable gfx950 devices (0 if none); never initialises more than the runtime needs */
+int ccz_device_count(void);
+
+/* ---- action space (replaces reference tools.py:172-272 tables and tools.py:133-166 flip) - */
+/* uci_out: 2086 x 5 bytes, NUL-terminated 4-char strings ("a0a1") */
+int ccz_action_table(char *uci_out_host, uint8_t *from_out_host, uint8_t *to_out_host);
+int ccz_flip_map(int32_t *flip_out_host); /* collect.py:118-123 */
+
+/* ---- engine lifetime --------------------------------------------------------------------- */
+int ccz_create(const ccz_config *cfg, ccz_engine **out);
+int ccz_destroy(ccz_engine *e);
+/* start new games (standard opening, fresh trees, empty records) on the boards whose mask byte is
+ * non-zero; mask_host == NULL means all boards. Replaces cchess.Board() + reset_player()
+ * (game.py:148, mcts.py:200-201). */
+int ccz_reset(ccz_engine *e, void *stream, const uint8_t *mask_host);
+/* set an arbitrary root position on one board (fresh tree, game record restarted); for tests and
+ * match play. sq_host: 90 piece codes. */
+int ccz_set_position(ccz_engine *e, void *stream, int32_t board, const uint8_t *sq_host,
+                     int32_t turn, int32_t halfmove);
+
+/* ---- one lockstep simulation = select -> (evaluator) -> expand+backup --------------------- */
+/* Replaces the first half of MCTS.playout (mcts.py:101-111) + policy_value_fn's input building
+ * (net.py:154-177) for all boards: PUCT descent from each root with make-move, legal-move
+ * generation and game-end tests at the leaf, and the evaluator input written to
+ * leaf_input_f16_dev [B,17,7,10,9] fp16. Only plane groups 7, 15 and 16 are ever non-zero on this
+ * path (net.py:160-173); the engine rewrites those three and assumes the other 14 groups are zero
+ * (ccz_zero_leaf_input zeroes the whole tensor once). */
+int ccz_select_leaves(ccz_engine *e, void *stream, void *leaf_input_f16_dev);
+int ccz_zero_leaf_input(ccz_engine *e, void *stream, void *leaf_input_f16_dev);
+/* Replaces the second half of MCTS.playout (mcts.py:113-129): Node.expand with priors
+ * prob_dev[b, id] (float32 [B,2086] = exp(log_act_probs), net.py:202-203) for the leaf's legal ids
+ * in ascending id order, leaf value value_dev[b] (float32 [B], side to move's view) or the terminal
+ * value, and Node.update_recursive up the path. */
+int ccz_expand_backup(ccz_engine *e, void *stream, const float *prob_dev, const float *value_dev);
+
+/* ---- once per move ------------------------------------------------------------------------ */
+/* Replaces MCTS.get_move_probs' tail (mcts.py:162-166), MCTS_AI.get_action's choice
+ * (mcts.py:216-224), MCTS.update_with_move (mcts.py:168-178) and the per-move part of
+ * Game.start_self_play (game.py:159,188-237): pi from root visits at the board's temperature,
+ * record (position, turn, pi), choose the move, re-root the tree on the chosen child (subtree
+ * kept), make the move on the root position, detect the end of the game and its winner.
+ *   forced_moves_dev: int32 [B] or NULL. entry >= 0: play that move id (host-exact numpy sampling
+ *     or match play); entry < 0 or NULL: sample on the device stream Philox(seed, board id).
+ *   temps_dev: float64 [B] or NULL (NULL: schedule of game.py:159 from cfg.temp).
+ *   moves_out_dev: int32 [B] or NULL, receives the move played.
+ *   keep_tree: 1 = self-play tree reuse (mcts.py:222-224); 0 = discard (mcts.py:228-229). */
+int ccz_finish_move(ccz_engine *e, void *stream, const int32_t *forced_moves_dev,
+                    const double *temps_dev, int32_t *moves_out_dev, int32_t keep_tree);
+
+/* root children of every board (syncs): k_host int32[B]; acts_host uint16[B*128];
+ * visits_host int32[B*128]; q_host/prior_host float[B*128] (may be NULL); root_visits_host int32[B]
+ * (may be NULL). What mcts.py:162-163 reads. */
+int ccz_root_children(ccz_engine *e, void *stream, int32_t *k_host, uint16_t *acts_host,
+                      int32_t *visits_host, float *q_host, float *prior_host, int32_t *root_visits_host);
+/* pi of the root at temperature temps_host[b] (float64 [B], or NULL for the schedule) without
+ * moving: pi_host float64 [B*128] aligned with ccz_root_children's acts (syncs). */
+int ccz_root_pi(ccz_engine *e, void *stream, const double *temps_host, double *pi_host);
+/* per-board game state (syncs): over_host uint8[B] (1 = finished, waiting for harvest),
+ * winner_host int8[B] (1 RED, 0 BLACK, -1 draw), plies_host int32[B], turn_host uint8[B];
+ * any pointer may be NULL. */
+int ccz_game_status(ccz_engine *e, void *stream, uint8_t *over_host, int8_t *winner_host,
+                    int32_t *plies_host, uint8_t *turn_host);
+/* root positions (syncs): sq_host uint8 [B*96] */
+int ccz_root_positions(ccz_engine *e, void *stream, uint8_t *sq_host);
+/* leaf bookkeeping of the last ccz_select_leaves (syncs; tests): status uint8[B], k int32[B],
+ * ids uint16[B*128], depth int32[B]; any pointer may be NULL. */
+int ccz_leaf_info(ccz_engine *e, void *stream, uint8_t *status_host, int32_t *k_host,
+                  uint16_t *ids_host, int32_t *depth_host);
+
+/* ---- training tuples ---------------------------------------------------------------------- */
+/* number of tuple rows the finished games would produce (syncs). */
+int ccz_harvest_rows(ccz_engine *e, void *stream, int64_t *rows_host);
+/* Replaces game.py:208-237 (z assignment) + collect.py:64-131 (preprocess, flip_data) for every
+ * finished board: writes rows (state fp16 [17,7,10,9], pi float32 [2086], z float32) into the
+ * caller's device buffers, game by game (samples, then their mirror images), then starts a new
+ * game on those boards. capacity_rows must be >= ccz_harvest_rows. Syncs. */
+int ccz_harvest(ccz_engine *e, void *stream, void *states_f16_dev, float *pi_dev, float *z_dev,
+                int64_t capacity_rows, int64_t *rows_host);
+
+int ccz_get_stats(ccz_engine *e, void *stream, ccz_stats *out); /* syncs */
+
+/* ---- stateless batch rules (parity tests, perft; replaces cchess legal_moves / game-end) ---- */
+/* n positions: sq_dev uint8 [n*96], turn_dev uint8 [n], halfmove_dev int32 [n] or NULL.
+ * outputs (any may be NULL): mask_dev uint32 [n*66] legal-move bitmask over the 2086 ids,
+ * count_dev int32 [n], flags_dev uint8 [n]: bit0 side to move in check, bit1 insufficient material,
+ * bit2 sixty-move rule (needs halfmove_dev). */
+int ccz_legal_moves(void *stream, int32_t n, const uint8_t *sq_dev, const uint8_t *turn_dev,
+                    const int32_t *halfmove_dev, uint32_t *mask_dev, int32_t *count_dev,
+                    uint8_t *flags_dev);
+/* apply move ids to n positions in place (captures reported in captured_dev uint8[n], may be NULL);
+ * replaces cchess.Board.push for batches. */
+int ccz_apply_moves(void *stream, int32_t n, uint8_t *sq_dev, uint8_t *turn_dev,
+                    const int32_t *move_ids_dev, uint8_t *captured_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

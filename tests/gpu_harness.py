@@ -1,0 +1,101 @@
+"""Shared helpers for the -m gpu parity tests: drive the HIP engine and the CPU oracle in lockstep."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from oracle import OracleBoard, OracleMCTS
+from oracle.evaluators import hash_eval, uniform_eval
+
+
+def planes_to_squares(planes: np.ndarray):
+    """leaf input [B,17,7,10,9] (0/1) -> (squares uint8 [B,90], turn [B]); also checks the static zeros."""
+    p = planes.reshape(planes.shape[0], 17, 7, 90)
+    assert p[:, :7].sum() == 0 and p[:, 8:15].sum() == 0, "history groups must stay zero on the search path"
+    types = np.arange(1, 8, dtype=np.int64)[None, :, None]
+    red = (p[:, 7] * types).sum(axis=1)
+    black = (p[:, 15] * (types + 8)).sum(axis=1)
+    assert np.all((p[:, 7].sum(axis=1) + p[:, 15].sum(axis=1)) <= 1)
+    turn_plane = p[:, 16].reshape(p.shape[0], -1)
+    assert np.all((turn_plane == turn_plane[:, :1]).all(axis=1))
+    return (red + black).astype(np.uint8), turn_plane[:, 0].astype(np.uint8)
+
+
+def make_evaluator(kind: str, salts):
+    """Batched evaluator on (squares, turn) with a per-board salt; returns (P [B,2086] f32, v [B] f32)."""
+    salts = list(salts)
+
+    def ev(sq, turn, rows=None):
+        rows = range(len(sq)) if rows is None else rows
+        P = np.zeros((len(sq), 2086), np.float32)
+        V = np.zeros(len(sq), np.float32)
+        for j, b in enumerate(rows):
+            if kind == "uniform":
+                p, v = uniform_eval(sq[j:j + 1], turn[j:j + 1])
+            elif kind == "hash":
+                p, v = hash_eval(sq[j:j + 1], turn[j:j + 1], salt=salts[b], scale=1.0)
+            else:
+                p, v = hash_eval(sq[j:j + 1], turn[j:j + 1], salt=salts[b], scale=40.0)
+            P[j], V[j] = p[0], v[0]
+        return P, V
+
+    return ev
+
+
+class Lockstep:
+    """B engine boards next to B independent sequential oracles (reference mcts.py restated in C)."""
+
+    def __init__(self, engine, boards, kind="hash", salts=None, c_puct=5):
+        self.e = engine
+        self.B = engine.B
+        self.boards = boards  # list[OracleBoard], root positions (also set on the engine by the caller)
+        self.salts = list(range(self.B)) if salts is None else salts
+        self.ev = make_evaluator(kind, self.salts)
+        self.mcts = [OracleMCTS(None, c_puct=c_puct, n_playout=0) for _ in range(self.B)]
+
+    def step(self, check_leaf=True):
+        e = self.e
+        leaf_in = e.select_leaves()
+        planes = leaf_in.float().cpu().numpy()
+        info = e.leaf_info()
+        sq, turn = planes_to_squares(planes)
+        P, V = self.ev(sq, turn)
+        # oracle side
+        for b in range(self.B):
+            if info["status"][b] == 3:
+                continue
+            leaf, depth = self.mcts[b].select(self.boards[b])
+            ids = leaf.legal_ids()
+            if check_leaf:
+                assert depth == info["depth"][b], (b, depth, info["depth"][b])
+                assert np.array_equal(leaf.squares(), sq[b]), b
+                assert int(leaf.turn) == int(turn[b])
+                assert info["k"][b] == len(ids)
+                assert info["ids"][b][: len(ids)].tolist() == ids
+                end, tie = leaf.is_game_over(), leaf.is_tie()
+                want = 0 if (not end and not tie) else (1 if (end and tie) else 2)
+                assert info["status"][b] == want, (b, info["status"][b], want)
+                assert np.array_equal(planes[b], leaf.leaf_planes())
+            self.mcts[b].expand_backup(leaf, ids, P[b][ids], V[b])
+        e.expand_backup(torch.from_numpy(P).to(e.device), torch.from_numpy(V).to(e.device))
+
+    def compare_roots(self):
+        rc = self.e.root_children()
+        for b in range(self.B):
+            acts, visits, q, prior = self.mcts[b].root_children()
+            k = len(acts)
+            assert rc["k"][b] == k, (b, rc["k"][b], k)
+            assert np.array_equal(rc["acts"][b][:k], acts.astype(np.uint16)), b
+            assert np.array_equal(rc["visits"][b][:k], visits), (b, rc["visits"][b][:k], visits)
+            assert np.array_equal(rc["q"][b][:k].view(np.uint32), q.view(np.uint32)), b
+            assert np.array_equal(rc["prior"][b][:k].view(np.uint32), prior.view(np.uint32)), b
+            assert rc["root_visits"][b] == self.mcts[b].root_visits()
+        return rc
+
+    def play(self, moves):
+        """Force `moves` (list of ids, -1 = skip board) on both sides with tree reuse."""
+        self.e.finish_move(forced_moves=np.asarray(moves, np.int32))
+        for b, m in enumerate(moves):
+            if m >= 0:
+                self.mcts[b].update_with_move(int(m))
+                self.boards[b].push_id(int(m))

@@ -1,0 +1,137 @@
+"""GPU: lockstep PUCT search of the HIP engine against the oracle and the reference's golden traces."""
+import numpy as np
+import pytest
+
+from golden_cases import case_start
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(B, n, **kw):
+    from chinesechesszero_amd.engine import SelfPlayEngine
+    return SelfPlayEngine(B, n_playout=n, **kw)
+
+
+def test_lockstep_matches_oracle_every_step():
+    """8 boards, distinct evaluators, 3 plies x 96 sims: leaf, legal ids, status, planes, then N/Q/P bit-exact."""
+    from gpu_harness import Lockstep
+    from oracle import OracleBoard
+    B = 8
+    e = _engine(B, 96)
+    ls = Lockstep(e, [OracleBoard() for _ in range(B)], kind="hash_sharp", salts=list(range(100, 100 + B)))
+    rs = np.random.RandomState(0)
+    for ply in range(3):
+        for _ in range(96):
+            ls.step(check_leaf=True)
+        rc = ls.compare_roots()
+        moves = []
+        for b in range(B):
+            k = rc["k"][b]
+            w = rc["visits"][b][:k].astype(np.float64) + 1e-3
+            moves.append(int(rc["acts"][b][rs.choice(k, p=w / w.sum())]))
+        ls.play(moves)
+        assert np.array_equal(e.root_positions(), np.stack([x.squares() for x in ls.boards]))
+    ls.compare_roots()
+    e.check_healthy()
+
+
+def test_uniform_priors_exact_ties_first_max_order():
+    from gpu_harness import Lockstep
+    from oracle import OracleBoard
+    e = _engine(2, 150)
+    ls = Lockstep(e, [OracleBoard(), OracleBoard()], kind="uniform")
+    for _ in range(150):
+        ls.step(check_leaf=True)
+    rc = ls.compare_roots()
+    assert rc["root_visits"][0] == 150 and rc["visits"][0][:44].sum() == 149  # first playout expands the root
+    e.check_healthy()
+
+
+@pytest.mark.parametrize("idx", range(11))
+def test_golden_traces_from_reference_mcts(golden, idx):
+    """Visit counts / Q / priors equal the numbers the reference's own mcts.py produced (bit-exact),
+    pi within 1e-12, with the golden moves forced (tree reuse across plies)."""
+    from gpu_harness import Lockstep
+    from oracle import OracleBoard
+    case = golden["meta"]["cases"][idx]
+    d = golden["data"]
+    name = case["name"]
+    sqs, turn, half = case_start(case)
+    e = _engine(1, case["n"])
+    if case["start"] != "start":
+        e.set_position(0, sqs, turn, half)
+        ob = OracleBoard.from_array(sqs, turn, half)
+    else:
+        ob = OracleBoard()
+    salt = {"hash": 0, "hash_sharp": 7, "uniform": 0}[case["ev"]]
+    ls = Lockstep(e, [ob], kind=case["ev"], salts=[salt])
+    for ply in range(case["plies_done"]):
+        for _ in range(case["n"]):
+            ls.step(check_leaf=False)
+        rc = e.root_children()
+        k = int(rc["k"][0])
+        assert np.array_equal(rc["acts"][0][:k], d[f"{name}_p{ply}_acts"].astype(np.uint16))
+        assert np.array_equal(rc["visits"][0][:k], d[f"{name}_p{ply}_visits"])
+        assert np.array_equal(rc["q"][0][:k].view(np.uint32), d[f"{name}_p{ply}_q"].view(np.uint32))
+        assert np.array_equal(rc["prior"][0][:k].view(np.uint32), d[f"{name}_p{ply}_prior"].view(np.uint32))
+        assert rc["root_visits"][0] == int(d[f"{name}_p{ply}_rootvisits"])
+        pi = e.root_pi(temps=case["temps"][ply])[0][:k]
+        assert np.allclose(pi, d[f"{name}_p{ply}_pi"], rtol=0, atol=1e-12)
+        move = int(d[f"{name}_p{ply}_move"])
+        if case["selfplay"]:
+            ls.play([move])
+        else:  # match play discards the tree (mcts.py:228-229)
+            e.finish_move(forced_moves=np.array([move], np.int32), keep_tree=False)
+            ls.mcts[0].update_with_move(-1)
+            ls.boards[0].push_id(move)
+    assert np.array_equal(e.root_positions()[0], d[f"{name}_final_sq"])
+    e.check_healthy()
+
+
+def test_device_sampler_matches_cpu_twin():
+    """pi (deterministic log/exp) and the Dirichlet-mixed Philox choice: bit-exact vs oracle/xq_sample.c."""
+    import oracle
+    from gpu_harness import Lockstep
+    from oracle import OracleBoard
+    B = 16
+    e = _engine(B, 40, seed=1234, board_id_base=5000)
+    ls = Lockstep(e, [OracleBoard() for _ in range(B)], kind="hash_sharp", salts=list(range(B)))
+    for ply in range(4):
+        for _ in range(40):
+            ls.step(check_leaf=False)
+        rc = ls.compare_roots()
+        temp = 1.0 if ply < 2 else 0.5
+        pi = e.root_pi(temps=temp)
+        moves = e.finish_move(temps=np.full(B, temp)).cpu().numpy()
+        for b in range(B):
+            k = int(rc["k"][b])
+            want_pi = oracle.det_pi(rc["visits"][b][:k], temp)
+            assert np.array_equal(pi[b][:k].view(np.uint64), want_pi.view(np.uint64)), (ply, b)
+            idx, _ = oracle.det_sample(1234, 5000 + b, ply, want_pi, 0.25, 0.2)
+            assert moves[b] == rc["acts"][b][idx], (ply, b, moves[b], rc["acts"][b][idx])
+            ls.mcts[b].update_with_move(int(moves[b]))
+            ls.boards[b].push_id(int(moves[b]))
+    ls.compare_roots()
+    e.check_healthy()
+
+
+def test_device_sampler_distribution():
+    """Sampled moves follow (1-eps)*pi + eps*Dirichlet in aggregate: chi-square-like sanity on 2048 boards."""
+    import torch
+    B = 2048
+    e = _engine(B, 8, seed=99)
+    P = torch.full((B, 2086), 1.0 / 2086, dtype=torch.float32, device=e.device)
+    V = torch.zeros(B, dtype=torch.float32, device=e.device)
+    for _ in range(60):
+        e.select_leaves()
+        e.expand_backup(P, V)
+    rc = e.root_children()
+    assert np.all(rc["k"] == 44) and np.all(rc["visits"] == rc["visits"][0])
+    pi = e.root_pi(temps=1.0)[0][:44]
+    moves = e.finish_move().cpu().numpy()
+    counts = np.array([(moves == a).sum() for a in rc["acts"][0][:44]], np.float64)
+    expect = B * (0.75 * pi + 0.25 / 44)
+    assert counts.sum() == B
+    assert np.all(np.abs(counts - expect) < 6 * np.sqrt(expect) + 6)
+    assert len(np.unique(moves)) > 20
+    e.check_healthy()
