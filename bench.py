@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""bench.py -- self-play MCTS throughput of the MI355X lockstep engine (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one lockstep simulation of every board: select+make-move+movegen+encode (HIP) ->
+policy-value net (PyTorch-ROCm fp16, same stream) -> expand+backup (HIP); every ``n_playout``-th
+step also plays one move on every board (pi, Dirichlet-mixed choice, re-root, game end; HIP) and
+exchanges finished training rows (RCCL all-gather when N > 1). Workload = BASELINE.json configs[2]:
+4096 concurrent boards per GPU x 400 sims/move, Dirichlet root noise on, random-init 40x256 net,
+all boards from the opening position (synthetic). Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md (6.29e12 measured copy peak)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--boards", type=int, default=4096, help="concurrent boards per GPU")
+    ap.add_argument("--playout", type=int, default=400, help="simulations per move")
+    ap.add_argument("--evaluator", choices=["net", "stub"], default="net")
+    ap.add_argument("--blocks", type=int, default=40)
+    ap.add_argument("--channels", type=int, default=256)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay one simulation as a hipGraph")
+    return ap.parse_args()
+
+
+def host_cores() -> int:
+    """CPU threads this process may really use: affinity mask, cgroup quota, and the GPU box's 16-core share."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(seconds: float, blocks: int, channels: int):
+    """Oracle leg: BASELINE config[0] restated -- ONE game, strictly sequential PUCT (oracle/xq_mcts.c,
+    restating mcts.py), n_playout=200, batch-1 reference-architecture net on the host CPU in fp32."""
+    import oracle
+    from oracle import OracleBoard, OracleMCTS
+    from chinesechesszero_amd.net import Net
+
+    torch.manual_seed(0)
+    net = Net(channels, blocks).eval()
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    t_net = [0.0]
+
+    def evaluator(board, ids):
+        x = torch.from_numpy(board.leaf_planes()[None])
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            logp, v = net(x)
+        t_net[0] += time.perf_counter() - t0
+        p = np.exp(logp.numpy().reshape(-1))
+        return p[ids], v.numpy().reshape(-1)[0]
+
+    board = OracleBoard()
+    mcts = OracleMCTS(evaluator, c_puct=5, n_playout=200)
+    rs = np.random.RandomState(0)
+    sims = moves = 0
+    t0 = time.perf_counter()
+    deadline = t0 + seconds
+    while time.perf_counter() < deadline and not board.is_game_over():
+        done_move = True
+        for _ in range(200):
+            mcts.playout(board)
+            sims += 1
+            if time.perf_counter() >= deadline:
+                done_move = False
+                break
+        if not done_move:
+            break
+        acts, visits, _, _ = mcts.root_children()
+        temp = 1.0
+        x = 1.0 / temp * np.log(visits.astype(np.int64) + 1e-10)
+        pr = np.exp(x - x.max())
+        pr /= pr.sum()
+        move = int(rs.choice(acts, p=0.75 * pr + 0.25 * rs.dirichlet(0.2 * np.ones(len(pr)))))
+        mcts.update_with_move(move)
+        board.push_id(move)
+        moves += 1
+    dt = time.perf_counter() - t0
+    return {"value": sims / dt, "unit": "sims/s", "cores": cores, "kind": "port",
+            "sample": f"{sims} sequential playouts ({moves} full moves) of one self-play game, n_playout=200, "
+                      f"batch-1 {blocks}x{channels} net fp32 on CPU, {dt:.1f} s; net share {t_net[0] / dt:.2f}",
+            "moves_per_sec": moves / dt if moves else sims / dt / 200.0}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with python -m torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from chinesechesszero_amd.net import PolicyValueNet, uniform_evaluator
+    from chinesechesszero_amd.replay import TupleGatherer
+    from chinesechesszero_amd.selfplay import BatchedSelfPlay
+
+    B, n = a.boards, a.playout
+    if a.evaluator == "net":
+        torch.manual_seed(0)
+        pvn = PolicyValueNet(device=dev, num_channels=a.channels, resblocks_num=a.blocks)
+        pvn.refresh_inference_copy()
+        evaluator = pvn.evaluate_leaves
+    else:
+        evaluator = uniform_evaluator
+    sp = BatchedSelfPlay(evaluator, B, n_playout=n, seed=0, board_id_base=rank * B, device=local_rank,
+                         sampling="device", use_graph=a.graph)
+    e = sp.engine
+    gather = TupleGatherer(512, dev) if world > 1 else None
+
+    def per_move():
+        sp.finish_move()
+        st = e.game_status()
+        if st["over"].any() or world > 1:
+            s, p, z = e.harvest() if st["over"].any() else (e.leaf_input[:0], torch.empty((0, 2086), device=dev), torch.empty((0,), device=dev))
+            if gather is not None:
+                gather.gather(s, p, z)
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    step_no = [0]
+
+    def run(steps, timed):
+        pairs = []
+        for _ in range(steps):
+            if timed:
+                e0, e1, e2, e3 = ev(), ev(), ev(), ev()
+                e0.record()
+                leaf = e.select_leaves()
+                e1.record()
+                prob, value = evaluator(leaf)
+                e2.record()
+                e.expand_backup(prob, value)
+                e3.record()
+                pairs.append((e0, e1, e2, e3))
+            elif sp._graph is not None:
+                sp._graph.replay()
+            else:
+                sp.simulate()
+            step_no[0] += 1
+            if step_no[0] % n == 0:
+                per_move()
+        return pairs
+
+    if a.graph:
+        sp._capture()
+    run(a.warmup, False)
+    torch.cuda.synchronize()
+    s0 = e.stats()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pairs = run(a.steps, not a.graph)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    s1 = e.stats()
+    e.check_healthy()
+
+    sims = s1["sims"] - s0["sims"]
+    exp = max(1, s1["expansions"] - s0["expansions"])
+    kbar = (s1["sum_children"] - s0["sum_children"]) / exp
+    dbar = (s1["sum_depth"] - s0["sum_depth"]) / max(1, sims)
+    out = None
+    if rank == 0:
+        value = world * B * a.steps / dt
+        if pairs:
+            t_sel = float(np.mean([p[0].elapsed_time(p[1]) for p in pairs])) * 1e-3
+            t_net = float(np.mean([p[1].elapsed_time(p[2]) for p in pairs])) * 1e-3
+            t_exp = float(np.mean([p[2].elapsed_time(p[3]) for p in pairs])) * 1e-3
+        else:
+            t_sel = t_net = t_exp = float("nan")
+        # algorithmic bytes per simulation, SURVEY 8(d), split over the two simulator kernels. The
+        # 21,420-B evaluator input is counted at the 3,780 B that can be non-zero (groups 7/15/16);
+        # the 14 static-zero groups are written once at create, not per simulation.
+        a_sel = 3780 + 12 * kbar * dbar + 6 * dbar + 180 + 2 * kbar
+        a_exp = (4 * kbar + 4) + 18 * kbar + 16 * (dbar + 1)
+        a_sim_survey = 21420 + (4 * kbar + 4) + 18 * kbar + 12 * kbar * dbar + 6 * dbar + 16 * (dbar + 1) + 180 + 2 * kbar
+        ach_sel = a_sel * B / t_sel if t_sel == t_sel else None
+        ach_exp = a_exp * B / t_exp if t_exp == t_exp else None
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc):
+            try:
+                with open(pmc) as f:
+                    traffic = json.load(f).get("k_select", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        flops = 8.551e9 * (a.blocks / 40.0) * (a.channels / 256.0) ** 2
+        out = {
+            "metric": "self-play MCTS simulations/sec", "value": value, "unit": "sims/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8 rules / f32 Q / f64 PUCT (net: fp16)", "data": "synthetic",
+            "config": {"workload": f"{B} concurrent boards/GPU x {n} sims/move, Dirichlet root noise on (device Philox), "
+                                   f"{'random-init %dx%d policy-value net fp16' % (a.blocks, a.channels) if a.evaluator == 'net' else 'stub evaluator (uniform priors, v=0)'}"
+                                   ", all boards from the opening position",
+                       "boards_per_gpu": B, "sims_per_move": n, "evaluator": a.evaluator, "hipgraph": bool(a.graph)},
+            "moves_per_sec": value / n,
+            "roofline": {"bound": "hbm", "kernel": "k_select", "achieved": (ach_sel or 0) / 1e9, "peak": HBM_PEAK / 1e9,
+                         "unit": "GB/s", "frac": (ach_sel or 0) / HBM_PEAK, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": a_sel * B, "avg_launch_us": t_sel * 1e6,
+                         "k_bar": kbar, "d_bar": dbar},
+            "roofline_expand_backup": {"bound": "hbm", "kernel": "k_expand_backup", "achieved": (ach_exp or 0) / 1e9,
+                                       "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": (ach_exp or 0) / HBM_PEAK,
+                                       "algorithmic_bytes_per_launch": a_exp * B, "avg_launch_us": t_exp * 1e6},
+            "survey_a_sim_bytes": a_sim_survey,
+            "step_split_us": {"select": t_sel * 1e6, "evaluator": t_net * 1e6, "expand_backup": t_exp * 1e6},
+            "net_tflops": (flops * B / t_net / 1e12) if (a.evaluator == "net" and t_net == t_net) else None,
+            "engine_hbm_gb": s1["hbm_bytes"] / 1e9, "nodes_peak": s1["nodes_peak"], "depth_peak": s1["depth_peak"],
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_seconds, a.blocks, a.channels)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

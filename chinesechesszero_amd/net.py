@@ -1,0 +1,243 @@
+"""Policy-value network and the evaluator boundary (mirror of reference net.py).
+
+The network stays in PyTorch-ROCm (north star: "the net stays in PyTorch"). ``Net`` re-declares the
+reference architecture with identical ``state_dict`` keys (net.py:46-110) so reference-trained
+``.pkl`` weights load. What changes is the boundary: instead of one batch-1 call per playout
+(net.py:151-205) the engine hands over ONE contiguous fp16 batch of all leaves per lockstep step
+(:meth:`PolicyValueNet.evaluate_leaves`), on the same HIP stream as the simulator kernels.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+PIECES = 7   # net.py:11
+PLAYS = 17   # net.py:12  red 8 + black 8 + side-to-move
+
+
+class ResBlock(nn.Module):
+    """net.py:15-43"""
+
+    def __init__(self, num_channels=256):
+        super().__init__()
+        self.conv1 = nn.Conv2d(num_channels, num_channels, kernel_size=(3, 3), stride=(1, 1), padding=1)
+        self.conv1_bn = nn.BatchNorm2d(num_channels)
+        self.conv1_act = nn.ReLU()
+        self.conv2 = nn.Conv2d(num_channels, num_channels, kernel_size=(3, 3), stride=(1, 1), padding=1)
+        self.conv2_bn = nn.BatchNorm2d(num_channels)
+        self.conv2_act = nn.ReLU()
+
+    def forward(self, x):
+        y = self.conv1_act(self.conv1_bn(self.conv1(x)))
+        y = self.conv2_bn(self.conv2(y))
+        return self.conv2_act(x + y)
+
+
+class Net(nn.Module):
+    """net.py:46-110: input [N,17,7,10,9] -> (log_softmax policy [N,2086], tanh value [N,1])."""
+
+    def __init__(self, num_channels=256, resblocks_num=40):
+        super().__init__()
+        self.input_channels = PLAYS * PIECES
+        self.conv_block = nn.Conv2d(self.input_channels, num_channels, kernel_size=(3, 3), stride=(1, 1), padding=1)
+        self.conv_block_bn = nn.BatchNorm2d(num_channels)
+        self.conv_block_act = nn.ReLU()
+        self.res_blocks = nn.ModuleList([ResBlock(num_channels=num_channels) for _ in range(resblocks_num)])
+        self.policy_conv = nn.Conv2d(num_channels, PLAYS, kernel_size=(1, 1), stride=(1, 1))
+        self.policy_bn = nn.BatchNorm2d(PLAYS)
+        self.policy_act = nn.ReLU()
+        self.policy_fc = nn.Linear(PLAYS * 10 * 9, 2086)
+        self.value_conv = nn.Conv2d(num_channels, PIECES, kernel_size=(1, 1), stride=(1, 1))
+        self.value_bn = nn.BatchNorm2d(PIECES)
+        self.value_act1 = nn.ReLU()
+        self.value_fc1 = nn.Linear(PIECES * 10 * 9, 256)
+        self.value_act2 = nn.ReLU()
+        self.value_fc2 = nn.Linear(256, 1)
+
+    def forward(self, x):
+        x = x.view(x.shape[0], -1, 10, 9)
+        x = self.conv_block_act(self.conv_block_bn(self.conv_block(x)))
+        for blk in self.res_blocks:
+            x = blk(x)
+        policy = self.policy_act(self.policy_bn(self.policy_conv(x)))
+        policy = F.log_softmax(self.policy_fc(torch.reshape(policy, [-1, PLAYS * 10 * 9])), dim=1)
+        value = self.value_act1(self.value_bn(self.value_conv(x)))
+        value = self.value_act2(self.value_fc1(torch.reshape(value, [-1, PIECES * 10 * 9])))
+        value = torch.tanh(self.value_fc2(value))
+        return policy, value
+
+
+def _fold(conv: nn.Conv2d, bn: nn.BatchNorm2d):
+    """eval-mode BatchNorm folded into the preceding conv (exact in real arithmetic)."""
+    scale = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+    w = conv.weight.detach().double() * scale.view(-1, 1, 1, 1)
+    b = (conv.bias.detach().double() - bn.running_mean.detach().double()) * scale + bn.bias.detach().double()
+    return w, b
+
+
+class InferenceNet(nn.Module):
+    """Inference copy of ``Net`` for the lockstep evaluator: BN folded, fp16, channels-last.
+
+    The first conv only sees the 21 planes that can be non-zero on the search path (groups 7, 15, 16;
+    net.py:160-173 leaves the other 14 groups zero), which is exact: zero inputs contribute nothing.
+    Outputs: prob = exp(log_softmax(policy)) float32 [B,2086] (net.py:202), value float32 [B].
+    """
+
+    LIVE = list(range(7 * 7, 8 * 7)) + list(range(15 * 7, 17 * 7))  # channel ids of groups 7, 15, 16
+
+    def __init__(self, net: Net, dtype=torch.float16, live_only: bool = True):
+        super().__init__()
+        self.dtype = dtype
+        self.live_only = live_only
+        cl = torch.channels_last
+        w, b = _fold(net.conv_block, net.conv_block_bn)
+        if live_only:
+            w = w[:, self.LIVE]
+        self.stem_w = nn.Parameter(w.to(dtype).contiguous(memory_format=cl), requires_grad=False)
+        self.stem_b = nn.Parameter(b.to(dtype), requires_grad=False)
+        ws, bs = [], []
+        for blk in net.res_blocks:
+            for conv, bn in ((blk.conv1, blk.conv1_bn), (blk.conv2, blk.conv2_bn)):
+                w, b = _fold(conv, bn)
+                ws.append(nn.Parameter(w.to(dtype).contiguous(memory_format=cl), requires_grad=False))
+                bs.append(nn.Parameter(b.to(dtype), requires_grad=False))
+        self.ws = nn.ParameterList(ws)
+        self.bs = nn.ParameterList(bs)
+        # both 1x1 head convs in one GEMM: 17 policy + 7 value output channels
+        wp, bp = _fold(net.policy_conv, net.policy_bn)
+        wv, bv = _fold(net.value_conv, net.value_bn)
+        self.head_w = nn.Parameter(torch.cat([wp, wv], 0).to(dtype).contiguous(memory_format=cl), requires_grad=False)
+        self.head_b = nn.Parameter(torch.cat([bp, bv], 0).to(dtype), requires_grad=False)
+        self.policy_fc_w = nn.Parameter(net.policy_fc.weight.detach().to(dtype), requires_grad=False)
+        self.policy_fc_b = nn.Parameter(net.policy_fc.bias.detach().to(dtype), requires_grad=False)
+        self.value_fc1_w = nn.Parameter(net.value_fc1.weight.detach().to(dtype), requires_grad=False)
+        self.value_fc1_b = nn.Parameter(net.value_fc1.bias.detach().to(dtype), requires_grad=False)
+        self.value_fc2_w = nn.Parameter(net.value_fc2.weight.detach().to(dtype), requires_grad=False)
+        self.value_fc2_b = nn.Parameter(net.value_fc2.bias.detach().to(dtype), requires_grad=False)
+
+    @torch.no_grad()
+    def forward(self, leaf_input: torch.Tensor):
+        B = leaf_input.shape[0]
+        x = leaf_input.view(B, PLAYS * PIECES, 10, 9)
+        if self.live_only:
+            x = torch.cat([x[:, 49:56], x[:, 105:119]], dim=1)
+        x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
+        x = F.relu_(F.conv2d(x, self.stem_w, self.stem_b, padding=1))
+        for i in range(0, len(self.ws), 2):
+            y = F.relu_(F.conv2d(x, self.ws[i], self.bs[i], padding=1))
+            y = F.conv2d(y, self.ws[i + 1], self.bs[i + 1], padding=1)
+            x = F.relu_(y.add_(x))
+        h = F.relu_(F.conv2d(x, self.head_w, self.head_b))
+        pol = h[:, :PLAYS].reshape(B, PLAYS * 90)          # NCHW flatten order, as torch.reshape in net.py:98
+        val = h[:, PLAYS:].reshape(B, PIECES * 90)
+        logits = F.linear(pol, self.policy_fc_w, self.policy_fc_b)
+        prob = torch.exp(F.log_softmax(logits.float(), dim=1))
+        v = F.relu_(F.linear(val, self.value_fc1_w, self.value_fc1_b))
+        v = torch.tanh(F.linear(v, self.value_fc2_w, self.value_fc2_b).float()).view(B)
+        return prob.contiguous(), v.contiguous()
+
+
+class PolicyValueNet:
+    """Mirror of reference net.py:113-247 (same constructor, ``policy_value``, ``policy_value_fn``,
+    ``save_model``, ``train_step``) plus the batched evaluator :meth:`evaluate_leaves`."""
+
+    def __init__(self, model=None, use_gpu=True, device=None, num_channels=256, resblocks_num=40):
+        self.use_gpu = use_gpu
+        self.l2_const = 2e-3
+        if device is not None:
+            self.device = torch.device(device)
+        else:
+            self.device = torch.device("cuda") if (use_gpu and torch.cuda.is_available()) else torch.device("cpu")
+        self.policy_value_net = Net(num_channels, resblocks_num).to(self.device)
+        self.optimizer = torch.optim.Adam(params=self.policy_value_net.parameters(), lr=1e-3, betas=(0.9, 0.999),
+                                          eps=1e-8, weight_decay=self.l2_const)
+        if model:
+            self.policy_value_net.load_state_dict(torch.load(model, map_location=self.device))
+        self._infer = None
+        self._graph = None
+
+    # ---- batched evaluator for the lockstep engine -------------------------------------------
+    def refresh_inference_copy(self):
+        self.policy_value_net.eval()
+        self._infer = InferenceNet(self.policy_value_net).to(self.device).eval()
+        self._graph = None
+        return self._infer
+
+    @torch.no_grad()
+    def evaluate_leaves(self, leaf_input: torch.Tensor):
+        """[B,17,7,10,9] fp16 device tensor -> (prob float32 [B,2086], value float32 [B]) on the same stream."""
+        if self._infer is None:
+            self.refresh_inference_copy()
+        return self._infer(leaf_input)
+
+    evaluate_leaves.batched = True
+
+    # ---- reference surface --------------------------------------------------------------------
+    def policy_value(self, state_batch):
+        """net.py:137-148"""
+        self.policy_value_net.eval()
+        if isinstance(state_batch, torch.Tensor):
+            state_batch = state_batch.to(self.device)
+        else:
+            state_batch = torch.tensor(np.asarray(state_batch), dtype=torch.float).to(self.device)
+        with torch.no_grad():
+            log_act_probs, value = self.policy_value_net(state_batch.float())
+        return np.exp(log_act_probs.cpu().numpy()), value.cpu().numpy()
+
+    def policy_value_fn(self, board, red_states=None, black_states=None):
+        """Single-board evaluator with the reference's signature and return convention (net.py:151-205):
+        ``(zip(legal ids, P[ids]), value ndarray(1,1))``. ``board`` is a :class:`game.Board`."""
+        from .tools import decode_board
+        self.policy_value_net.eval()
+        legal_positions = board.legal_ids()
+        if red_states is None or black_states is None:
+            red_state, black_state = decode_board(board)
+            red_states = [np.zeros((PIECES, 10, 9), dtype=np.float16) for _ in range(PIECES)] + [red_state]
+            black_states = [np.zeros((PIECES, 10, 9), dtype=np.float16) for _ in range(PIECES)] + [black_state]
+        current_player = (np.ones if board.turn else np.zeros)((1, PIECES, 10, 9), dtype=np.float16)
+        states = np.concatenate((red_states, black_states, current_player), axis=0)
+        x = torch.as_tensor(np.ascontiguousarray(states.reshape(-1, PLAYS, PIECES, 10, 9)).astype("float16"))
+        with torch.no_grad():
+            if self.device.type == "cuda":
+                with torch.autocast("cuda"):
+                    log_act_probs, value = self.policy_value_net(x.to(self.device))
+            else:
+                log_act_probs, value = self.policy_value_net(x.float().to(self.device))
+        act_probs = np.exp(log_act_probs.float().cpu().numpy().flatten())
+        return zip(legal_positions, act_probs[legal_positions]), value.float().cpu().numpy()
+
+    def save_model(self, model_file):
+        torch.save(self.policy_value_net.state_dict(), model_file)
+
+    def train_step(self, state_batch, mcts_probs, winner_batch, lr=0.002):
+        """net.py:212-247 (plain PyTorch; the trainer is a consumer of the rollout path, not part of it)."""
+        self.policy_value_net.train()
+        to = lambda t: (t if isinstance(t, torch.Tensor) else torch.as_tensor(np.asarray(t))).to(self.device, dtype=torch.float)
+        state_batch, mcts_probs, winner_batch = to(state_batch), to(mcts_probs), to(winner_batch)
+        self.optimizer.zero_grad()
+        log_act_probs, value = self.policy_value_net(state_batch)
+        value_loss = F.mse_loss(input=torch.reshape(value, shape=[-1]), target=winner_batch)
+        policy_loss = -torch.mean(torch.sum(mcts_probs * log_act_probs, dim=1))
+        loss = value_loss + policy_loss
+        loss.backward()
+        self.optimizer.step()
+        with torch.no_grad():
+            entropy = -torch.mean(torch.sum(torch.exp(log_act_probs) * log_act_probs, dim=1))
+        self._infer = None
+        return loss.detach().cpu().numpy(), entropy.detach().cpu().numpy()
+
+
+def uniform_evaluator(leaf_input: torch.Tensor):
+    """Constant-time stub evaluator (uniform priors, value 0) used to time the simulator alone."""
+    B = leaf_input.shape[0]
+    key = (B, leaf_input.device)
+    cache = uniform_evaluator.__dict__.setdefault("_cache", {})
+    if key not in cache:
+        cache[key] = (torch.full((B, 2086), 1.0 / 2086, dtype=torch.float32, device=leaf_input.device),
+                      torch.zeros((B,), dtype=torch.float32, device=leaf_input.device))
+    return cache[key]
+
+
+uniform_evaluator.batched = True

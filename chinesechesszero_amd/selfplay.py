@@ -1,0 +1,103 @@
+"""Lockstep batched self-play: the GPU-native form of reference collect.py:133-143 + game.py:133-237.
+
+The reference plays ONE game at a time, one batch-1 net call per playout. Here B games advance in
+lockstep: per simulation ``select_leaves -> evaluator -> expand_backup`` for all boards (the
+evaluator is PyTorch-ROCm on the same stream), per move ``finish_move``; finished games are
+harvested into (state, pi, z) rows and restart immediately.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .engine import SelfPlayEngine
+from .parameters import ALPHA, C_PUCT, EPS
+
+
+class BatchedSelfPlay:
+    """``evaluator(leaf_input fp16 [B,17,7,10,9]) -> (prob f32 [B,2086], value f32 [B])`` on the device."""
+
+    def __init__(self, evaluator, n_boards: int, n_playout: int = 400, c_puct: float = C_PUCT, eps: float = EPS,
+                 alpha: float = ALPHA, temp: float = 1.0, seed: int = 0, board_id_base: int = 0, device: int = 0,
+                 sampling: str = "device", use_graph: bool = False, **engine_kw):
+        if sampling not in ("device", "numpy"):
+            raise ValueError("sampling must be 'device' (Philox on the GPU) or 'numpy' (reference-exact host RNG)")
+        self.evaluator = evaluator
+        self.engine = SelfPlayEngine(n_boards, n_playout=n_playout, c_puct=c_puct, eps=eps, alpha=alpha, temp=temp,
+                                     seed=seed, board_id_base=board_id_base, device=device, **engine_kw)
+        self.B = n_boards
+        self.n_playout = n_playout
+        self.sampling = sampling
+        self.eps, self.alpha, self.temp = eps, alpha, temp
+        # reference-exact host sampling: one legacy RandomState per board (mcts.py:216-224 uses the global one)
+        self.rngs = [np.random.RandomState((seed + board_id_base + b) % (2**32)) for b in range(n_boards)] if sampling == "numpy" else None
+        self._graph = None
+        self.use_graph = use_graph
+
+    # one lockstep simulation of every board
+    def simulate(self):
+        e = self.engine
+        leaf = e.select_leaves()
+        prob, value = self.evaluator(leaf)
+        e.expand_backup(prob, value)
+
+    def _capture(self):
+        """hipGraph of one simulation (select -> net -> expand/backup): launch-bound at small B."""
+        e = self.engine
+        s = torch.cuda.Stream(device=e.device)
+        s.wait_stream(torch.cuda.current_stream(e.device))
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self.simulate()  # warm-up outside capture (MIOpen find, allocator)
+        torch.cuda.current_stream(e.device).wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.simulate()
+        self._graph = g
+
+    def run_move(self, on_playout=None):
+        """n_playout simulations then one move on every board. Returns the moves (device int32 [B])."""
+        if self.use_graph and self._graph is None:
+            self._capture()
+        interval = max(1, self.n_playout // 100)
+        acc = 0
+        for i in range(self.n_playout):
+            if self._graph is not None:
+                self._graph.replay()
+            else:
+                self.simulate()
+            acc += 1
+            if on_playout is not None and (acc >= interval or i == self.n_playout - 1):
+                try:
+                    on_playout(acc)  # mcts.py:153-160
+                except Exception:
+                    pass
+                acc = 0
+        return self.finish_move()
+
+    def finish_move(self):
+        e = self.engine
+        if self.sampling == "device":
+            return e.finish_move()
+        # reference-exact: pi by the reference's own NumPy formula, Dirichlet + choice from legacy MT19937
+        rc = e.root_children()
+        st = e.game_status()
+        forced = np.full(self.B, -1, np.int32)
+        temps = np.ones(self.B, np.float64)
+        for b in range(self.B):
+            if st["over"][b]:
+                continue
+            k = int(rc["k"][b])
+            temp = self.temp if (st["plies"][b] + 1) <= 30 else max(0.1, self.temp * 0.5)  # game.py:159
+            temps[b] = temp
+            visits = rc["visits"][b][:k].astype(np.int64)
+            x = 1.0 / temp * np.log(visits + 1e-10)
+            probs = np.exp(x - np.max(x))
+            probs /= np.sum(probs)
+            rs = self.rngs[b]
+            p = (1 - self.eps) * probs + self.eps * rs.dirichlet(self.alpha * np.ones(k))
+            forced[b] = int(rs.choice(rc["acts"][b][:k].astype(np.int64), p=p))
+        return e.finish_move(forced_moves=forced, temps=temps)
+
+    def harvest(self):
+        return self.engine.harvest()
