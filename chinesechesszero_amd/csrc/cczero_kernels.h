@@ -373,7 +373,10 @@ __global__ __launch_bounds__(64) void k_finish_move(Dev D, const int32_t *forced
     const uint32_t *Bn = D.nodeB + baseOld;
     const NodeA root = A[0];
     int k = (int)(Bn[0] >> 16);
-    if (k == 0 || k > kMaxLegal) { if (lane == 0) set_err(D, 16); return; }
+    const int want = forced ? forced[b] : -1;
+    if (k > kMaxLegal) { if (lane == 0) set_err(D, 16); return; }
+    if (k == 0 && want < 0) { if (lane == 0) set_err(D, 16); return; } // nothing searched, nothing to sample from
+    if (want >= kNMoves) { if (lane == 0) set_err(D, 16); return; }
 
     if (lane < 24) ((uint32_t *)s_sq)[lane] = ((const uint32_t *)(D.root_sq + (size_t)b * 96))[lane];
     for (int i = lane; i < k; i += 64) {
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(64) void k_finish_move(Dev D, const int32_t *forced
     __syncthreads();
 
     // ---- pi (mcts.py:162-166) and the training record (game.py:195-198)
-    root_pi(s_vis, s_pi, k, board_temp(D, m, temps, b), lane);
+    if (k > 0) root_pi(s_vis, s_pi, k, board_temp(D, m, temps, b), lane);
     if (m.ply >= D.max_plies || m.pi_used + (uint32_t)k > (uint32_t)D.pi_cap) {
         // documented cap: the game is adjudicated a draw, its records so far stay valid
         if (lane == 0) {
@@ -404,15 +407,16 @@ __global__ __launch_bounds__(64) void k_finish_move(Dev D, const int32_t *forced
     }
 
     // ---- move choice (mcts.py:216-229)
-    const int want = forced ? forced[b] : -1;
     if (want >= 0) {
+        // a forced move that is not a child of the root (root unexpanded, or an opponent's reply the
+        // search never saw) gives a fresh root, as MCTS.update_with_move does (mcts.py:176-178)
         int found = -1;
         for (int i0 = 0; i0 < k; i0 += 64) {
             const int i = i0 + lane;
             const uint64_t hit = __ballot(i < k && s_act[i] == want);
             if (hit && found < 0) found = i0 + __ffsll((long long)hit) - 1;
         }
-        if (found < 0) { if (lane == 0) set_err(D, 16); return; }
+        if (found < 0 && s_sq[c_tab.from[want]] == 0) { if (lane == 0) set_err(D, 16); return; }
         if (lane == 0) s_choice = found;
     } else {
         // move ~ Categorical((1-EPS)*pi + EPS*Dirichlet(ALPHA)) on the board's Philox stream
@@ -435,7 +439,8 @@ __global__ __launch_bounds__(64) void k_finish_move(Dev D, const int32_t *forced
     }
     __syncthreads();
     const int ci = s_choice;
-    const int mv = s_act[ci];
+    const int mv = ci >= 0 ? (int)s_act[ci] : want;
+    if (ci < 0) keep_tree = 0;
     if (moves_out && lane == 0) moves_out[b] = mv;
 
     // ---- MCTS.update_with_move (mcts.py:168-178): re-root on the chosen child, subtree copied

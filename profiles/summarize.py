@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output into small, committable summaries (profiles/<tag>_*.{csv,json}).
+
+usage: summarize.py <gpurun_out/prof_TAG dir> <TAG>
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB-like units of the derived metric; on gfx950
+FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md "HBM"): the summary stores the
+raw counter and the corrected byte count (fetch x 2).
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def find(d, pat):
+    r = sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
+    return r[0] if r else None
+
+
+def main():
+    out_dir, tag = sys.argv[1], sys.argv[2]
+    root = os.path.dirname(os.path.abspath(__file__))
+    summary = {}
+    stats = find(os.path.join(out_dir, "trace"), "*kernel_stats.csv")
+    if stats:
+        rows = list(csv.DictReader(open(stats)))
+        keep = rows[:25]
+        with open(os.path.join(root, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+            w.writeheader()
+            w.writerows(keep)
+        for r in rows:
+            name = r.get("Name", "")
+            for k in ("k_select", "k_expand_backup", "k_finish_move", "k_harvest"):
+                if k in name:
+                    summary.setdefault(k, {})["avg_ns"] = float(r.get("AverageNs", 0) or 0)
+                    summary[k]["calls"] = int(float(r.get("Calls", 0) or 0))
+                    summary[k]["pct"] = float(r.get("Percentage", 0) or 0)
+    for kind, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        cc = find(os.path.join(out_dir, kind), "*counter_collection.csv")
+        if not cc:
+            continue
+        acc = defaultdict(lambda: [0.0, 0])
+        for r in csv.DictReader(open(cc)):
+            if r.get("Counter_Name") != counter:
+                continue
+            name = r.get("Kernel_Name", "")
+            for k in ("k_select", "k_expand_backup", "k_finish_move"):
+                if k in name:
+                    acc[k][0] += float(r.get("Counter_Value", 0) or 0)
+                    acc[k][1] += 1
+        for k, (tot, n) in acc.items():
+            if n:
+                summary.setdefault(k, {})[counter + "_raw_per_launch"] = tot / n
+                summary[k][counter + "_launches"] = n
+    for k, d in summary.items():
+        f = d.get("FETCH_SIZE_raw_per_launch")
+        w = d.get("WRITE_SIZE_raw_per_launch")
+        if f is not None and w is not None:
+            # rocprofv3 FETCH_SIZE / WRITE_SIZE are in kilobytes; gfx950: double the fetch side
+            d["hbm_bytes_per_launch"] = (2.0 * f + w) * 1024.0
+            d["hbm_bytes_per_launch_uncorrected"] = (f + w) * 1024.0
+    for name in ("trace_bench.json", "pmc_fetch_bench.json", "pmc_write_bench.json"):
+        p = os.path.join(out_dir, name)
+        if os.path.exists(p):
+            try:
+                line = [l for l in open(p).read().splitlines() if l.startswith("{")][-1]
+                summary.setdefault("_bench", {})[name] = json.loads(line)
+            except Exception:
+                pass
+    with open(os.path.join(root, f"{tag}_summary.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+    with open(os.path.join(root, "pmc_summary.json"), "w") as f:
+        json.dump({k: v for k, v in summary.items() if not k.startswith("_")}, f, indent=1)
+    print(json.dumps({k: v for k, v in summary.items() if not k.startswith("_")}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
