@@ -1,0 +1,201 @@
+"""Host mirror of reference collect.py: ``CollectPipeline`` (collect.py:26-198).
+
+Two modes behind the same class:
+  * ``n_boards == 1``: the reference's own control flow -- ``Game.start_self_play`` with an ``MCTS_AI``
+    player, ``preprocess`` and ``flip_data`` on the host -- for drop-in use and parity tests;
+  * ``n_boards > 1``: the MI355X-native path -- ``BatchedSelfPlay`` runs all games in lockstep on the
+    GPU, ``harvest`` materialises (state, pi, z) rows incl. the mirror images on the device, and (with
+    ``torch.distributed`` initialised) rows are all-gathered over RCCL.
+Rows go to a ``TupleSink``: ``states.npy / mcts.npy / winners.npy / meta.json`` exactly as the
+reference's convert.py:84-99 produces and dataset.py:45-89 reads (h5py is not part of this image; the
+per-game HDF5 groups of collect.py:146-167 are written instead when h5py is importable).
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+import torch
+
+from .game import RED, Board, Game
+from .mcts import MCTS_AI
+from .net import PolicyValueNet
+from .parameters import C_PUCT, DATA_DIR, MODEL_DIR, PLAYOUT
+from .tools import flip_map, log
+
+
+class TupleSink:
+    """Append-only store of training rows in the trainer's on-disk format (convert.py:84-99)."""
+
+    def __init__(self, out_dir: str = DATA_DIR, pi_dtype=np.float32):
+        self.out_dir = out_dir
+        self.pi_dtype = pi_dtype
+        self._states, self._pi, self._z = [], [], []
+        self.games = 0
+        os.makedirs(out_dir, exist_ok=True)
+        meta = os.path.join(out_dir, "meta.json")
+        if os.path.exists(meta):
+            with open(meta) as f:
+                self.games = int(json.load(f).get("iters", 0))
+
+    def append(self, states, pi, z, games: int = 1):
+        to_np = lambda t: t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+        s, p, w = to_np(states), to_np(pi), to_np(z)
+        if len(s) == 0:
+            return
+        self._states.append(s.astype(np.float16).reshape(-1, 17, 7, 10, 9))
+        self._pi.append(p.astype(self.pi_dtype).reshape(-1, 2086))
+        self._z.append(w.astype(np.float32).reshape(-1))
+        self.games += games
+
+    def rows(self) -> int:
+        return int(sum(len(z) for z in self._z))
+
+    def flush(self):
+        """Rewrite the three .npy files with everything collected so far (+ what was on disk)."""
+        paths = {k: os.path.join(self.out_dir, k + ".npy") for k in ("states", "mcts", "winners")}
+        old = [np.load(paths[k]) for k in ("states", "mcts", "winners")] if all(os.path.exists(p) for p in paths.values()) else None
+        parts = [self._states, self._pi, self._z]
+        if old is not None:
+            parts = [[o] + p for o, p in zip(old, parts)]
+        if not parts[2]:
+            return 0
+        arrs = [np.concatenate(p) for p in parts]
+        for k, a in zip(("states", "mcts", "winners"), arrs):
+            np.save(paths[k], a)
+        with open(os.path.join(self.out_dir, "meta.json"), "w") as f:
+            json.dump({"iters": self.games, "total_samples": int(len(arrs[2])), "state_shape": [17, 7, 10, 9],
+                       "state_dtype": "float16", "mcts_dtype": str(arrs[1].dtype), "winner_dtype": "float32"}, f)
+        self._states, self._pi, self._z = [arrs[0]], [arrs[1]], [arrs[2]]
+        if old is not None:  # everything is on disk now; keep nothing twice
+            self._states, self._pi, self._z = [], [], []
+        return int(len(arrs[2]))
+
+
+class CollectPipeline:
+    def __init__(self, init_model=None, n_boards: int = 1, n_playout: int = PLAYOUT, device: int = 0, seed: int = 0,
+                 data_dir: str = DATA_DIR, reference_quirks: bool = False, num_channels: int = 256, resblocks_num: int = 40):
+        self.board = Board()                       # collect.py:28 (never advanced: source of the turn-plane quirk)
+        self.game = Game(self.board, reference_quirks=reference_quirks)
+        self.temp = 1.0
+        self.n_playout = n_playout
+        self.c_puct = C_PUCT
+        self.init_model = init_model
+        self.n_boards = n_boards
+        self.device = device
+        self.seed = seed
+        self.reference_quirks = reference_quirks
+        self._net_shape = (num_channels, resblocks_num)
+        self.mcts_ai = None
+        self.policy_value_net = None
+        self.selfplay = None
+        self.sink = TupleSink(data_dir)
+        self.iters = self.sink.games
+        self.episode_len = 0
+
+    def load_model(self):
+        """collect.py:48-62: load once; on failure fall back to a random-init net."""
+        if self.policy_value_net is None:
+            model_path = self.init_model if self.init_model else MODEL_DIR
+            dev = f"cuda:{self.device}"
+            try:
+                self.policy_value_net = PolicyValueNet(model=model_path, device=dev, num_channels=self._net_shape[0],
+                                                       resblocks_num=self._net_shape[1])
+                log(f"Loaded model: {model_path}")
+            except Exception as e:
+                log(f"Failed to load model {model_path}: {e}", "ERROR")
+                self.policy_value_net = PolicyValueNet(device=dev, num_channels=self._net_shape[0], resblocks_num=self._net_shape[1])
+            self.mcts_ai = MCTS_AI(self.policy_value_net.policy_value_fn, c_puct=self.c_puct, n_playout=self.n_playout,
+                                   is_selfplay=True, device=self.device, seed=self.seed)
+
+    # ---- host path (one game at a time, the reference's own steps) ---------------------------------
+    def preprocess(self, play_data):
+        """collect.py:64-110"""
+        processed = []
+        self.episode_len = 0
+        for i, (red_states, black_states, mcts_prob, winner) in enumerate(play_data):
+            self.episode_len += 1
+            if self.reference_quirks:
+                red_turn = self.board.turn == RED          # collect.py:78: always RED
+            else:
+                red_turn = (i % 2 == 0)                   # side to move at ply i of a game that RED starts
+            current_player = (np.ones if red_turn else np.zeros)((1, 7, 10, 9), dtype=np.float16)
+            states = np.concatenate((red_states, black_states), axis=0)
+            states = np.concatenate((states, current_player), axis=0)
+            mcts_prob = np.asarray(mcts_prob)
+            prob_sum = np.sum(mcts_prob)
+            if prob_sum <= 0:
+                log(f"mcts_prob sum is {prob_sum}; skipping this step", "WARNING")
+                continue
+            elif abs(prob_sum - 1.0) > 1e-6:
+                mcts_prob = mcts_prob / prob_sum
+            processed.append((states, mcts_prob, winner))
+        return processed
+
+    def flip_data(self, data):
+        """collect.py:112-131: append the left-right mirror of every sample."""
+        fm = flip_map()
+        data_flip = []
+        for states, mcts_prob, winner in data:
+            states_flip = [np.flip(state, axis=2) for state in states]
+            data_flip.append((states_flip, mcts_prob[fm], winner))
+        return data + data_flip
+
+    def collect_data(self, is_shown=False):
+        """collect.py:133-176 (n_boards == 1) or one lockstep move of all boards + harvest (n_boards > 1)."""
+        self.load_model()
+        if self.n_boards > 1:
+            return self.collect_batched(1)
+        self.current_game_index = self.iters + 1
+        play_data = self.game.start_self_play(self.mcts_ai, is_shown=is_shown, game_index=self.current_game_index)
+        play_data = self.flip_data(self.preprocess(play_data))
+        self.sink.append(np.array([np.asarray(s, dtype=np.float16) for s, _, _ in play_data]),
+                         np.array([p for _, p, _ in play_data]), np.array([w for _, _, w in play_data]))
+        self.sink.flush()
+        self.iters = self.sink.games
+        return self.iters
+
+    # ---- MI355X path --------------------------------------------------------------------------------
+    def collect_batched(self, n_moves: int, gatherer=None):
+        """Play ``n_moves`` lockstep moves on all boards; harvest + (optionally) all-gather finished games."""
+        from .selfplay import BatchedSelfPlay
+        self.load_model()
+        if self.selfplay is None:
+            rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+            self.selfplay = BatchedSelfPlay(self.policy_value_net.evaluate_leaves, self.n_boards, n_playout=self.n_playout,
+                                            c_puct=self.c_puct, temp=self.temp, seed=self.seed, board_id_base=rank * self.n_boards,
+                                            device=self.device, reference_quirks=self.reference_quirks)
+        for _ in range(n_moves):
+            self.selfplay.run_move()
+            st = self.selfplay.engine.game_status()
+            done = int(st["over"].sum())
+            if done or gatherer is not None:
+                s, p, z = self.selfplay.harvest()
+                if gatherer is not None:
+                    s, p, z = gatherer.gather(s, p, z)
+                self.sink.append(s, p, z, games=done)
+        self.selfplay.engine.check_healthy()
+        self.sink.flush()
+        self.iters = self.sink.games
+        return self.iters
+
+    def run(self, is_shown=False):
+        """collect.py:178-186"""
+        try:
+            while True:
+                iters = self.collect_data(is_shown=is_shown)
+                log(f"Episode {iters}, steps {self.episode_len}")
+        except KeyboardInterrupt:
+            log("Exit")
+
+
+if __name__ == "__main__":
+    import argparse
+    parser = argparse.ArgumentParser(description="collect Xiangqi self-play data on MI355X")
+    parser.add_argument("--show", action="store_true", default=False)
+    parser.add_argument("--model", type=str, default="current_policy.pkl")
+    parser.add_argument("--boards", type=int, default=4096)
+    parser.add_argument("--playout", type=int, default=PLAYOUT)
+    args = parser.parse_args()
+    CollectPipeline(init_model=args.model, n_boards=args.boards, n_playout=args.playout).run(is_shown=args.show)

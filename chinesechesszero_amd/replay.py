@@ -25,10 +25,10 @@ class TupleGatherer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         d = self.device
-        self._s = torch.zeros((self.cap, STATE_ELEMS), dtype=torch.int16, device=d)  # fp16 bits
+        self._s = torch.zeros((self.cap, STATE_ELEMS * 2), dtype=torch.uint8, device=d)  # fp16 bytes (gloo-safe)
         self._p = torch.zeros((self.cap, NMOVES), dtype=torch.float32, device=d)
         self._z = torch.zeros((self.cap,), dtype=torch.float32, device=d)
-        self._S = torch.zeros((self.world * self.cap, STATE_ELEMS), dtype=torch.int16, device=d)
+        self._S = torch.zeros((self.world * self.cap, STATE_ELEMS * 2), dtype=torch.uint8, device=d)
         self._P = torch.zeros((self.world * self.cap, NMOVES), dtype=torch.float32, device=d)
         self._Z = torch.zeros((self.world * self.cap,), dtype=torch.float32, device=d)
         self._cnt = torch.zeros((1,), dtype=torch.int64, device=d)
@@ -44,7 +44,7 @@ class TupleGatherer:
         counts = self._cnts.tolist()
         rounds = max(1, -(-max(counts) // self.cap))
         outs_s, outs_p, outs_z = [], [], []
-        sbits = states.reshape(n, STATE_ELEMS).view(torch.int16) if n else states.reshape(0, STATE_ELEMS).view(torch.int16)
+        sbits = states.contiguous().reshape(n, STATE_ELEMS).view(torch.uint8)
         for r in range(rounds):
             lo = min(n, r * self.cap)
             hi = min(n, (r + 1) * self.cap)

@@ -1,0 +1,78 @@
+"""CPU: the N>1 exchange path (all-gather of finished tuples) under gloo, world_size 2."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rows(rank, n):
+    g = torch.Generator().manual_seed(100 + rank)
+    s = (torch.rand((n, 17, 7, 10, 9), generator=g) > 0.9).to(torch.float16)
+    p = torch.rand((n, 2086), generator=g)
+    z = torch.full((n,), float(rank + 1))
+    return s, p, z
+
+
+def _worker(rank, world, port, counts_per_round, cap, q):
+    try:
+        _worker_body(rank, world, port, counts_per_round, cap, q)
+    except Exception as e:  # surface the failure instead of letting the parent wait for its timeout
+        q.put((rank, False, repr(e)))
+
+
+def _worker_body(rank, world, port, counts_per_round, cap, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chinesechesszero_amd.replay import ReplayBuffer, TupleGatherer
+    g = TupleGatherer(cap, "cpu")
+    rb = ReplayBuffer(64, "cpu")
+    ok = True
+    for counts in counts_per_round:
+        s, p, z = _rows(rank, counts[rank])
+        S, P, Z = g.gather(s, p, z)
+        exp = [_rows(r, counts[r]) for r in range(world)]
+        ES = torch.cat([e[0] for e in exp])
+        EP = torch.cat([e[1] for e in exp])
+        EZ = torch.cat([e[2] for e in exp])
+        ok = ok and S.shape[0] == sum(counts) and torch.equal(S, ES) and torch.equal(P, EP) and torch.equal(Z, EZ)
+        rb.append(S, P, Z)
+    q.put((rank, ok, rb.total))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_gather_of_tuples_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    # uneven counts, an empty rank, and a round that needs two passes through the padded buffer (cap 4)
+    rounds = [(3, 1), (0, 2), (0, 0), (9, 4)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, rounds, 4, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert [r[1] for r in res] == [True, True]
+    assert res[0][2] == res[1][2] == sum(sum(c) for c in rounds)  # every rank holds the union of the shards
+
+
+def test_board_id_streams_independent_of_gpu_count():
+    """RNG streams are keyed by the GLOBAL board id: rank r's board b uses id r*B+b (oracle twin of the device sampler)."""
+    import oracle
+    pi = np.full(44, 1 / 44)
+    whole = [oracle.det_sample(7, gid, 0, pi)[0] for gid in range(8)]
+    shards = [oracle.det_sample(7, r * 4 + b, 0, pi)[0] for r in range(2) for b in range(4)]
+    assert whole == shards and len(set(whole)) > 1

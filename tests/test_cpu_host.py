@@ -1,0 +1,117 @@
+"""CPU: host-side logic and the C-ABI library surface (no GPU compute)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    """Every function include/cczero.h declares is exported by libcczero.so and bound by the shim."""
+    from chinesechesszero_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "cczero.h")).read()
+    declared = set(re.findall(r"\b(ccz_[a-z_]+)\s*\(", hdr))
+    declared -= {"ccz_engine", "ccz_config", "ccz_stats"}
+    assert len(declared) >= 20
+    L = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+        assert name in _lib.PROTOTYPES, f"{name} not bound in _lib.PROTOTYPES"
+    assert set(_lib.PROTOTYPES) == declared
+    assert L.ccz_abi_version() == 1
+    assert ctypes.sizeof(_lib.Config) == 64 and ctypes.sizeof(_lib.Stats) == 96
+
+
+def test_tables_from_library_match_reference_golden(golden):
+    from chinesechesszero_amd import tools
+    assert [tools.move_id2move_action[i] for i in range(2086)] == golden["table"]
+    assert all(tools.move_action2move_id[s] == i for i, s in enumerate(golden["table"]))
+    assert np.array_equal(tools.flip_map(), golden["data"]["flip_map"])
+    for i in (0, 17, 2037, 2038, 2085):
+        s = golden["table"][i]
+        assert tools.move_action2move_id[tools.flip(s)] == golden["data"]["flip_map"][i]
+    assert tools.flip("d9e8") == "f9e8"
+    x = np.array([0.5, 2.0, -1.0])
+    assert np.allclose(tools.softmax(x), np.exp(x) / np.exp(x).sum())
+
+
+def test_engine_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from chinesechesszero_amd._lib import CczError
+    from chinesechesszero_amd.engine import SelfPlayEngine, legal_moves
+    with pytest.raises(CczError):
+        SelfPlayEngine(4)
+    with pytest.raises(CczError):
+        legal_moves(np.zeros((1, 90), np.uint8), np.zeros(1, np.uint8))
+    # the C ABI itself also refuses: no CPU fallback behind the boundary
+    from chinesechesszero_amd import _lib
+    L = _lib.lib()
+    cfg = _lib.Config(n_boards=2, n_playout=4, c_puct=5, eps=0.25, alpha=0.2, temp=1.0)
+    h = ctypes.c_void_p()
+    assert L.ccz_create(ctypes.byref(cfg), ctypes.byref(h)) != 0
+    assert b"no HIP device" in L.ccz_last_error() or b"failed" in L.ccz_last_error()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "chinesechesszero_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, f
+
+
+def test_inference_copy_equals_reference_architecture():
+    from chinesechesszero_amd.net import InferenceNet, Net
+    torch.manual_seed(1)
+    net = Net(16, 2).eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 2)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.1)
+    assert sorted(net.state_dict().keys())[:3] == ["conv_block.bias", "conv_block.weight", "conv_block_bn.bias"]
+    assert "res_blocks.1.conv2_bn.running_var" in net.state_dict() and "value_fc2.weight" in net.state_dict()
+    x = torch.zeros(6, 17, 7, 10, 9)
+    x[:, 7] = (torch.rand(6, 7, 10, 9) > 0.9).float()
+    x[:, 15] = (torch.rand(6, 7, 10, 9) > 0.9).float()
+    x[::2, 16] = 1
+    with torch.no_grad():
+        logp, v = net(x)
+        for live in (True, False):
+            p2, v2 = InferenceNet(net, dtype=torch.float32, live_only=live)(x.half())
+            assert torch.allclose(logp.exp(), p2, atol=1e-6) and torch.allclose(v.view(-1), v2, atol=1e-6)
+    full = Net()
+    assert sum(p.numel() for p in full.parameters()) == 50883979  # SURVEY: reference net size
+
+
+def test_tuple_sink_and_replay_buffer(tmp_path):
+    from chinesechesszero_amd.collect import TupleSink
+    from chinesechesszero_amd.replay import ReplayBuffer
+    sink = TupleSink(str(tmp_path))
+    s = torch.zeros(5, 17, 7, 10, 9, dtype=torch.float16)
+    s[:, 16] = 1
+    p = torch.rand(5, 2086)
+    z = torch.tensor([1., -1, 0, 1, -1])
+    sink.append(s, p, z, games=1)
+    assert sink.flush() == 5
+    sink2 = TupleSink(str(tmp_path))
+    sink2.append(s[:2], p[:2], z[:2], games=1)
+    assert sink2.flush() == 7
+    st = np.load(tmp_path / "states.npy", mmap_mode="r")
+    assert st.shape == (7, 17, 7, 10, 9) and st.dtype == np.float16
+    assert np.load(tmp_path / "winners.npy").tolist() == [1, -1, 0, 1, -1, 1, -1]
+    import json
+    assert json.load(open(tmp_path / "meta.json"))["iters"] == 2
+    rb = ReplayBuffer(8, "cpu")
+    rb.append(s, p, z)
+    rb.append(s, p, z)
+    assert rb.size == 8 and rb.total == 10 and rb.head == 2
+    a, b, c = rb.sample(4)
+    assert a.shape == (4, 17, 7, 10, 9) and b.shape == (4, 2086) and c.shape == (4,)

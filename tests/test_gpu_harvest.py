@@ -1,0 +1,141 @@
+"""GPU: per-move bookkeeping and training-tuple harvest against a NumPy restatement of
+reference game.py:133-237 + collect.py:64-131 built on the oracle's positions."""
+import numpy as np
+import pytest
+import torch
+
+from golden_cases import STARTS
+
+pytestmark = pytest.mark.gpu
+
+
+def _expected_rows(positions, turns, pis, winner, fm, quirks, mirror):
+    """positions[t] = squares before move t; pis[t] dense float64[2086]; returns (states, pi, z)."""
+    T = len(positions)
+
+    def planes(sq):
+        red = np.zeros((7, 90), np.float16)
+        black = np.zeros((7, 90), np.float16)
+        for s in np.nonzero(sq)[0]:
+            pc = int(sq[s])
+            (black if pc & 8 else red)[(pc & 7) - 1, s] = 1
+        return red.reshape(7, 10, 9), black.reshape(7, 10, 9)
+
+    dec = [planes(p) for p in positions]
+    rows_s, rows_p, rows_z = [], [], []
+    for t in range(T):
+        te = T - 1 if quirks else t
+        red = [dec[max(te - i, 0)][0] for i in range(8)]      # game.py:36-44 newest first, start position before that
+        black = [dec[max(te - i, 0)][1] for i in range(8)]
+        turn_plane = np.ones((1, 7, 10, 9), np.float16) if (quirks or turns[t]) else np.zeros((1, 7, 10, 9), np.float16)
+        rows_s.append(np.concatenate((red, black, turn_plane), axis=0))
+        rows_p.append(pis[t])
+        rows_z.append(0.0 if winner < 0 else (1.0 if turns[t] == winner else -1.0))
+    if mirror:
+        n = len(rows_s)
+        for i in range(n):
+            rows_s.append(np.stack([np.flip(g, axis=2) for g in rows_s[i]]))
+            rows_p.append(rows_p[i][fm])
+            rows_z.append(rows_z[i])
+    return np.stack(rows_s), np.stack(rows_p), np.array(rows_z, np.float32)
+
+
+@pytest.mark.parametrize("quirks,mirror", [(False, True), (True, True), (False, False)])
+def test_harvest_matches_numpy_restatement(quirks, mirror):
+    import oracle
+    from oracle import OracleBoard
+    from chinesechesszero_amd.engine import SelfPlayEngine
+    from chinesechesszero_amd.net import uniform_evaluator
+    fm = oracle.flip_map()
+    B, n, max_plies = 4, 6, 12
+    e = SelfPlayEngine(B, n_playout=n, max_plies=max_plies, reference_quirks=quirks, mirror=mirror, seed=5)
+    boards = [OracleBoard(),
+              OracleBoard.from_array(STARTS["two_rooks"], 1, 0),
+              OracleBoard.from_array(STARTS["capture_to_bare"], 1, 3),
+              OracleBoard.from_array(STARTS["rook_knight"], 0, 100)]
+    for b in range(1, B):
+        e.set_position(b, boards[b].squares(), 1 if boards[b].turn else 0, boards[b].halfmove)
+    scripted = {1: ["a7a9"], 2: ["e0e1"]}
+    rs = np.random.RandomState(11)
+    hist = [dict(pos=[], turn=[], pi=[]) for _ in range(B)]
+    done = [False] * B
+    winner = [-1] * B
+    for ply in range(max_plies + 1):
+        for _ in range(n):
+            leaf = e.select_leaves()
+            p, v = uniform_evaluator(leaf)
+            e.expand_backup(p, v)
+        rc = e.root_children()
+        temps = np.array([1.0 if ply + 1 <= 30 else 0.5] * B)
+        pi = e.root_pi(temps=temps)
+        forced = np.full(B, -1, np.int32)
+        for b in range(B):
+            if done[b]:
+                continue
+            if len(hist[b]["pos"]) >= max_plies:  # the engine adjudicates a draw at the cap
+                done[b] = True
+                continue
+            ids = boards[b].legal_ids()
+            k = int(rc["k"][b])
+            assert rc["acts"][b][:k].tolist() == ids
+            if b in scripted and ply < len(scripted[b]):
+                mv = oracle.lib().xq_move_id(*[(ord(s[0]) - 97) + 9 * int(s[1]) for s in (scripted[b][ply][:2], scripted[b][ply][2:])])
+            else:
+                mv = ids[rs.randint(len(ids))]
+            forced[b] = mv
+            dense = np.zeros(2086)
+            dense[ids] = pi[b][:k]
+            hist[b]["pos"].append(boards[b].squares())
+            hist[b]["turn"].append(1 if boards[b].turn else 0)
+            hist[b]["pi"].append(dense)
+            boards[b].push_id(mv)
+            if boards[b].is_game_over() or boards[b].is_tie():
+                done[b] = True
+                o = boards[b].outcome()
+                winner[b] = -1 if (o is None or o.winner is None) else (1 if o.winner else 0)
+        moves = e.finish_move(forced_moves=forced, temps=temps).cpu().numpy()
+        assert all(moves[b] == forced[b] for b in range(B) if forced[b] >= 0)
+        if all(done):
+            break
+    e.finish_move(forced_moves=np.full(B, -1, np.int32))  # lets boards at the cap adjudicate
+    st = e.game_status()
+    assert st["over"].tolist() == [1] * B
+    assert st["winner"].tolist() == winner
+    assert winner[1] == 1 and winner[2] == -1
+    states, pis, z = e.harvest()
+    exp = [_expected_rows(h["pos"], h["turn"], h["pi"], w, fm, quirks, mirror) for h, w in zip(hist, winner)]
+    S = np.concatenate([x[0] for x in exp])
+    P = np.concatenate([x[1] for x in exp])
+    Z = np.concatenate([x[2] for x in exp])
+    assert states.shape[0] == S.shape[0] == sum(len(h["pos"]) for h in hist) * (2 if mirror else 1)
+    assert np.array_equal(states.cpu().numpy(), S)
+    assert np.allclose(pis.cpu().numpy(), P, rtol=0, atol=1e-7)      # float32 rows of float64 pi
+    assert np.array_equal(z.cpu().numpy(), Z)
+    assert np.allclose(pis.sum(1).cpu().numpy(), 1.0, atol=1e-5)
+    # harvested boards restarted from the opening position with fresh trees
+    st = e.game_status()
+    assert st["over"].sum() == 0 and st["plies"].sum() == 0
+    from golden_cases import start_position
+    assert np.array_equal(e.root_positions(), np.stack([start_position()] * B))
+    assert e.root_children()["k"].sum() == 0
+    e.check_healthy()
+
+
+def test_staggered_restart_and_stats():
+    """Boards finish at different plies, are harvested and restarted while the others keep searching."""
+    from chinesechesszero_amd.selfplay import BatchedSelfPlay
+    from chinesechesszero_amd.net import uniform_evaluator
+    sp = BatchedSelfPlay(uniform_evaluator, 32, n_playout=8, seed=1, max_plies=10)
+    rows = 0
+    for move in range(25):
+        sp.run_move()
+        st = sp.engine.game_status()
+        if st["over"].any():
+            s, p, z = sp.harvest()
+            assert s.shape[0] == 2 * int(st["plies"][st["over"] == 1].sum())
+            rows += s.shape[0]
+    stats = sp.engine.stats()
+    assert stats["sims"] == 32 * 8 * 25
+    assert stats["games"] >= 32 * 2 and rows >= 32 * 2 * 10 * 2
+    assert stats["truncated_games"] == stats["games"]
+    sp.engine.check_healthy()
