@@ -40,7 +40,9 @@ def parse():
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="replay one simulation as a hipGraph")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse "
+                    "the N>1 control flow with several ranks sharing one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -123,11 +125,17 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     import torch.distributed as dist
+    if a.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
+    xdev = dev if a.backend == "nccl" else torch.device("cpu")  # where the exchange buffers live
 
     from chinesechesszero_amd.net import PolicyValueNet, uniform_evaluator
     from chinesechesszero_amd.replay import TupleGatherer
@@ -142,9 +150,9 @@ def main():
     else:
         evaluator = uniform_evaluator
     sp = BatchedSelfPlay(evaluator, B, n_playout=n, seed=0, board_id_base=rank * B, device=local_rank,
-                         sampling="device", use_graph=a.graph)
+                         sampling="device")
     e = sp.engine
-    gather = TupleGatherer(512, dev) if world > 1 else None
+    gather = TupleGatherer(512, xdev) if world > 1 else None
 
     def per_move():
         sp.finish_move()
@@ -152,35 +160,40 @@ def main():
         if st["over"].any() or world > 1:
             s, p, z = e.harvest() if st["over"].any() else (e.leaf_input[:0], torch.empty((0, 2086), device=dev), torch.empty((0,), device=dev))
             if gather is not None:
-                gather.gather(s, p, z)
+                gather.gather(s.to(xdev), p.to(xdev), z.to(xdev))
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     step_no = [0]
+    state = {"leaf": None}
 
     def run(steps, timed):
+        """steps x [evaluator -> fused k_step (expand+backup of this leaf, select of the next)]; a move boundary
+        flushes with expand_backup, plays the move and re-selects."""
         pairs = []
         for _ in range(steps):
+            if state["leaf"] is None:
+                state["leaf"] = e.select_leaves()
+            last_of_move = (step_no[0] + 1) % n == 0
             if timed:
-                e0, e1, e2, e3 = ev(), ev(), ev(), ev()
+                e0, e1, e2 = ev(), ev(), ev()
                 e0.record()
-                leaf = e.select_leaves()
+            prob, value = evaluator(state["leaf"])
+            if timed:
                 e1.record()
-                prob, value = evaluator(leaf)
-                e2.record()
+            if last_of_move:
                 e.expand_backup(prob, value)
-                e3.record()
-                pairs.append((e0, e1, e2, e3))
-            elif sp._graph is not None:
-                sp._graph.replay()
+                state["leaf"] = None
             else:
-                sp.simulate()
+                state["leaf"] = e.step(prob, value)
+            if timed:
+                e2.record()
+                if not last_of_move:
+                    pairs.append((e0, e1, e2))
             step_no[0] += 1
-            if step_no[0] % n == 0:
+            if last_of_move:
                 per_move()
         return pairs
 
-    if a.graph:
-        sp._capture()
     run(a.warmup, False)
     torch.cuda.synchronize()
     s0 = e.stats()
@@ -188,14 +201,14 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pairs = run(a.steps, not a.graph)
+    pairs = run(a.steps, True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     s1 = e.stats()
@@ -209,25 +222,24 @@ def main():
     if rank == 0:
         value = world * B * a.steps / dt
         if pairs:
-            t_sel = float(np.mean([p[0].elapsed_time(p[1]) for p in pairs])) * 1e-3
-            t_net = float(np.mean([p[1].elapsed_time(p[2]) for p in pairs])) * 1e-3
-            t_exp = float(np.mean([p[2].elapsed_time(p[3]) for p in pairs])) * 1e-3
+            t_net = float(np.mean([p[0].elapsed_time(p[1]) for p in pairs])) * 1e-3
+            t_step = float(np.mean([p[1].elapsed_time(p[2]) for p in pairs])) * 1e-3
         else:
-            t_sel = t_net = t_exp = float("nan")
-        # algorithmic bytes per simulation, SURVEY 8(d), split over the two simulator kernels. The
+            t_net = t_step = float("nan")
+        # algorithmic bytes per simulation, SURVEY 8(d): the fused k_step kernel does all of it. The
         # 21,420-B evaluator input is counted at the 3,780 B that can be non-zero (groups 7/15/16);
         # the 14 static-zero groups are written once at create, not per simulation.
         a_sel = 3780 + 12 * kbar * dbar + 6 * dbar + 180 + 2 * kbar
         a_exp = (4 * kbar + 4) + 18 * kbar + 16 * (dbar + 1)
-        a_sim_survey = 21420 + (4 * kbar + 4) + 18 * kbar + 12 * kbar * dbar + 6 * dbar + 16 * (dbar + 1) + 180 + 2 * kbar
-        ach_sel = a_sel * B / t_sel if t_sel == t_sel else None
-        ach_exp = a_exp * B / t_exp if t_exp == t_exp else None
+        a_step = a_sel + a_exp
+        a_sim_survey = a_step - 3780 + 21420
+        ach = a_step * B / t_step if t_step == t_step else None
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
             try:
                 with open(pmc) as f:
-                    traffic = json.load(f).get("k_select", {}).get("hbm_bytes_per_launch")
+                    traffic = json.load(f).get("k_step", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         flops = 8.551e9 * (a.blocks / 40.0) * (a.channels / 256.0) ** 2
@@ -239,17 +251,14 @@ def main():
             "config": {"workload": f"{B} concurrent boards/GPU x {n} sims/move, Dirichlet root noise on (device Philox), "
                                    f"{'random-init %dx%d policy-value net fp16' % (a.blocks, a.channels) if a.evaluator == 'net' else 'stub evaluator (uniform priors, v=0)'}"
                                    ", all boards from the opening position",
-                       "boards_per_gpu": B, "sims_per_move": n, "evaluator": a.evaluator, "hipgraph": bool(a.graph)},
+                       "boards_per_gpu": B, "sims_per_move": n, "evaluator": a.evaluator},
             "moves_per_sec": value / n,
-            "roofline": {"bound": "hbm", "kernel": "k_select", "achieved": (ach_sel or 0) / 1e9, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": (ach_sel or 0) / HBM_PEAK, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": a_sel * B, "avg_launch_us": t_sel * 1e6,
+            "roofline": {"bound": "hbm", "kernel": "k_step (fused expand+backup+select+movegen+encode)",
+                         "achieved": (ach or 0) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": (ach or 0) / HBM_PEAK,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": a_step * B, "avg_launch_us": t_step * 1e6,
                          "k_bar": kbar, "d_bar": dbar},
-            "roofline_expand_backup": {"bound": "hbm", "kernel": "k_expand_backup", "achieved": (ach_exp or 0) / 1e9,
-                                       "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": (ach_exp or 0) / HBM_PEAK,
-                                       "algorithmic_bytes_per_launch": a_exp * B, "avg_launch_us": t_exp * 1e6},
             "survey_a_sim_bytes": a_sim_survey,
-            "step_split_us": {"select": t_sel * 1e6, "evaluator": t_net * 1e6, "expand_backup": t_exp * 1e6},
+            "step_split_us": {"k_step": t_step * 1e6, "evaluator": t_net * 1e6},
             "net_tflops": (flops * B / t_net / 1e12) if (a.evaluator == "net" and t_net == t_net) else None,
             "engine_hbm_gb": s1["hbm_bytes"] / 1e9, "nodes_peak": s1["nodes_peak"], "depth_peak": s1["depth_peak"],
         }

@@ -67,6 +67,7 @@ PROTOTYPES = {
     "ccz_select_leaves": (C.c_int, [_P, _P, _P]),
     "ccz_zero_leaf_input": (C.c_int, [_P, _P, _P]),
     "ccz_expand_backup": (C.c_int, [_P, _P, _P, _P]),
+    "ccz_step": (C.c_int, [_P, _P, _P, _P, _P]),
     "ccz_finish_move": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32]),
     "ccz_root_children": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "ccz_root_pi": (C.c_int, [_P, _P, _P, _P]),

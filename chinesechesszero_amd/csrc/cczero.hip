@@ -252,6 +252,16 @@ int ccz_expand_backup(ccz_engine *e, void *stream, const float *prob_dev, const 
     return 0;
 }
 
+int ccz_step(ccz_engine *e, void *stream, const float *prob_dev, const float *value_dev, void *leaf_input_f16_dev)
+{
+    NEED(e);
+    if (!prob_dev || !value_dev) return fail(-1, "ccz_step: null prob/value");
+    hipLaunchKernelGGL(k_step, dim3(e->d.B), dim3(64), 0, (hipStream_t)stream, e->d, prob_dev, value_dev,
+                       (uint16_t *)leaf_input_f16_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int ccz_finish_move(ccz_engine *e, void *stream, const int32_t *forced_moves_dev, const double *temps_dev,
                     int32_t *moves_out_dev, int32_t keep_tree)
 {

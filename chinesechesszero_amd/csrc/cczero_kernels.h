@@ -111,47 +111,57 @@ __device__ inline LeafEval eval_position(const uint8_t *s_sq, int turn, int half
 }
 
 // ------------------------------------------------------------------ K1: select + make-move + movegen + terminal + encode
-__global__ __launch_bounds__(64) void k_select(Dev D, uint16_t *leaf_in)
-{
-    const int b = blockIdx.x, lane = threadIdx.x;
-    __shared__ __align__(16) uint8_t s_sq[96];
-    __shared__ uint64_t s_chain[kChainCap];
-    __shared__ GenScratch S;
+struct SelectShared {
+    __align__(16) uint8_t sq[96];
+    uint64_t chain[kChainCap];
+    GenScratch S;
+};
 
+// One wave: PUCT descent from the root of board b, leaf rules, evaluator input. Per tree level there is
+// ONE dependent global load round (the children's 16-B NodeA records + their move/count words); the
+// chosen child's own N / first_child / count are broadcast from the winning lane, not re-read.
+__device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *leaf_in, SelectShared &sh)
+{
+    uint8_t *s_sq = sh.sq;
+    uint64_t *s_chain = sh.chain;
     const BoardMeta m = D.meta[b];
     if (m.over) {
         if (lane == 0) D.leaf_status[b] = CCZ_LEAF_SKIP;
         return;
     }
+    const size_t base = ((size_t)b * 2 + m.half) * (size_t)D.cap;
+    const NodeA *A = D.nodeA + base;
+    const uint32_t *Bn = D.nodeB + base;
+    // independent loads issued together: root record, root board, hash chain
+    NodeA pa = A[0];
+    uint32_t nb = Bn[0];
     if (lane < 24) ((uint32_t *)s_sq)[lane] = ((const uint32_t *)(D.root_sq + (size_t)b * 96))[lane];
     for (int i = lane; i < m.chain_len; i += 64) s_chain[i] = D.chain[(size_t)b * kChainCap + i];
     __syncthreads();
 
-    const size_t base = ((size_t)b * 2 + m.half) * (size_t)D.cap;
-    const NodeA *A = D.nodeA + base;
-    const uint32_t *Bn = D.nodeB + base;
     int32_t *path = D.path + (size_t)b * D.maxd;
-    int node = 0, depth = 0, turn = m.turn, halfmove = m.halfmove, chain_len = m.chain_len;
+    int depth = 0, turn = m.turn, halfmove = m.halfmove, chain_len = m.chain_len;
     uint64_t key = m.key;
     bool bad = false;
     if (lane == 0) path[0] = 0;
 
     // ---- PUCT descent (mcts.py:105-111, 41-61)
     for (;;) {
-        const int nc = (int)(Bn[node] >> 16);
+        const int nc = (int)(nb >> 16);
         if (nc == 0) break;
-        const NodeA pa = A[node];
         const double sqrtNp = sqrt((double)pa.N); // np.sqrt(parent.visits): float64
         double best = -__builtin_huge_val();
-        int besti = 0x7fffffff;
+        int besti = 0x7fffffff, bN = 0, bfc = -1;
+        uint32_t bw = 0;
         for (int c0 = 0; c0 < nc; c0 += 64) {
             const int i = c0 + lane;
             if (i < nc) {
                 const NodeA c = A[pa.fc + i];
+                const uint32_t w = Bn[pa.fc + i];
                 // value + c_puct*prob*sqrt(N_parent)/(1+N): float32 product, float64 elsewhere; inf if unvisited
                 const double sc = c.N == 0 ? __builtin_huge_val()
                                            : (double)c.Q + (double)(D.c_puct * c.P) * sqrtNp / (double)(1 + c.N);
-                if (sc > best) { best = sc; besti = i; }
+                if (sc > best) { best = sc; besti = i; bN = c.N; bfc = c.fc; bw = w; }
             }
         }
 #pragma unroll
@@ -161,8 +171,13 @@ __global__ __launch_bounds__(64) void k_select(Dev D, uint16_t *leaf_in)
             if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
         }
         if (besti >= nc) { bad = true; set_err(D, 32); break; } // NaN priors: no comparable child
+        // the winning index sits in lane besti%64, whose running best is that very child
+        const int owner = besti & 63;
         const int child = pa.fc + besti;
-        const int mv = (int)(Bn[child] & 0xffffu);
+        pa.N = __shfl(bN, owner);
+        pa.fc = __shfl(bfc, owner);
+        nb = (uint32_t)__shfl((int)bw, owner);
+        const int mv = (int)(nb & 0xffffu);
         // board.push(move)  (mcts.py:111)
         const int from = c_tab.from[mv], to = c_tab.to[mv];
         const int pc = s_sq[from], cap = s_sq[to];
@@ -178,7 +193,6 @@ __global__ __launch_bounds__(64) void k_select(Dev D, uint16_t *leaf_in)
         ++depth;
         if (depth >= D.maxd) { bad = true; set_err(D, 2); break; }
         if (lane == 0) path[depth] = child;
-        node = child;
         __syncthreads();
     }
     __syncthreads();
@@ -189,7 +203,7 @@ __global__ __launch_bounds__(64) void k_select(Dev D, uint16_t *leaf_in)
 
     // ---- leaf: legal moves (net.py:154-157), game end (mcts.py:116-117)
     bool overflow;
-    const LeafEval L = eval_position(s_sq, turn, halfmove, key, s_chain, chain_len, S,
+    const LeafEval L = eval_position(s_sq, turn, halfmove, key, s_chain, chain_len, sh.S,
                                      D.leaf_ids + (size_t)b * kMaxLegal, lane, overflow);
     if (overflow) set_err(D, 4);
     if (lane == 0) {
@@ -221,10 +235,15 @@ __global__ __launch_bounds__(64) void k_select(Dev D, uint16_t *leaf_in)
     }
 }
 
-// ------------------------------------------------------------------ K2: expand + backup
-__global__ __launch_bounds__(64) void k_expand_backup(Dev D, const float *prob, const float *value)
+__global__ __launch_bounds__(64) void k_select(Dev D, uint16_t *leaf_in)
 {
-    const int b = blockIdx.x, lane = threadIdx.x;
+    __shared__ SelectShared sh;
+    select_phase(D, blockIdx.x, threadIdx.x, leaf_in, sh);
+}
+
+// ------------------------------------------------------------------ K2: expand + backup
+__device__ inline void expand_backup_phase(const Dev &D, int b, int lane, const float *prob, const float *value)
+{
     const int status = D.leaf_status[b];
     if (status == CCZ_LEAF_SKIP) return;
     BoardMeta *mp = D.meta + b;
@@ -265,7 +284,10 @@ __global__ __launch_bounds__(64) void k_expand_backup(Dev D, const float *prob, 
         v = status == CCZ_LEAF_DRAW ? 0.0f : -1.0f; // mcts.py:120-126
         if (lane == 0) D.stats[b].terminal += 1;
     }
-    if (lane == 0) D.stats[b].sims += 1;
+    if (lane == 0) {
+        D.stats[b].sims += 1;
+        D.leaf_status[b] = CCZ_LEAF_SKIP; // consumed: a repeated call must not back the same leaf up twice
+    }
     // Node.update_recursive(-leaf_value) (mcts.py:73-78,129): leaf gets -v, its parent +v, ...
     for (int j = lane; j <= d; j += 64) {
         const int node = path[j];
@@ -280,6 +302,24 @@ __global__ __launch_bounds__(64) void k_expand_backup(Dev D, const float *prob, 
         *np_ = n;
         *qp = q + delta;
     }
+}
+
+__global__ __launch_bounds__(64) void k_expand_backup(Dev D, const float *prob, const float *value)
+{
+    expand_backup_phase(D, blockIdx.x, threadIdx.x, prob, value);
+}
+
+// ------------------------------------------------------------------ fused step: expand+backup of the pending leaf, then the next select
+// Saves one launch boundary and the re-read of the board's tree head per simulation. The phases
+// touch the same nodes from different lanes, so a workgroup barrier (one wave) separates them.
+__global__ __launch_bounds__(64) void k_step(Dev D, const float *prob, const float *value, uint16_t *leaf_in)
+{
+    __shared__ SelectShared sh;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    expand_backup_phase(D, b, lane, prob, value);
+    __threadfence_block();
+    __syncthreads();
+    select_phase(D, b, lane, leaf_in, sh);
 }
 
 // ------------------------------------------------------------------ pi from root visits (mcts.py:162-166)

@@ -94,6 +94,17 @@ class SelfPlayEngine:
             raise ValueError("prob/value must be contiguous device tensors")
         check(self.L.ccz_expand_backup(self.h, self._stream(), _ptr(prob), _ptr(value)))
 
+    def step(self, prob: torch.Tensor, value: torch.Tensor) -> torch.Tensor:
+        """Fused expand_backup(prob, value) for the pending leaf + select_leaves() for the next simulation."""
+        if prob.dtype != torch.float32 or value.dtype != torch.float32:
+            raise TypeError("prob and value must be float32")
+        if tuple(prob.shape) != (self.B, NMOVES) or value.numel() != self.B:
+            raise ValueError(f"prob must be [{self.B},{NMOVES}] and value [{self.B}]")
+        if not (prob.is_cuda and value.is_cuda and prob.is_contiguous() and value.is_contiguous()):
+            raise ValueError("prob/value must be contiguous device tensors")
+        check(self.L.ccz_step(self.h, self._stream(), _ptr(prob), _ptr(value), _ptr(self.leaf_input)))
+        return self.leaf_input
+
     # ------------------------------------------------------------------ once per move
     def finish_move(self, forced_moves=None, temps=None, keep_tree: bool = True) -> torch.Tensor:
         """Record pi, choose (or accept) the move, re-root, push, detect game end. Returns moves int32[B] (device)."""

@@ -19,7 +19,7 @@ class BatchedSelfPlay:
 
     def __init__(self, evaluator, n_boards: int, n_playout: int = 400, c_puct: float = C_PUCT, eps: float = EPS,
                  alpha: float = ALPHA, temp: float = 1.0, seed: int = 0, board_id_base: int = 0, device: int = 0,
-                 sampling: str = "device", use_graph: bool = False, **engine_kw):
+                 sampling: str = "device", **engine_kw):
         if sampling not in ("device", "numpy"):
             raise ValueError("sampling must be 'device' (Philox on the GPU) or 'numpy' (reference-exact host RNG)")
         self.evaluator = evaluator
@@ -31,8 +31,6 @@ class BatchedSelfPlay:
         self.eps, self.alpha, self.temp = eps, alpha, temp
         # reference-exact host sampling: one legacy RandomState per board (mcts.py:216-224 uses the global one)
         self.rngs = [np.random.RandomState((seed + board_id_base + b) % (2**32)) for b in range(n_boards)] if sampling == "numpy" else None
-        self._graph = None
-        self.use_graph = use_graph
 
     # one lockstep simulation of every board
     def simulate(self):
@@ -41,31 +39,20 @@ class BatchedSelfPlay:
         prob, value = self.evaluator(leaf)
         e.expand_backup(prob, value)
 
-    def _capture(self):
-        """hipGraph of one simulation (select -> net -> expand/backup): launch-bound at small B."""
-        e = self.engine
-        s = torch.cuda.Stream(device=e.device)
-        s.wait_stream(torch.cuda.current_stream(e.device))
-        with torch.cuda.stream(s):
-            for _ in range(2):
-                self.simulate()  # warm-up outside capture (MIOpen find, allocator)
-        torch.cuda.current_stream(e.device).wait_stream(s)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self.simulate()
-        self._graph = g
-
     def run_move(self, on_playout=None):
-        """n_playout simulations then one move on every board. Returns the moves (device int32 [B])."""
-        if self.use_graph and self._graph is None:
-            self._capture()
+        """n_playout simulations then one move on every board. Returns the moves (device int32 [B]).
+
+        Launch sequence: select, (evaluator, fused step) x (n-1), evaluator, expand_backup."""
+        e = self.engine
         interval = max(1, self.n_playout // 100)
         acc = 0
+        leaf = e.select_leaves()
         for i in range(self.n_playout):
-            if self._graph is not None:
-                self._graph.replay()
+            prob, value = self.evaluator(leaf)
+            if i + 1 < self.n_playout:
+                leaf = e.step(prob, value)
             else:
-                self.simulate()
+                e.expand_backup(prob, value)
             acc += 1
             if on_playout is not None and (acc >= interval or i == self.n_playout - 1):
                 try:

@@ -96,7 +96,8 @@ typedef struct ccz_stats {
 #define CCZ_ERR_DEPTH 2       /* a selection path exceeded max_depth                             */
 #define CCZ_ERR_MOVES 4       /* more than CCZ_MAX_LEGAL legal moves / pseudo-move overflow       */
 #define CCZ_ERR_RECORD 8      /* pi record arena overflow (game adjudicated)                     */
-#define CCZ_ERR_BAD_MOVE 16   /* a forced move is not a child of the root                        */
+#define CCZ_ERR_BAD_MOVE 16   /* forced move id invalid / nothing searched and nothing forced    */
+#define CCZ_ERR_NAN 32        /* NaN priors: no comparable child during selection                */
 
 /* ---- library ---------------------------------------------------------------------------- */
 int ccz_abi_version(void);
@@ -135,6 +136,12 @@ int ccz_zero_leaf_input(ccz_engine *e, void *stream, void *leaf_input_f16_dev);
  * in ascending id order, leaf value value_dev[b] (float32 [B], side to move's view) or the terminal
  * value, and Node.update_recursive up the path. */
 int ccz_expand_backup(ccz_engine *e, void *stream, const float *prob_dev, const float *value_dev);
+
+/* Fused form of "ccz_expand_backup for the pending leaf, then ccz_select_leaves for the next
+ * simulation" in ONE launch (one launch boundary and one tree-head re-read less per simulation).
+ * A move of n simulations is: select, (evaluator, step) x (n-1), evaluator, expand_backup. */
+int ccz_step(ccz_engine *e, void *stream, const float *prob_dev, const float *value_dev,
+             void *leaf_input_f16_dev);
 
 /* ---- once per move ------------------------------------------------------------------------ */
 /* Replaces MCTS.get_move_probs' tail (mcts.py:162-166), MCTS_AI.get_action's choice

@@ -53,16 +53,17 @@ class Lockstep:
         self.ev = make_evaluator(kind, self.salts)
         self.mcts = [OracleMCTS(None, c_puct=c_puct, n_playout=0) for _ in range(self.B)]
 
-    def step(self, check_leaf=True):
+    def _after_select(self, check_leaf):
+        """Leaf of every board is selected on the engine: select on the oracles too, compare, evaluate."""
         e = self.e
-        leaf_in = e.select_leaves()
-        planes = leaf_in.float().cpu().numpy()
+        planes = e.leaf_input.float().cpu().numpy()
         info = e.leaf_info()
         sq, turn = planes_to_squares(planes)
         P, V = self.ev(sq, turn)
-        # oracle side
+        pending = []
         for b in range(self.B):
             if info["status"][b] == 3:
+                pending.append(None)
                 continue
             leaf, depth = self.mcts[b].select(self.boards[b])
             ids = leaf.legal_ids()
@@ -76,8 +77,34 @@ class Lockstep:
                 want = 0 if (not end and not tie) else (1 if (end and tie) else 2)
                 assert info["status"][b] == want, (b, info["status"][b], want)
                 assert np.array_equal(planes[b], leaf.leaf_planes())
-            self.mcts[b].expand_backup(leaf, ids, P[b][ids], V[b])
+            pending.append((leaf, ids))
+        return P, V, pending
+
+    def _oracle_backup(self, P, V, pending):
+        for b, item in enumerate(pending):
+            if item is not None:
+                leaf, ids = item
+                self.mcts[b].expand_backup(leaf, ids, P[b][ids], V[b])
+
+    def step(self, check_leaf=True):
+        e = self.e
+        e.select_leaves()
+        P, V, pending = self._after_select(check_leaf)
+        self._oracle_backup(P, V, pending)
         e.expand_backup(torch.from_numpy(P).to(e.device), torch.from_numpy(V).to(e.device))
+
+    def run_fused(self, n, check_leaf=True):
+        """n simulations through the fused launch sequence: select, (evaluate, step) x (n-1), evaluate, expand_backup."""
+        e = self.e
+        e.select_leaves()
+        for i in range(n):
+            P, V, pending = self._after_select(check_leaf)
+            self._oracle_backup(P, V, pending)
+            tp, tv = torch.from_numpy(P).to(e.device), torch.from_numpy(V).to(e.device)
+            if i + 1 < n:
+                e.step(tp, tv)
+            else:
+                e.expand_backup(tp, tv)
 
     def compare_roots(self):
         rc = self.e.root_children()

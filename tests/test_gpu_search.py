@@ -35,6 +35,31 @@ def test_lockstep_matches_oracle_every_step():
     e.check_healthy()
 
 
+def test_fused_step_kernel_matches_oracle():
+    """The fused expand_backup+select launch (ccz_step) walks exactly the same trees as the two-kernel form."""
+    from gpu_harness import Lockstep
+    from oracle import OracleBoard
+    from golden_cases import STARTS
+    B = 6
+    e = _engine(B, 80)
+    boards = [OracleBoard(), OracleBoard(), OracleBoard.from_array(STARTS["two_rooks"], 1, 112),
+              OracleBoard.from_array(STARTS["rook_knight"], 0, 100), OracleBoard.from_array(STARTS["capture_to_bare"], 1, 0),
+              OracleBoard()]
+    for b in (2, 3, 4):
+        e.set_position(b, boards[b].squares(), 1 if boards[b].turn else 0, boards[b].halfmove)
+    ls = Lockstep(e, boards, kind="hash_sharp", salts=[5, 6, 7, 8, 9, 10])
+    for ply in range(2):
+        ls.run_fused(80, check_leaf=True)
+        rc = ls.compare_roots()
+        over = e.game_status()["over"]
+        ls.play([-1 if (over[b] or rc["k"][b] == 0) else int(rc["acts"][b][int(np.argmax(rc["visits"][b][:rc["k"][b]]))])
+                 for b in range(B)])
+    ls.compare_roots()
+    st = e.stats()
+    assert st["sims"] >= 3 * 160 and st["terminal_leaves"] > 0
+    e.check_healthy()
+
+
 def test_uniform_priors_exact_ties_first_max_order():
     from gpu_harness import Lockstep
     from oracle import OracleBoard
