@@ -121,7 +121,7 @@ int ccz_create(const ccz_config *cfg, ccz_engine **out)
     d.B = cfg->n_boards;
     // nodes per pool half: every playout creates <= ~k children; the retained subtree adds to it
     const int n_play = cfg->n_playout > 0 ? cfg->n_playout : 400;
-    d.cap = cfg->max_nodes > 0 ? cfg->max_nodes : (n_play + 64) * 112;
+    d.cap = cfg->max_nodes > 0 ? cfg->max_nodes : (n_play + 64) * 256;
     d.maxd = cfg->max_depth > 0 ? cfg->max_depth : 512;
     d.max_plies = cfg->max_plies > 0 ? cfg->max_plies : 2048;
     d.pi_cap = d.max_plies * 48;
