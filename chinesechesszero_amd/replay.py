@@ -119,3 +119,17 @@ class ReplayBuffer:
     def sample(self, batch: int, generator=None):
         idx = torch.randint(0, self.size, (batch,), device=self.states.device, generator=generator)
         return self.states[idx], self.pi[idx], self.z[idx]
+
+
+def broadcast_model(policy_value_net, src: int = 0, group=None):
+    """Model hot-reload across ranks: broadcast every parameter and buffer of the
+    ``PolicyValueNet`` from ``src`` (the trainer's rank) and rebuild the inference copy. The reference's
+    collector loads its model once per process and never refreshes it (collect.py:49)."""
+    net = policy_value_net.policy_value_net
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        with torch.no_grad():
+            for t in list(net.parameters()) + list(net.buffers()):
+                dist.broadcast(t.data, src=src, group=group)
+    if hasattr(policy_value_net, "refresh_inference_copy"):
+        policy_value_net.refresh_inference_copy()
+    return policy_value_net

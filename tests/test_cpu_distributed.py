@@ -76,3 +76,39 @@ def test_board_id_streams_independent_of_gpu_count():
     whole = [oracle.det_sample(7, gid, 0, pi)[0] for gid in range(8)]
     shards = [oracle.det_sample(7, r * 4 + b, 0, pi)[0] for r in range(2) for b in range(4)]
     assert whole == shards and len(set(whole)) > 1
+
+
+def _bcast_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from chinesechesszero_amd.net import PolicyValueNet
+        from chinesechesszero_amd.replay import broadcast_model
+        torch.manual_seed(10 + rank)  # different weights on every rank before the reload
+        pvn = PolicyValueNet(use_gpu=False, device="cpu", num_channels=8, resblocks_num=1)
+        for m in pvn.policy_value_net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.fill_(float(rank + 1))
+        broadcast_model(pvn, src=0)
+        sd = pvn.policy_value_net.state_dict()
+        digest = float(sum(v.double().abs().sum() for v in sd.values()))
+        q.put((rank, True, digest, float(sd["conv_block_bn.running_mean"][0])))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        q.put((rank, False, repr(e), 0.0))
+
+
+def test_model_hot_reload_broadcast_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bcast_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] for r in res), res
+    assert res[0][2] == res[1][2] and res[0][3] == res[1][3] == 1.0  # rank 1 now holds rank 0's weights and BN stats

@@ -115,3 +115,27 @@ def test_tuple_sink_and_replay_buffer(tmp_path):
     assert rb.size == 8 and rb.total == 10 and rb.head == 2
     a, b, c = rb.sample(4)
     assert a.shape == (4, 17, 7, 10, 9) and b.shape == (4, 2086) and c.shape == (4,)
+
+
+def test_uci_fen_parsing_roundtrip():
+    from chinesechesszero_amd.game import Board, start_squares
+    from chinesechesszero_amd.uci import board_from_fen, parse_position
+    b = parse_position(["startpos"])
+    assert np.array_equal(b.squares(), start_squares()) and b.turn is True
+    fen = Board().fen()
+    assert fen == "rnbakabnr/9/1c5c1/p1p1p1p1p/9/9/P1P1P1P1P/1C5C1/9/RNBAKABNR w - - 0 1"
+    b2 = board_from_fen(fen)
+    assert np.array_equal(b2.squares(), start_squares()) and b2.turn is True and b2.halfmove_clock == 0
+    b3 = board_from_fen("4k4/9/9/9/9/9/9/9/4R4/3K5 b - - 37 60")
+    assert b3.turn is False and b3.halfmove_clock == 37 and b3.piece_at(3).piece_type == 7 and b3.piece_at(13).piece_type == 3
+    assert b3.piece_at(85).color is False and b3.fen().startswith("4k4/9/9/9/9/9/9/9/4R4/3K5 b")
+    with pytest.raises(ValueError):
+        board_from_fen("9/9/9 w")
+    with pytest.raises(ValueError):
+        parse_position(["fen"])
+    # host-side push bookkeeping (no rules involved)
+    b.push("b2e2")
+    assert b.turn is False and b.halfmove_clock == 1 and b.piece_at(4 + 18).piece_type == 2 and b.peek().uci() == "b2e2"
+    b.push("h9g7")
+    b.push("e2e6")  # cannon takes the pawn: clock resets
+    assert b.halfmove_clock == 0 and len(b.move_stack) == 3 and len(b._chain) == 1
