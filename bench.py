@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-every", type=int, default=0, help="BASELINE config 5: rank 0 runs one trainer update "
+                    "(batch 2048, side stream, GPU0) every this many simulation steps, fed from the replay buffer")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse "
                     "the N>1 control flow with several ranks sharing one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -154,13 +156,31 @@ def main():
     e = sp.engine
     gather = TupleGatherer(512, xdev) if world > 1 else None
 
+    trainer = None
+    if a.train_every > 0 and rank == 0:
+        from chinesechesszero_amd.replay import ReplayBuffer
+        from chinesechesszero_amd.trainer import Trainer
+        torch.manual_seed(1)
+        trainer = Trainer(PolicyValueNet(device=dev, num_channels=a.channels, resblocks_num=a.blocks))
+        rb = ReplayBuffer(32768, dev)
+        # no game finishes within a short bench window: prefill the buffer with synthetic rows so that the
+        # trainer runs at its steady-state cadence next to self-play ("data": "synthetic")
+        g = torch.Generator(device=dev).manual_seed(2)
+        ps = torch.rand((8192, 2086), device=dev, generator=g)
+        rb.append((torch.rand((8192, 17, 7, 10, 9), device=dev, generator=g) > 0.9).half(), ps / ps.sum(1, keepdim=True),
+                  torch.randint(-1, 2, (8192,), device=dev, generator=g).float())
+        side = torch.cuda.Stream(device=dev)
+        train_steps = [0]
+
     def per_move():
         sp.finish_move()
         st = e.game_status()
         if st["over"].any() or world > 1:
             s, p, z = e.harvest() if st["over"].any() else (e.leaf_input[:0], torch.empty((0, 2086), device=dev), torch.empty((0,), device=dev))
             if gather is not None:
-                gather.gather(s.to(xdev), p.to(xdev), z.to(xdev))
+                s, p, z = gather.gather(s.to(xdev), p.to(xdev), z.to(xdev))
+            if trainer is not None and s.shape[0]:
+                rb.append(s.to(dev), p.to(dev), z.to(dev))
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     step_no = [0]
@@ -190,6 +210,10 @@ def main():
                 if not last_of_move:
                     pairs.append((e0, e1, e2))
             step_no[0] += 1
+            if trainer is not None and step_no[0] % a.train_every == 0:
+                with torch.cuda.stream(side):
+                    trainer.step(*rb.sample(2048), sync=False)
+                train_steps[0] += 1
             if last_of_move:
                 per_move()
         return pairs
@@ -259,6 +283,7 @@ def main():
                          "k_bar": kbar, "d_bar": dbar},
             "survey_a_sim_bytes": a_sim_survey,
             "step_split_us": {"k_step": t_step * 1e6, "evaluator": t_net * 1e6},
+            "trainer_updates": (train_steps[0] if trainer is not None else 0),
             "net_tflops": (flops * B / t_net / 1e12) if (a.evaluator == "net" and t_net == t_net) else None,
             "engine_hbm_gb": s1["hbm_bytes"] / 1e9, "nodes_peak": s1["nodes_peak"], "depth_peak": s1["depth_peak"],
         }

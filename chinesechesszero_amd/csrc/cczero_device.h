@@ -103,65 +103,81 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane)
 }
 
 // ------------------------------------------------------------------ rules
+// Sliding pieces and king-safety rays work on OCCUPANCY WORDS (one per rank and per file) with
+// ctz / bit-reverse instead of square-by-square ray walks: straight-line code, no divergent loops
+// (the ray-walk version spent half its instructions on exec-mask bookkeeping).
 struct GenScratch {
+    uint16_t R[10];   // bit f of R[r]: square (rank r, file f) occupied
+    uint16_t F[10];   // bit r of F[f]: square (rank r, file f) occupied  (F[9] unused)
     uint8_t plist[16];
-    uint8_t cand[64 * 10];
+    uint8_t pad_[8];
+    __align__(16) uint8_t cand[64 * 16]; // per-lane destination squares
     uint16_t list[kPseudoCap];
     uint32_t mask[kMaskWords + 2];
 };
 
+// steps (>= 1, 0 = none) from index `pos` to the first and second set bit of `word` in the +direction
+__device__ __forceinline__ void line_scan(uint32_t word, int pos, int &step1, int &step2)
+{
+    const uint32_t m = word >> (pos + 1);
+    step1 = __ffs((int)m);
+    const uint32_t m2 = m & (m - 1u);
+    step2 = __ffs((int)m2);
+}
+
 // Is the king of the side `turn` (1 RED / 0 BLACK), standing on ksq, attacked on the board that
 // results from moving `mover` from `from` to `to` (from < 0: the board as it is)? Includes the
-// facing-kings rule. Reverse rays from the king square.
-__device__ inline bool king_attacked(const uint8_t *sq, int ksq, int from, int to, int mover, int turn)
+// facing-kings rule. sq[90..95] must be 0 (index 95 serves as the "no square" dummy).
+__device__ inline bool king_attacked(const uint8_t *sq, const GenScratch &S, int ksq, int from, int to, int mover, int turn)
 {
     const int eb = turn ? 8 : 0; // enemy piece-code base
     const int eR = eb + ROOK, eC = eb + CANNON, eK = eb + KING, eN = eb + KNIGHT, eP = eb + PAWN;
     const int r = ksq / 9, f = ksq - 9 * r;
-#define AT(S) ((S) == from ? 0 : ((S) == to ? mover : (int)sq[S]))
+#define AT(S_) ((S_) == from ? 0 : ((S_) == to ? mover : (int)sq[S_]))
+    uint32_t rw = S.R[r], fw = S.F[f];
+    if (from >= 0) { // occupancy of the king's rank and file after the move
+        const int fr = from / 9, ff = from - 9 * fr, tr = to / 9, tf = to - 9 * tr;
+        rw = fr == r ? (rw & ~(1u << ff)) : rw;
+        rw = tr == r ? (rw | (1u << tf)) : rw;
+        fw = ff == f ? (fw & ~(1u << fr)) : fw;
+        fw = tf == f ? (fw | (1u << tr)) : fw;
+    }
+    bool att = false;
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        const int dr = (d == 0) - (d == 1), df = (d == 2) - (d == 3);
-        int r2 = r + dr, f2 = f + df;
-        bool seen = false;
-        while ((unsigned)r2 < 10u && (unsigned)f2 < 9u) {
-            const int s2 = f2 + 9 * r2;
-            const int q = AT(s2);
-            if (q) {
-                if (!seen) {
-                    if (q == eR || (q == eK && df == 0)) return true;
-                    seen = true;
-                } else {
-                    if (q == eC) return true;
-                    break;
-                }
-            }
-            r2 += dr; f2 += df;
-        }
+    for (int d = 0; d < 4; ++d) { // first piece on a ray: rook (or the facing king on the file); second: cannon
+        const bool horiz = d >= 2, positive = !(d & 1);
+        const int len = horiz ? 9 : 10;
+        uint32_t word = horiz ? rw : fw;
+        int pos = horiz ? f : r, delta = horiz ? 1 : 9;
+        if (!positive) { word = __brev(word) >> (32 - len); pos = len - 1 - pos; delta = -delta; }
+        int s1, s2;
+        line_scan(word, pos, s1, s2);
+        const int q1i = s1 ? ksq + s1 * delta : 95, q2i = s2 ? ksq + s2 * delta : 95;
+        const int q1 = AT(q1i), q2 = AT(q2i);
+        att |= (q1 == eR) | (!horiz && q1 == eK) | (q2 == eC);
     }
 #pragma unroll
     for (int d = 0; d < 4; ++d) { // a knight's leg is the king's diagonal neighbour
         const int a = (d & 2) ? -1 : 1, b = (d & 1) ? -1 : 1;
         const int rl = r + a, fl = f + b;
-        if ((unsigned)rl >= 10u || (unsigned)fl >= 9u) continue;
-        const int sl = fl + 9 * rl;
-        if (AT(sl)) continue;
+        const bool vl = (unsigned)rl < 10u && (unsigned)fl < 9u;
+        const int sl = vl ? fl + 9 * rl : 95;
+        const bool open = vl && AT(sl) == 0;
         const int r2 = rl + a, f3 = fl + b;
-        if ((unsigned)r2 < 10u) { const int s2 = fl + 9 * r2; if (AT(s2) == eN) return true; }
-        if ((unsigned)f3 < 9u) { const int s3 = f3 + 9 * rl; if (AT(s3) == eN) return true; }
+        const int i2 = (open && (unsigned)r2 < 10u) ? fl + 9 * r2 : 95;
+        const int i3 = (open && (unsigned)f3 < 9u) ? f3 + 9 * rl : 95;
+        att |= (AT(i2) == eN) | (AT(i3) == eN);
     }
     {
-        const int fw = turn ? -1 : 1; // direction of travel of the ENEMY pawns
-        const int rp = r - fw;
-        if ((unsigned)rp < 10u) { const int s2 = f + 9 * rp; if (AT(s2) == eP) return true; }
-        const bool crossed = turn ? (r <= 4) : (r >= 5); // enemy pawn on the king's rank is over the river
-        if (crossed) {
-            if (f > 0) { const int s2 = ksq - 1; if (AT(s2) == eP) return true; }
-            if (f < 8) { const int s2 = ksq + 1; if (AT(s2) == eP) return true; }
-        }
+        const int fw_ = turn ? -1 : 1; // direction of travel of the ENEMY pawns
+        const int rp = r - fw_;
+        const int i0 = (unsigned)rp < 10u ? f + 9 * rp : 95;
+        const bool crossed = turn ? (r <= 4) : (r >= 5); // an enemy pawn on the king's rank is over the river
+        const int i1 = (crossed && f > 0) ? ksq - 1 : 95, i2 = (crossed && f < 8) ? ksq + 1 : 95;
+        att |= (AT(i0) == eP) | (AT(i1) == eP) | (AT(i2) == eP);
     }
 #undef AT
-    return false;
+    return att;
 }
 
 struct GenResult {
@@ -174,7 +190,7 @@ struct GenResult {
 // Legal moves of the side to move as a bitmask over the 2086 action ids (S.mask) and, if ids_out
 // is non-null, as an ascending id list (the canonical `board.legal_moves` order).
 // Lane 4p+d generates direction d of piece p; lane j then tests pseudo-move j for king safety.
-// Must be called by all 64 lanes of the wave.
+// Must be called by all 64 lanes of the wave; sq[90..95] must be 0.
 __device__ inline GenResult gen_legal(const uint8_t *sq, int turn, GenScratch &S, uint16_t *ids_out, int lane)
 {
     GenResult R;
@@ -201,12 +217,29 @@ __device__ inline GenResult gen_legal(const uint8_t *sq, int turn, GenScratch &S
         const bool a0 = p0 != 0 && t0 >= PAWN && t0 <= KNIGHT, a1 = p1 != 0 && t1 >= PAWN && t1 <= KNIGHT;
         R.insufficient = (__ballot(a0) | __ballot(a1)) == 0ull;
     }
+    { // occupancy words: ranks from the square-order ballot, files from a transposed ballot
+        const uint64_t lo = __ballot(p0 != 0), hi = __ballot(p1 != 0);
+        if (lane < 10) {
+            const int s = 9 * lane;
+            const uint64_t v = s < 64 ? ((lo >> s) | (s > 55 ? (hi << (64 - s)) : 0ull)) : (hi >> (s - 64));
+            S.R[lane] = (uint16_t)(v & 0x1ffu);
+        }
+        const int t0 = lane, t1 = 64 + lane;
+        const int q0 = sq[(t0 / 10) + 9 * (t0 % 10)];
+        const int q1 = t1 < 90 ? sq[(t1 / 10) + 9 * (t1 % 10)] : 0;
+        const uint64_t tlo = __ballot(q0 != 0), thi = __ballot(q1 != 0);
+        if (lane < 9) {
+            const int s = 10 * lane;
+            const uint64_t v = s < 64 ? ((tlo >> s) | (s > 54 ? (thi << (64 - s)) : 0ull)) : (thi >> (s - 64));
+            S.F[lane] = (uint16_t)(v & 0x3ffu);
+        }
+    }
     for (int w = lane; w < kMaskWords + 2; w += 64) S.mask[w] = 0u;
     __syncthreads();
 
     // ---- phase B: pseudo-legal generation, lane = 4*piece + direction
     int cnt = 0, from = 0;
-    uint8_t *out = S.cand + lane * 10;
+    uint8_t *out = S.cand + lane * 16;
     const int p = lane >> 2, d = lane & 3;
     if (p < npieces) {
         from = S.plist[p];
@@ -215,21 +248,22 @@ __device__ inline GenResult gen_legal(const uint8_t *sq, int turn, GenScratch &S
         const int dr = (d == 0) - (d == 1), df = (d == 2) - (d == 3); // orthogonal step
         const int a = (d & 2) ? -1 : 1, b = (d & 1) ? -1 : 1;         // diagonal step
         if (t == ROOK || t == CANNON) {
-            int r2 = r + dr, f2 = f + df;
-            bool jumped = false;
-            while ((unsigned)r2 < 10u && (unsigned)f2 < 9u) {
-                const int s2 = f2 + 9 * r2, q = sq[s2];
-                if (!jumped) {
-                    if (!q) out[cnt++] = (uint8_t)s2;
-                    else {
-                        if (t == ROOK) { if (!OWN(q)) out[cnt++] = (uint8_t)s2; break; }
-                        jumped = true; // the cannon's screen
-                    }
-                } else if (q) {
-                    if (!OWN(q)) out[cnt++] = (uint8_t)s2;
-                    break;
-                }
-                r2 += dr; f2 += df;
+            const bool horiz = d >= 2, positive = !(d & 1);
+            const int len = horiz ? 9 : 10;
+            uint32_t word = horiz ? S.R[r] : S.F[f];
+            int pos = horiz ? f : r, delta = horiz ? 1 : 9;
+            if (!positive) { word = __brev(word) >> (32 - len); pos = len - 1 - pos; delta = -delta; }
+            int s1, s2;
+            line_scan(word, pos, s1, s2);
+            const int empt = s1 ? s1 - 1 : len - 1 - pos; // quiet moves: steps 1..empt
+            // destination bytes from + i*delta, i = 1..9 (bytes past `empt` are never read)
+            *(uint64_t *)out = (uint64_t)from * 0x0101010101010101ull + (uint64_t)(int64_t)delta * 0x0807060504030201ull;
+            out[8] = (uint8_t)(from + 9 * delta);
+            cnt = empt;
+            const int cs = t == ROOK ? s1 : s2; // a rook takes the first piece, a cannon the second (over its screen)
+            if (cs) {
+                const int s2q = from + cs * delta, q = sq[s2q];
+                if (!OWN(q)) out[cnt++] = (uint8_t)s2q;
             }
         } else if (t == KNIGHT) {
             const int rl = r + dr, fl = f + df;
@@ -282,7 +316,7 @@ __device__ inline GenResult gen_legal(const uint8_t *sq, int turn, GenScratch &S
         const int fr = S.list[j] >> 8, to = S.list[j] & 0xff;
         const int mover = sq[fr];
         const int ksq = (mover & 7) == KING ? to : R.ksq;
-        if (ksq >= 0 && !king_attacked(sq, ksq, fr, to, mover, turn)) {
+        if (ksq >= 0 && !king_attacked(sq, S, ksq, fr, to, mover, turn)) {
             const uint32_t id = c_tab.inv[fr * 90 + to];
             if (id < (uint32_t)kNMoves) atomicOr(&S.mask[id >> 5], 1u << (id & 31));
         }
@@ -320,6 +354,17 @@ __device__ inline GenResult gen_legal(const uint8_t *sq, int turn, GenScratch &S
     }
 #undef OWN
     return R;
+}
+
+// load a 96-byte mailbox row into LDS (24 dwords) with the 6 pad bytes forced to zero
+__device__ __forceinline__ void load_board(uint8_t *s_sq, const uint8_t *src, int lane)
+{
+    if (lane < 24) {
+        uint32_t v = ((const uint32_t *)src)[lane];
+        if (lane == 22) v &= 0x0000ffffu;
+        if (lane == 23) v = 0u;
+        ((uint32_t *)s_sq)[lane] = v;
+    }
 }
 
 // ------------------------------------------------------------------ deterministic math (twin of oracle/xq_sample.c)

@@ -135,7 +135,7 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
     // independent loads issued together: root record, root board, hash chain
     NodeA pa = A[0];
     uint32_t nb = Bn[0];
-    if (lane < 24) ((uint32_t *)s_sq)[lane] = ((const uint32_t *)(D.root_sq + (size_t)b * 96))[lane];
+    load_board(s_sq, D.root_sq + (size_t)b * 96, lane);
     for (int i = lane; i < m.chain_len; i += 64) s_chain[i] = D.chain[(size_t)b * kChainCap + i];
     __syncthreads();
 
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(64) void k_finish_move(Dev D, const int32_t *forced
     if (k == 0 && want < 0) { if (lane == 0) set_err(D, 16); return; } // nothing searched, nothing to sample from
     if (want >= kNMoves) { if (lane == 0) set_err(D, 16); return; }
 
-    if (lane < 24) ((uint32_t *)s_sq)[lane] = ((const uint32_t *)(D.root_sq + (size_t)b * 96))[lane];
+    load_board(s_sq, D.root_sq + (size_t)b * 96, lane);
     for (int i = lane; i < k; i += 64) {
         s_vis[i] = A[root.fc + i].N;
         s_act[i] = (uint16_t)(Bn[root.fc + i] & 0xffffu);
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(64) void k_legal_moves(int n, const uint8_t *sq, co
     if (b >= n) return;
     __shared__ __align__(16) uint8_t s_sq[96];
     __shared__ GenScratch S;
-    if (lane < 24) ((uint32_t *)s_sq)[lane] = ((const uint32_t *)(sq + (size_t)b * 96))[lane];
+    load_board(s_sq, sq + (size_t)b * 96, lane);
     __syncthreads();
     const int t = turn[b] ? 1 : 0;
     const GenResult g = gen_legal(s_sq, t, S, nullptr, lane);
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(64) void k_legal_moves(int n, const uint8_t *sq, co
         if (count) count[b] = g.n_legal;
         if (flags) {
             uint8_t f = 0;
-            if (g.ksq >= 0 && king_attacked(s_sq, g.ksq, -1, -1, 0, t)) f |= 1;
+            if (g.ksq >= 0 && king_attacked(s_sq, S, g.ksq, -1, -1, 0, t)) f |= 1;
             if (g.insufficient) f |= 2;
             if (halfmove && halfmove[b] >= 120 && g.n_legal > 0) f |= 4;
             if (g.overflow) f |= 128;

