@@ -80,16 +80,23 @@ struct Dev {
 #define CCZ_LEAF_SKIP 3
 
 // ------------------------------------------------------------------ small helpers
-__device__ __forceinline__ uint64_t mix64(uint64_t z)
+constexpr uint64_t mix64(uint64_t z)
 {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
-__device__ __forceinline__ uint64_t zob(int pc, int sq)
+// Zobrist keys as a compile-time table in constant memory: in the descent the indices are wave-uniform,
+// so a key is one scalar load instead of ~40 VALU instructions of 64-bit hashing.
+struct ZobTable { uint64_t k[16 * 90]; };
+constexpr ZobTable make_zob()
 {
-    return mix64(0x9E3779B97F4A7C15ull * (uint64_t)(pc * 90 + sq + 1));
+    ZobTable t{};
+    for (int i = 0; i < 16 * 90; ++i) t.k[i] = mix64(0x9E3779B97F4A7C15ull * (uint64_t)(i + 1));
+    return t;
 }
+__constant__ ZobTable c_zob = make_zob();
+__device__ __forceinline__ uint64_t zob(int pc, int sq) { return c_zob.k[pc * 90 + sq]; }
 __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 
 __device__ __forceinline__ int wave_incl_scan(int v, int lane)

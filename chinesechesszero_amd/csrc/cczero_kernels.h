@@ -115,16 +115,34 @@ struct SelectShared {
     __align__(16) uint8_t sq[96];
     uint64_t chain[kChainCap];
     GenScratch S;
+    uint32_t enc[948]; // staging of the 3 live plane groups (945 dwords)
 };
+
+// per-board state every phase needs, loaded in ONE round at the top of the kernel
+struct Prefetch {
+    BoardMeta m;
+    uint32_t sqw;      // lane < 24: dword `lane` of the root mailbox
+    uint64_t c0;       // chain key `lane` (keys 64.. are fetched on demand: > 64 plies without a capture is rare)
+};
+
+__device__ __forceinline__ Prefetch prefetch_board(const Dev &D, int b, int lane)
+{
+    Prefetch P;
+    P.m = D.meta[b];
+    P.sqw = lane < 24 ? ((const uint32_t *)(D.root_sq + (size_t)b * 96))[lane] : 0u;
+    const uint64_t *ch = D.chain + (size_t)b * kChainCap;
+    P.c0 = ch[lane];
+    return P;
+}
 
 // One wave: PUCT descent from the root of board b, leaf rules, evaluator input. Per tree level there is
 // ONE dependent global load round (the children's 16-B NodeA records + their move/count words); the
 // chosen child's own N / first_child / count are broadcast from the winning lane, not re-read.
-__device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *leaf_in, SelectShared &sh)
+__device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *leaf_in, SelectShared &sh, const Prefetch &P)
 {
     uint8_t *s_sq = sh.sq;
     uint64_t *s_chain = sh.chain;
-    const BoardMeta m = D.meta[b];
+    const BoardMeta m = P.m;
     if (m.over) {
         if (lane == 0) D.leaf_status[b] = CCZ_LEAF_SKIP;
         return;
@@ -132,11 +150,16 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
     const size_t base = ((size_t)b * 2 + m.half) * (size_t)D.cap;
     const NodeA *A = D.nodeA + base;
     const uint32_t *Bn = D.nodeB + base;
-    // independent loads issued together: root record, root board, hash chain
     NodeA pa = A[0];
     uint32_t nb = Bn[0];
-    load_board(s_sq, D.root_sq + (size_t)b * 96, lane);
-    for (int i = lane; i < m.chain_len; i += 64) s_chain[i] = D.chain[(size_t)b * kChainCap + i];
+    if (lane < 24) {
+        uint32_t v = P.sqw;
+        if (lane == 22) v &= 0x0000ffffu;
+        if (lane == 23) v = 0u;
+        ((uint32_t *)s_sq)[lane] = v;
+    }
+    s_chain[lane] = P.c0;
+    if (m.chain_len > 64) s_chain[64 + lane] = D.chain[(size_t)b * kChainCap + 64 + lane];
     __syncthreads();
 
     int32_t *path = D.path + (size_t)b * D.maxd;
@@ -215,22 +238,30 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
         if (depth > st.depth_peak) st.depth_peak = depth;
     }
 
-    // ---- evaluator input (net.py:160-177): groups 7 (red now), 15 (black now), 16 (side to move)
+    // ---- evaluator input (net.py:160-177): groups 7 (red now), 15 (black now), 16 (side to move).
+    // Staged in LDS: fill (zeros / the turn plane), scatter one fp16 1.0 per piece, stream out as dwords.
     if (leaf_in) {
+        uint32_t *enc = sh.enc;
+        const uint32_t tv = turn ? 0x3C003C00u : 0u;
+#pragma unroll
+        for (int it = 0; it < 15; ++it) {
+            const int i = lane + 64 * it;
+            if (i < 945) enc[i] = i >= 630 ? tv : 0u;
+        }
+        __syncthreads();
+        {
+            uint16_t *eh = (uint16_t *)enc;
+            const int q0 = s_sq[lane];
+            const int q1 = lane < 26 ? s_sq[64 + lane] : 0;
+            if (q0) eh[(q0 >> 3) * 630 + ((q0 & 7) - 1) * 90 + lane] = kHalfOne;
+            if (q1) eh[(q1 >> 3) * 630 + ((q1 & 7) - 1) * 90 + 64 + lane] = kHalfOne;
+        }
+        __syncthreads();
         uint32_t *row = (uint32_t *)(leaf_in + (size_t)b * 10710);
-        for (int i = lane; i < 945; i += 64) {
-            const int region = i / 315, w = i - region * 315;
-            uint32_t v;
-            if (region == 2) {
-                v = turn ? 0x3C003C00u : 0u;
-            } else {
-                const int add = region ? 8 : 0;
-                const int j0 = 2 * w, j1 = j0 + 1;
-                const int ch0 = j0 / 90, s0 = j0 - 90 * ch0, ch1 = j1 / 90, s1 = j1 - 90 * ch1;
-                v = (s_sq[s0] == ch0 + 1 + add ? 0x3C00u : 0u) | (s_sq[s1] == ch1 + 1 + add ? 0x3C000000u : 0u);
-            }
-            const int off = (region == 0 ? 2205 : region == 1 ? 4725 : 5040) + w;
-            row[off] = v;
+#pragma unroll
+        for (int it = 0; it < 15; ++it) {
+            const int i = lane + 64 * it;
+            if (i < 945) row[i + (i < 315 ? 2205 : (i < 630 ? 4725 - 315 : 5040 - 630))] = enc[i];
         }
     }
 }
@@ -238,41 +269,52 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
 __global__ __launch_bounds__(64) void k_select(Dev D, uint16_t *leaf_in)
 {
     __shared__ SelectShared sh;
-    select_phase(D, blockIdx.x, threadIdx.x, leaf_in, sh);
+    const Prefetch P = prefetch_board(D, blockIdx.x, threadIdx.x);
+    select_phase(D, blockIdx.x, threadIdx.x, leaf_in, sh, P);
 }
 
 // ------------------------------------------------------------------ K2: expand + backup
-__device__ inline void expand_backup_phase(const Dev &D, int b, int lane, const float *prob, const float *value)
+__device__ inline void expand_backup_phase(const Dev &D, int b, int lane, const float *prob, const float *value,
+                                           const BoardMeta &m0)
 {
+    // everything that does not depend on another load is requested first
     const int status = D.leaf_status[b];
+    const int d = D.path_len[b];
+    const int k_leaf = D.leaf_k[b];
+    const float v_net = value[b];
+    const int32_t *path = D.path + (size_t)b * D.maxd;
+    const uint16_t *ids = D.leaf_ids + (size_t)b * kMaxLegal;
+    const int id0 = ids[lane], id1 = ids[64 + lane];
+    const int pj = path[lane < D.maxd ? lane : 0];
     if (status == CCZ_LEAF_SKIP) return;
     BoardMeta *mp = D.meta + b;
-    const int half = mp->half;
+    const int half = m0.half;
     const size_t base = ((size_t)b * 2 + half) * (size_t)D.cap;
     NodeA *A = D.nodeA + base;
     uint32_t *Bn = D.nodeB + base;
-    const int32_t *path = D.path + (size_t)b * D.maxd;
-    const int d = D.path_len[b];
-    const int leaf = path[d];
+    const int leaf = __shfl(pj, d < 64 ? d : 0);
     float v;
     if (status == CCZ_LEAF_EXPAND) {
         // Node.expand (mcts.py:31-39): one child per legal id, ascending id order
-        const int k = D.leaf_k[b];
-        const int n0 = mp->n_nodes;
-        v = value[b];
+        const int k = k_leaf;
+        const int n0 = m0.n_nodes;
+        v = v_net;
         if (n0 + k > D.cap) {
             set_err(D, 1); // pool exhausted: the leaf stays unexpanded, the value is still backed up
         } else {
-            const uint16_t *ids = D.leaf_ids + (size_t)b * kMaxLegal;
             const float *pr = prob + (size_t)b * kNMoves;
-            for (int i = lane; i < k; i += 64) {
-                const int id = ids[i];
-                A[n0 + i] = NodeA{0, 0.0f, pr[id], -1};
-                Bn[n0 + i] = (uint32_t)id;
+            if (lane < k) {
+                A[n0 + lane] = NodeA{0, 0.0f, pr[id0], -1};
+                Bn[n0 + lane] = (uint32_t)id0;
+            }
+            if (64 + lane < k) {
+                A[n0 + 64 + lane] = NodeA{0, 0.0f, pr[id1], -1};
+                Bn[n0 + 64 + lane] = (uint32_t)id1;
             }
             if (lane == 0) {
-                A[leaf].fc = n0;
-                Bn[leaf] = (Bn[leaf] & 0xffffu) | ((uint32_t)k << 16);
+                const int leaf0 = d < 64 ? leaf : path[d];
+                A[leaf0].fc = n0;
+                Bn[leaf0] = (Bn[leaf0] & 0xffffu) | ((uint32_t)k << 16);
                 mp->n_nodes = n0 + k;
                 BoardStats &st = D.stats[b];
                 st.sum_children += (unsigned long long)k;
@@ -290,7 +332,7 @@ __device__ inline void expand_backup_phase(const Dev &D, int b, int lane, const 
     }
     // Node.update_recursive(-leaf_value) (mcts.py:73-78,129): leaf gets -v, its parent +v, ...
     for (int j = lane; j <= d; j += 64) {
-        const int node = path[j];
+        const int node = j < 64 ? pj : path[j];
         const float val = ((d - j) & 1) ? v : -v;
         int32_t *np_ = &A[node].N;
         float *qp = &A[node].Q;
@@ -306,7 +348,8 @@ __device__ inline void expand_backup_phase(const Dev &D, int b, int lane, const 
 
 __global__ __launch_bounds__(64) void k_expand_backup(Dev D, const float *prob, const float *value)
 {
-    expand_backup_phase(D, blockIdx.x, threadIdx.x, prob, value);
+    const BoardMeta m0 = D.meta[blockIdx.x];
+    expand_backup_phase(D, blockIdx.x, threadIdx.x, prob, value, m0);
 }
 
 // ------------------------------------------------------------------ fused step: expand+backup of the pending leaf, then the next select
@@ -316,10 +359,11 @@ __global__ __launch_bounds__(64) void k_step(Dev D, const float *prob, const flo
 {
     __shared__ SelectShared sh;
     const int b = blockIdx.x, lane = threadIdx.x;
-    expand_backup_phase(D, b, lane, prob, value);
+    const Prefetch P = prefetch_board(D, b, lane); // root board, chain and meta: untouched by the expand phase
+    expand_backup_phase(D, b, lane, prob, value, P.m);
     __threadfence_block();
     __syncthreads();
-    select_phase(D, b, lane, leaf_in, sh);
+    select_phase(D, b, lane, leaf_in, sh, P);
 }
 
 // ------------------------------------------------------------------ pi from root visits (mcts.py:162-166)
