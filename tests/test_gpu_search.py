@@ -91,8 +91,11 @@ def test_golden_traces_from_reference_mcts(golden, idx):
     salt = {"hash": 0, "hash_sharp": 7, "uniform": 0}[case["ev"]]
     ls = Lockstep(e, [ob], kind=case["ev"], salts=[salt])
     for ply in range(case["plies_done"]):
-        for _ in range(case["n"]):
-            ls.step(check_leaf=False)
+        if idx % 2 == 0:   # even cases through the fused launch sequence, odd ones through select + expand_backup
+            ls.run_fused(case["n"], check_leaf=False)
+        else:
+            for _ in range(case["n"]):
+                ls.step(check_leaf=False)
         rc = e.root_children()
         k = int(rc["k"][0])
         assert np.array_equal(rc["acts"][0][:k], d[f"{name}_p{ply}_acts"].astype(np.uint16))
