@@ -99,14 +99,45 @@ __constant__ ZobTable c_zob = make_zob();
 __device__ __forceinline__ uint64_t zob(int pc, int sq) { return c_zob.k[pc * 90 + sq]; }
 __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 
-__device__ __forceinline__ int wave_incl_scan(int v, int lane)
+// Wave-wide scan / reduction on the DPP network (row_shr 1,2,4,8 + row_bcast15/31: the gfx9 sequence),
+// VALU latency instead of six dependent trips through the LDS crossbar (ds_bpermute).
+#define CCZ_DPP(old_, src_, ctrl_, rmask_) __builtin_amdgcn_update_dpp((old_), (src_), (ctrl_), (rmask_), 0xf, false)
+
+__device__ __forceinline__ int wave_incl_scan(int v, int /*lane*/)
 {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int t = __shfl_up(v, o);
-        if (lane >= o) v += t;
-    }
+    v += CCZ_DPP(0, v, 0x111, 0xf);
+    v += CCZ_DPP(0, v, 0x112, 0xf);
+    v += CCZ_DPP(0, v, 0x114, 0xf);
+    v += CCZ_DPP(0, v, 0x118, 0xf);
+    v += CCZ_DPP(0, v, 0x142, 0xa);
+    v += CCZ_DPP(0, v, 0x143, 0xc);
     return v;
+}
+
+// maximum over the 64 lanes of a double (no NaNs), returned in every lane
+__device__ __forceinline__ double wave_max_f64(double x)
+{
+    const long long ninf = __double_as_longlong(-__builtin_huge_val());
+    const int ilo = (int)(ninf & 0xffffffffll), ihi = (int)(ninf >> 32);
+#define CCZ_MAX_STEP(ctrl_, rmask_)                                                         \
+    {                                                                                       \
+        const long long b = __double_as_longlong(x);                                        \
+        const int lo = CCZ_DPP(ilo, (int)(b & 0xffffffffll), ctrl_, rmask_);                \
+        const int hi = CCZ_DPP(ihi, (int)(b >> 32), ctrl_, rmask_);                         \
+        const double t = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);    \
+        x = __builtin_fmax(x, t);                                                           \
+    }
+    CCZ_MAX_STEP(0x111, 0xf)
+    CCZ_MAX_STEP(0x112, 0xf)
+    CCZ_MAX_STEP(0x114, 0xf)
+    CCZ_MAX_STEP(0x118, 0xf)
+    CCZ_MAX_STEP(0x142, 0xa)
+    CCZ_MAX_STEP(0x143, 0xc)
+#undef CCZ_MAX_STEP
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
 // ------------------------------------------------------------------ rules

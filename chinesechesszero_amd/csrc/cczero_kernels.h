@@ -187,19 +187,18 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
                 if (sc > best) { best = sc; besti = i; bN = c.N; bfc = c.fc; bw = w; }
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { // first maximum in insertion order wins (Python max())
-            const double ob = __shfl_xor(best, o);
-            const int oi = __shfl_xor(besti, o);
-            if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
-        }
-        if (besti >= nc) { bad = true; set_err(D, 32); break; } // NaN priors: no comparable child
-        // the winning index sits in lane besti%64, whose running best is that very child
-        const int owner = besti & 63;
+        // first maximum in insertion order wins (Python max()): wave max of the score, then the lowest index
+        // holding it (a lane's running best is its lowest-index maximum; indices < 64 precede the second pass)
+        const double top = wave_max_f64(best);
+        const bool hit = best == top && besti < nc;
+        const uint64_t h0 = __ballot(hit && besti < 64), h1 = __ballot(hit);
+        if (h1 == 0ull) { bad = true; set_err(D, 32); break; } // NaN priors: no comparable child
+        const int owner = __builtin_amdgcn_readfirstlane((h0 ? __ffsll((long long)h0) : __ffsll((long long)h1)) - 1);
+        besti = __builtin_amdgcn_readlane(besti, owner);
         const int child = pa.fc + besti;
-        pa.N = __shfl(bN, owner);
-        pa.fc = __shfl(bfc, owner);
-        nb = (uint32_t)__shfl((int)bw, owner);
+        pa.N = __builtin_amdgcn_readlane(bN, owner);
+        pa.fc = __builtin_amdgcn_readlane(bfc, owner);
+        nb = (uint32_t)__builtin_amdgcn_readlane((int)bw, owner);
         const int mv = (int)(nb & 0xffffu);
         // board.push(move)  (mcts.py:111)
         const int from = c_tab.from[mv], to = c_tab.to[mv];
