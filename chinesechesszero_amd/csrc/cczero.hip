@@ -122,7 +122,9 @@ int ccz_create(const ccz_config *cfg, ccz_engine **out)
     // nodes per pool half: every playout creates <= ~k children; the retained subtree adds to it
     const int n_play = cfg->n_playout > 0 ? cfg->n_playout : 400;
     d.cap = cfg->max_nodes > 0 ? cfg->max_nodes : (n_play + 64) * 256;
-    d.maxd = cfg->max_depth > 0 ? cfg->max_depth : 512;
+    d.maxd = cfg->max_depth > 0 ? cfg->max_depth : kMaxDepth;
+    if (d.maxd > kMaxDepth) { delete e; return fail(-1, "ccz_create: max_depth %d exceeds the compiled limit %d", d.maxd, kMaxDepth); }
+    if (d.maxd < 64) { delete e; return fail(-1, "ccz_create: max_depth must be >= 64"); }
     d.max_plies = cfg->max_plies > 0 ? cfg->max_plies : 2048;
     d.pi_cap = d.max_plies * 48;
     d.c_puct = cfg->c_puct;

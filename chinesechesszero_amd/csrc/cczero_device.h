@@ -114,6 +114,27 @@ __device__ __forceinline__ int wave_incl_scan(int v, int /*lane*/)
     return v;
 }
 
+// inclusive XOR scan of a 64-bit value over the wave; readlane of a 64-bit value
+__device__ __forceinline__ uint64_t wave_incl_xor64(uint64_t x)
+{
+    int lo = (int)(x & 0xffffffffull), hi = (int)(x >> 32);
+#define CCZ_XOR_STEP(ctrl_, rmask_) { lo ^= CCZ_DPP(0, lo, ctrl_, rmask_); hi ^= CCZ_DPP(0, hi, ctrl_, rmask_); }
+    CCZ_XOR_STEP(0x111, 0xf)
+    CCZ_XOR_STEP(0x112, 0xf)
+    CCZ_XOR_STEP(0x114, 0xf)
+    CCZ_XOR_STEP(0x118, 0xf)
+    CCZ_XOR_STEP(0x142, 0xa)
+    CCZ_XOR_STEP(0x143, 0xc)
+#undef CCZ_XOR_STEP
+    return ((uint64_t)(unsigned int)hi << 32) | (unsigned int)lo;
+}
+__device__ __forceinline__ uint64_t wave_readlane64(uint64_t x, int l)
+{
+    const int lo = __builtin_amdgcn_readlane((int)(x & 0xffffffffull), l);
+    const int hi = __builtin_amdgcn_readlane((int)(x >> 32), l);
+    return ((uint64_t)(unsigned int)hi << 32) | (unsigned int)lo;
+}
+
 // maximum over the 64 lanes of a double (no NaNs), returned in every lane
 __device__ __forceinline__ double wave_max_f64(double x)
 {

@@ -5,6 +5,7 @@
 namespace ccz {
 
 constexpr uint16_t kHalfOne = 0x3C00; // fp16 1.0
+constexpr int kMaxDepth = 512;     // selection path capacity (Dev.maxd <= kMaxDepth)
 
 __device__ __forceinline__ void set_err(const Dev &D, int bit) { atomicOr(D.err, bit); }
 
@@ -115,7 +116,13 @@ struct SelectShared {
     __align__(16) uint8_t sq[96];
     uint64_t chain[kChainCap];
     GenScratch S;
-    uint32_t enc[948]; // staging of the 3 live plane groups (945 dwords)
+    union {
+        uint32_t enc[948]; // staging of the 3 live plane groups (945 dwords); used after move generation
+        struct {           // deferred make-move of the selection path; dead before move generation starts
+            uint16_t mv[kMaxDepth];
+            uint8_t from[kMaxDepth], to[kMaxDepth], pc[kMaxDepth], cap[kMaxDepth];
+        } pm;
+    };
 };
 
 // per-board state every phase needs, loaded in ONE round at the top of the kernel
@@ -200,28 +207,70 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
         pa.fc = __builtin_amdgcn_readlane(bfc, owner);
         nb = (uint32_t)__builtin_amdgcn_readlane((int)bw, owner);
         const int mv = (int)(nb & 0xffffu);
-        // board.push(move)  (mcts.py:111)
-        const int from = c_tab.from[mv], to = c_tab.to[mv];
-        const int pc = s_sq[from], cap = s_sq[to];
-        __syncthreads();
-        if (lane == 0) { s_sq[to] = (uint8_t)pc; s_sq[from] = 0; }
-        key ^= zob(pc, from) ^ zob(pc, to) ^ kTurnKey;
-        if (cap) key ^= zob(cap, to);
-        turn ^= 1;
-        if (cap) { halfmove = 0; chain_len = 0; } else ++halfmove;
-        if (chain_len >= kChainCap) { bad = true; set_err(D, 2); break; }
-        if (lane == 0) s_chain[chain_len] = key;
-        ++chain_len;
+        // board.push(move) (mcts.py:111) is DEFERRED: only the move id is noted here, so that a tree level costs
+        // one global load round plus the arg-max and nothing else sits on the critical path
+        if (lane == 0) sh.pm.mv[depth] = (uint16_t)mv;
         ++depth;
         if (depth >= D.maxd) { bad = true; set_err(D, 2); break; }
         if (lane == 0) path[depth] = child;
-        __syncthreads();
     }
     __syncthreads();
     if (bad) {
         if (lane == 0) D.leaf_status[b] = CCZ_LEAF_SKIP;
         return;
     }
+
+    // ---- replay the selection path on the LDS board: (1) table lookups in parallel, (2) the inherently
+    // serial piece shuffling by one lane, (3) Zobrist deltas in parallel + XOR prefix scan
+    if (depth > 0) {
+        for (int j = lane; j < depth; j += 64) {
+            const int mvj = sh.pm.mv[j];
+            sh.pm.from[j] = c_tab.from[mvj];
+            sh.pm.to[j] = c_tab.to[mvj];
+        }
+        __syncthreads();
+        int lastcap = -1;
+        if (lane == 0) {
+            for (int j = 0; j < depth; ++j) {
+                const int fr = sh.pm.from[j], to = sh.pm.to[j];
+                const uint8_t pc = s_sq[fr], cp = s_sq[to];
+                s_sq[to] = pc;
+                s_sq[fr] = 0;
+                sh.pm.pc[j] = pc;
+                sh.pm.cap[j] = cp;
+                if (cp) lastcap = j;
+            }
+        }
+        lastcap = __builtin_amdgcn_readfirstlane(lastcap);
+        __syncthreads();
+        // keys: key_j = root_key ^ XOR_{i<=j} delta_i ; a capture at move c restarts the chain at key_c
+        const int first = lastcap >= 0 ? lastcap : 0;
+        const int new_len = (lastcap >= 0 ? 0 : chain_len) + (depth - first);
+        if (new_len > kChainCap) {
+            set_err(D, 2);
+            if (lane == 0) D.leaf_status[b] = CCZ_LEAF_SKIP;
+            return;
+        }
+        uint64_t carry = key;
+        const int off = lastcap >= 0 ? -first : chain_len; // chain slot of move j is off + j
+        for (int j0 = 0; j0 < depth; j0 += 64) {
+            const int j = j0 + lane;
+            uint64_t dlt = 0;
+            if (j < depth) {
+                const int fr = sh.pm.from[j], to = sh.pm.to[j], pc = sh.pm.pc[j], cp = sh.pm.cap[j];
+                dlt = zob(pc, fr) ^ zob(pc, to) ^ kTurnKey;
+                if (cp) dlt ^= zob(cp, to);
+            }
+            dlt = wave_incl_xor64(dlt) ^ carry;
+            if (j < depth && j >= first) s_chain[off + j] = dlt;
+            carry = wave_readlane64(dlt, 63);
+        }
+        key = carry;
+        halfmove = lastcap >= 0 ? depth - 1 - lastcap : halfmove + depth;
+        chain_len = new_len;
+        turn ^= depth & 1;
+    }
+    __syncthreads();
 
     // ---- leaf: legal moves (net.py:154-157), game end (mcts.py:116-117)
     bool overflow;
