@@ -99,6 +99,17 @@ __constant__ ZobTable c_zob = make_zob();
 __device__ __forceinline__ uint64_t zob(int pc, int sq) { return c_zob.k[pc * 90 + sq]; }
 __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 
+// LDS-only synchronisation inside the one-wave workgroup. LDS instructions of a wave execute in program
+// order, so a later ds_read sees an earlier ds_write of any lane; all that is needed is that the COMPILER
+// keeps that order. __syncthreads() would also drain every outstanding global load and store
+// (s_waitcnt vmcnt(0)), which put ~1 us of store latency on the critical path at each of ~15 sync points.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Wave-wide scan / reduction on the DPP network (row_shr 1,2,4,8 + row_bcast15/31: the gfx9 sequence),
 // VALU latency instead of six dependent trips through the LDS crossbar (ds_bpermute).
 #define CCZ_DPP(old_, src_, ctrl_, rmask_) __builtin_amdgcn_update_dpp((old_), (src_), (ctrl_), (rmask_), 0xf, false)
@@ -294,7 +305,7 @@ __device__ inline GenResult gen_legal(const uint8_t *sq, int turn, GenScratch &S
         }
     }
     for (int w = lane; w < kMaskWords + 2; w += 64) S.mask[w] = 0u;
-    __syncthreads();
+    wave_sync();
 
     // ---- phase B: pseudo-legal generation, lane = 4*piece + direction
     int cnt = 0, from = 0;
@@ -368,7 +379,7 @@ __device__ inline GenResult gen_legal(const uint8_t *sq, int turn, GenScratch &S
     if (npseudo > kPseudoCap) { R.overflow = true; npseudo = kPseudoCap; }
     for (int i = 0; i < cnt; ++i)
         if (excl + i < kPseudoCap) S.list[excl + i] = (uint16_t)((from << 8) | out[i]);
-    __syncthreads();
+    wave_sync();
 
     // ---- phase C: king safety, lane per pseudo-move
     for (int j = lane; j < npseudo; j += 64) {
@@ -380,7 +391,7 @@ __device__ inline GenResult gen_legal(const uint8_t *sq, int turn, GenScratch &S
             if (id < (uint32_t)kNMoves) atomicOr(&S.mask[id >> 5], 1u << (id & 31));
         }
     }
-    __syncthreads();
+    wave_sync();
 
     // ---- phase D: count and list in ascending id order
     const uint32_t w0 = S.mask[lane];

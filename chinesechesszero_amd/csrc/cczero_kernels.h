@@ -167,7 +167,7 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
     }
     s_chain[lane] = P.c0;
     if (m.chain_len > 64) s_chain[64 + lane] = D.chain[(size_t)b * kChainCap + 64 + lane];
-    __syncthreads();
+    wave_sync();
 
     int32_t *path = D.path + (size_t)b * D.maxd;
     int depth = 0, turn = m.turn, halfmove = m.halfmove, chain_len = m.chain_len;
@@ -214,7 +214,7 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
         if (depth >= D.maxd) { bad = true; set_err(D, 2); break; }
         if (lane == 0) path[depth] = child;
     }
-    __syncthreads();
+    wave_sync();
     if (bad) {
         if (lane == 0) D.leaf_status[b] = CCZ_LEAF_SKIP;
         return;
@@ -228,7 +228,7 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
             sh.pm.from[j] = c_tab.from[mvj];
             sh.pm.to[j] = c_tab.to[mvj];
         }
-        __syncthreads();
+        wave_sync();
         int lastcap = -1;
         if (lane == 0) {
             for (int j = 0; j < depth; ++j) {
@@ -242,7 +242,7 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
             }
         }
         lastcap = __builtin_amdgcn_readfirstlane(lastcap);
-        __syncthreads();
+        wave_sync();
         // keys: key_j = root_key ^ XOR_{i<=j} delta_i ; a capture at move c restarts the chain at key_c
         const int first = lastcap >= 0 ? lastcap : 0;
         const int new_len = (lastcap >= 0 ? 0 : chain_len) + (depth - first);
@@ -270,7 +270,7 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
         chain_len = new_len;
         turn ^= depth & 1;
     }
-    __syncthreads();
+    wave_sync();
 
     // ---- leaf: legal moves (net.py:154-157), game end (mcts.py:116-117)
     bool overflow;
@@ -296,7 +296,7 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
             const int i = lane + 64 * it;
             if (i < 945) enc[i] = i >= 630 ? tv : 0u;
         }
-        __syncthreads();
+        wave_sync();
         {
             uint16_t *eh = (uint16_t *)enc;
             const int q0 = s_sq[lane];
@@ -304,7 +304,7 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
             if (q0) eh[(q0 >> 3) * 630 + ((q0 & 7) - 1) * 90 + lane] = kHalfOne;
             if (q1) eh[(q1 >> 3) * 630 + ((q1 & 7) - 1) * 90 + 64 + lane] = kHalfOne;
         }
-        __syncthreads();
+        wave_sync();
         uint32_t *row = (uint32_t *)(leaf_in + (size_t)b * 10710);
 #pragma unroll
         for (int it = 0; it < 15; ++it) {
@@ -429,13 +429,13 @@ __device__ inline void root_pi(const int32_t *s_vis, double *s_pi, int k, double
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(mx, o); if (t > mx) mx = t; }
     for (int i = lane; i < k; i += 64) s_pi[i] = det_exp(s_pi[i] - mx);
-    __syncthreads();
+    wave_sync();
     double sum = 0.0;
     if (lane == 0) for (int i = 0; i < k; ++i) sum += s_pi[i];
     sum = __shfl(sum, 0);
-    __syncthreads();
+    wave_sync();
     for (int i = lane; i < k; i += 64) s_pi[i] = s_pi[i] / sum;
-    __syncthreads();
+    wave_sync();
 }
 
 __device__ __forceinline__ double board_temp(const Dev &D, const BoardMeta &m, const double *temps, int b)
