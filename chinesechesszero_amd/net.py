@@ -160,6 +160,10 @@ class PolicyValueNet:
 
     # ---- batched evaluator for the lockstep engine -------------------------------------------
     def refresh_inference_copy(self):
+        # MIOpen "find" mode: PyTorch's default immediate mode picks the asm implicit-GEMM kernel for the
+        # [B,256,10,9] 3x3 convolutions (0.87 ms at B=4096); the find step measures all applicable solvers once
+        # per shape and selects the composable-kernel XDL grouped-conv kernel (0.60 ms) -- profiles/miopen_find_r01.txt
+        torch.backends.cudnn.benchmark = True
         self.policy_value_net.eval()
         self._infer = InferenceNet(self.policy_value_net).to(self.device).eval()
         self._graph = None
