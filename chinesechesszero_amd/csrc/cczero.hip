@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "cczero_kernels.h"
+#include "cczero_netops.h"
 
 using namespace ccz;
 
@@ -456,6 +457,24 @@ int ccz_apply_moves(void *stream, int32_t n, uint8_t *sq_dev, uint8_t *turn_dev,
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_apply_moves, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, sq_dev, turn_dev, move_ids_dev,
                        captured_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ccz_bias_act_f16(void *stream, void *y_dev, const void *bias_dev, const void *residual_dev, int64_t rows, int32_t channels)
+{
+    if (!y_dev || !bias_dev || rows < 0 || channels <= 0 || (channels & 7)) return fail(-1, "ccz_bias_act_f16: bad arguments (channels must be a multiple of 8)");
+    if ((((uintptr_t)y_dev) | ((uintptr_t)bias_dev) | ((uintptr_t)residual_dev)) & 15) return fail(-1, "ccz_bias_act_f16: pointers must be 16-byte aligned");
+    const long n_vec = rows * (long)(channels / 8);
+    if (n_vec == 0) return 0;
+    long blocks = (n_vec + 255) / 256;
+    if (blocks > 4096) blocks = 4096; // grid-stride: 16 resident blocks per CU
+    if (residual_dev)
+        hipLaunchKernelGGL(k_bias_act<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (half8_t *)y_dev, (const half8_t *)bias_dev,
+                           (const half8_t *)residual_dev, n_vec, channels / 8);
+    else
+        hipLaunchKernelGGL(k_bias_act<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (half8_t *)y_dev, (const half8_t *)bias_dev,
+                           (const half8_t *)nullptr, n_vec, channels / 8);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -117,6 +117,24 @@ class InferenceNet(nn.Module):
         self.value_fc2_w = nn.Parameter(net.value_fc2.weight.detach().to(dtype), requires_grad=False)
         self.value_fc2_b = nn.Parameter(net.value_fc2.bias.detach().to(dtype), requires_grad=False)
 
+    def _epilogue(self, y, bias, residual=None):
+        """relu(y + bias [+ residual]) in ONE pass (libcczero ccz_bias_act_f16) on NHWC fp16 device tensors;
+        plain torch ops otherwise (CPU tests, other dtypes)."""
+        if y.is_cuda and y.dtype == torch.float16 and y.is_contiguous(memory_format=torch.channels_last) \
+                and (residual is None or residual.is_contiguous(memory_format=torch.channels_last)):
+            import ctypes as C
+            from . import _lib
+            n, c, h, w = y.shape
+            _lib.check(_lib.lib().ccz_bias_act_f16(C.c_void_p(torch.cuda.current_stream(y.device).cuda_stream),
+                                                   C.c_void_p(y.data_ptr()), C.c_void_p(bias.data_ptr()),
+                                                   C.c_void_p(residual.data_ptr()) if residual is not None else None,
+                                                   n * h * w, c))
+            return y
+        y = y + bias.view(1, -1, 1, 1)
+        if residual is not None:
+            y = y + residual
+        return F.relu_(y)
+
     @torch.no_grad()
     def forward(self, leaf_input: torch.Tensor):
         B = leaf_input.shape[0]
@@ -124,11 +142,10 @@ class InferenceNet(nn.Module):
         if self.live_only:
             x = torch.cat([x[:, 49:56], x[:, 105:119]], dim=1)
         x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
-        x = F.relu_(F.conv2d(x, self.stem_w, self.stem_b, padding=1))
+        x = self._epilogue(F.conv2d(x, self.stem_w, None, padding=1), self.stem_b)
         for i in range(0, len(self.ws), 2):
-            y = F.relu_(F.conv2d(x, self.ws[i], self.bs[i], padding=1))
-            y = F.conv2d(y, self.ws[i + 1], self.bs[i + 1], padding=1)
-            x = F.relu_(y.add_(x))
+            y = self._epilogue(F.conv2d(x, self.ws[i], None, padding=1), self.bs[i])
+            x = self._epilogue(F.conv2d(y, self.ws[i + 1], None, padding=1), self.bs[i + 1], x)
         h = F.relu_(F.conv2d(x, self.head_w, self.head_b))
         pol = h[:, :PLAYS].reshape(B, PLAYS * 90)          # NCHW flatten order, as torch.reshape in net.py:98
         val = h[:, PLAYS:].reshape(B, PIECES * 90)

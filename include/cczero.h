@@ -202,6 +202,14 @@ int ccz_legal_moves(void *stream, int32_t n, const uint8_t *sq_dev, const uint8_
 int ccz_apply_moves(void *stream, int32_t n, uint8_t *sq_dev, uint8_t *turn_dev,
                     const int32_t *move_ids_dev, uint8_t *captured_dev);
 
+/* ---- evaluator epilogue (the net itself stays in PyTorch-ROCm / MIOpen) ------------------------ */
+/* One-pass fused epilogue of a tower convolution on NHWC fp16 activations y [rows, channels]:
+ * y = relu(y + bias[c])  or, with residual_dev != NULL,  y = relu(y + bias[c] + residual)  (reference
+ * net.py:32-43: conv -> BN(folded into conv/bias) -> [+x] -> ReLU). Replaces three separate full-tensor
+ * passes (bias, add, clamp) that PyTorch issues around an MIOpen convolution. 16-byte aligned pointers. */
+int ccz_bias_act_f16(void *stream, void *y_dev, const void *bias_dev, const void *residual_dev,
+                     int64_t rows, int32_t channels);
+
 #ifdef __cplusplus
 }
 #endif

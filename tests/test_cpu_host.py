@@ -14,7 +14,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     """Every function include/cczero.h declares is exported by libcczero.so and bound by the shim."""
     from chinesechesszero_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "cczero.h")).read()
-    declared = set(re.findall(r"\b(ccz_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(ccz_[a-z0-9_]+)\s*\(", hdr))
     declared -= {"ccz_engine", "ccz_config", "ccz_stats"}
     assert len(declared) >= 20
     L = _lib.lib()

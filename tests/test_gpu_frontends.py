@@ -51,3 +51,44 @@ def test_uci_loop_go_returns_a_legal_move():
     assert best[0].split()[1] in [m.uci() for m in b.legal_moves]
     assert any(l.startswith("info nodes 40") for l in text)
     assert any("illegal move a0a5" in l for l in text)  # rook cannot jump its own pawn... a0a5 is blocked by a3
+
+
+def test_inference_net_fp16_fused_epilogue_matches_fp32_reference_architecture():
+    """The evaluator's inference copy (BN folded, NHWC fp16, MIOpen convs + the one-pass HIP epilogue
+    ccz_bias_act_f16) against the reference architecture in fp32 (tolerances of fp16 inference)."""
+    from chinesechesszero_amd.net import InferenceNet, Net
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(4)
+    net = Net(64, 3).to(dev).eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 2)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.1)
+    x = torch.zeros(33, 17, 7, 10, 9, device=dev)
+    x[:, 7] = (torch.rand(33, 7, 10, 9, device=dev) > 0.9).float()
+    x[:, 15] = (torch.rand(33, 7, 10, 9, device=dev) > 0.9).float()
+    x[::2, 16] = 1
+    with torch.no_grad():
+        logp, v = net(x)
+        inf = InferenceNet(net).to(dev).eval()
+        p16, v16 = inf(x.half())
+        p32, v32 = InferenceNet(net, dtype=torch.float32).to(dev).eval()(x.half())
+    assert torch.allclose(logp.exp(), p32, atol=1e-5) and torch.allclose(v.view(-1), v32, atol=1e-5)
+    assert p16.dtype == torch.float32 and v16.dtype == torch.float32
+    assert (logp.exp() - p16).abs().max().item() < 2e-3 and (v.view(-1) - v16).abs().max().item() < 2e-2
+    assert torch.allclose(p16.sum(1), torch.ones(33, device=dev), atol=1e-3)
+    # the epilogue kernel itself, bit-exact against the same fp16 op sequence in torch
+    import ctypes as C
+    from chinesechesszero_amd import _lib
+    y = torch.randn(7, 64, 10, 9, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+    r = torch.randn_like(y).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(64, device=dev, dtype=torch.float16)
+    want1 = torch.relu(y + b.view(1, -1, 1, 1))
+    want2 = torch.relu((y + b.view(1, -1, 1, 1)) + r)
+    s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    y1, y2 = y.clone(memory_format=torch.preserve_format), y.clone(memory_format=torch.preserve_format)
+    _lib.check(_lib.lib().ccz_bias_act_f16(s, C.c_void_p(y1.data_ptr()), C.c_void_p(b.data_ptr()), None, 7 * 90, 64))
+    _lib.check(_lib.lib().ccz_bias_act_f16(s, C.c_void_p(y2.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(r.data_ptr()), 7 * 90, 64))
+    assert torch.equal(y1, want1) and torch.equal(y2, want2)
