@@ -1,0 +1,124 @@
+"""GPU: reference-exact NumPy sampling mode of the batched driver, and the loud-failure paths of the engine."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class HashEvaluator:
+    """Device-side wrapper of the integer hash evaluator (round trip through the host; small B only)."""
+
+    batched = True
+
+    def __init__(self, salts, scale=40.0):
+        self.salts = salts
+        self.scale = scale
+
+    def __call__(self, leaf):
+        from gpu_harness import planes_to_squares
+        from oracle.evaluators import hash_eval
+        sq, turn = planes_to_squares(leaf.float().cpu().numpy())
+        P = np.zeros((len(sq), 2086), np.float32)
+        V = np.zeros(len(sq), np.float32)
+        for b in range(len(sq)):
+            p, v = hash_eval(sq[b:b + 1], turn[b:b + 1], salt=self.salts[b], scale=self.scale)
+            P[b], V[b] = p[0], v[0]
+        return torch.from_numpy(P).to(leaf.device), torch.from_numpy(V).to(leaf.device)
+
+
+def test_numpy_sampling_mode_reproduces_sequential_reference_games():
+    """BatchedSelfPlay(sampling='numpy'): every board plays exactly the game a sequential reference-style loop
+    (oracle MCTS + game.py's temperature schedule + mcts.py:216-224 sampling on its own RandomState) plays."""
+    from oracle import OracleBoard, OracleMCTS
+    from oracle.evaluators import hash_eval
+    from chinesechesszero_amd.selfplay import BatchedSelfPlay
+    B, n, plies, seed = 5, 48, 5, 77
+    salts = [21, 22, 23, 24, 25]
+    sp = BatchedSelfPlay(HashEvaluator(salts), B, n_playout=n, seed=seed, sampling="numpy")
+    got = [[] for _ in range(B)]
+    for _ in range(plies):
+        mv = sp.run_move().cpu().numpy()
+        for b in range(B):
+            got[b].append(int(mv[b]))
+    sp.engine.check_healthy()
+    for b in range(B):
+        def ev(board, ids, _s=salts[b]):
+            p, v = hash_eval(board.squares()[None, :], np.array([1 if board.turn else 0]), salt=_s, scale=40.0)
+            return p[0][ids], v[0]
+        board, mcts = OracleBoard(), OracleMCTS(ev, c_puct=5, n_playout=n)
+        rs = np.random.RandomState((seed + b) % (2**32))
+        want = []
+        for ply in range(plies):
+            temp = 1.0 if ply + 1 <= 30 else 0.5
+            acts, visits, _ = mcts.get_move_probs(board, temp)
+            x = 1.0 / temp * np.log(visits.astype(np.int64) + 1e-10)
+            probs = np.exp(x - np.max(x))
+            probs /= probs.sum()
+            move = int(rs.choice(acts, p=0.75 * probs + 0.25 * rs.dirichlet(0.2 * np.ones(len(probs)))))
+            mcts.update_with_move(move)
+            board.push_id(move)
+            want.append(move)
+        assert got[b] == want, (b, got[b], want)
+
+
+def test_node_pool_exhaustion_is_loud_and_safe():
+    from chinesechesszero_amd._lib import CczError
+    from chinesechesszero_amd.engine import SelfPlayEngine
+    from chinesechesszero_amd.net import uniform_evaluator
+    e = SelfPlayEngine(4, n_playout=64, max_nodes=200)  # room for ~4 expansions only
+    for _ in range(64):
+        leaf = e.select_leaves()
+        e.expand_backup(*uniform_evaluator(leaf))
+    st = e.stats()
+    assert st["error_flags"] & 1 and st["nodes_peak"] <= 200 and st["sims"] == 4 * 64
+    with pytest.raises(CczError, match="node pool"):
+        e.check_healthy()
+    # the engine stays usable: a move can still be played from the visits it has
+    moves = e.finish_move().cpu().numpy()
+    assert np.all(moves >= 0)
+
+
+def test_nan_priors_and_bad_arguments_are_rejected():
+    from chinesechesszero_amd._lib import CczError
+    from chinesechesszero_amd.engine import SelfPlayEngine
+    e = SelfPlayEngine(2, n_playout=8)
+    leaf = e.select_leaves()
+    P = torch.full((2, 2086), float("nan"), device=e.device)
+    V = torch.zeros(2, device=e.device)
+    e.expand_backup(P, V)
+    for _ in range(3):
+        e.select_leaves()
+        e.expand_backup(P, V)
+    assert e.stats()["error_flags"] & 32
+    with pytest.raises(TypeError):
+        e.expand_backup(P.double(), V)
+    with pytest.raises(ValueError):
+        e.expand_backup(P[:1], V)
+    with pytest.raises(ValueError):
+        e.expand_backup(P.cpu(), V.cpu())
+    with pytest.raises(CczError):
+        e.set_position(0, np.zeros(90, np.uint8), 1, 0)  # no kings
+    with pytest.raises(CczError):
+        e.set_position(5, np.zeros(90, np.uint8), 1, 0)  # board index out of range
+    with pytest.raises(CczError):
+        SelfPlayEngine(2, max_depth=100000)
+
+
+def test_concurrent_trainer_config5_smoke():
+    """bench.py --train-every (BASELINE config 5 on one GPU): self-play keeps running next to trainer updates."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--boards", "64", "--playout", "8", "--steps", "24", "--warmup", "2",
+                          "--blocks", "2", "--channels", "32", "--train-every", "6", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["trainer_updates"] == 4 and j["value"] > 0 and j["n_gpus"] == 1
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in j
+    assert set(j["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
