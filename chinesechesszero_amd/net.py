@@ -8,6 +8,8 @@ reference architecture with identical ``state_dict`` keys (net.py:46-110) so ref
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -180,7 +182,6 @@ class PolicyValueNet:
         # MIOpen "find" mode: PyTorch's default immediate mode picks the asm implicit-GEMM kernel for the
         # [B,256,10,9] 3x3 convolutions (0.87 ms at B=4096); the find step measures all applicable solvers once
         # per shape and selects the composable-kernel XDL grouped-conv kernel (0.60 ms) -- profiles/miopen_find_r01.txt
-        torch.backends.cudnn.benchmark = True
         self.policy_value_net.eval()
         self._infer = InferenceNet(self.policy_value_net).to(self.device).eval()
         self._graph = None
@@ -191,7 +192,10 @@ class PolicyValueNet:
         """[B,17,7,10,9] fp16 device tensor -> (prob float32 [B,2086], value float32 [B]) on the same stream."""
         if self._infer is None:
             self.refresh_inference_copy()
-        return self._infer(leaf_input)
+        if os.environ.get("CCZ_MIOPEN_FIND", "1") == "0":  # immediate mode: no per-shape find step (tests, tiny nets)
+            return self._infer(leaf_input)
+        with torch.backends.cudnn.flags(enabled=True, benchmark=True):  # find mode for the evaluator's convs only
+            return self._infer(leaf_input)
 
     evaluate_leaves.batched = True
 
