@@ -126,6 +126,10 @@ def main():
         raise SystemExit("for --gpus N > 1 launch with python -m torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    if world > 1:  # every rank runs MIOpen's find step: keep their user perf-db / kernel caches apart
+        os.environ.setdefault("MIOPEN_USER_DB_PATH", f"/tmp/cczero_miopen_rank{rank}")
+        os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", f"/tmp/cczero_miopen_rank{rank}/cache")
+        os.makedirs(os.environ["MIOPEN_CUSTOM_CACHE_DIR"], exist_ok=True)
     import torch.distributed as dist
     if a.share_gpu:
         local_rank = 0
