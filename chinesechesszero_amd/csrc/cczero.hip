@@ -157,6 +157,7 @@ int ccz_create(const ccz_config *cfg, ccz_engine **out)
     ALLOC(d.rec_pi, B * d.pi_cap);
     ALLOC(d.stats, B);
     ALLOC(d.err, 4);
+    ALLOC(d.stamps, B * 16);
     ALLOC(e->st_k, B);
     ALLOC(e->st_visits, B * kMaxLegal);
     ALLOC(e->st_rootn, B);
@@ -478,5 +479,17 @@ int ccz_bias_act_f16(void *stream, void *y_dev, const void *bias_dev, const void
     HIP_TRY(hipGetLastError());
     return 0;
 }
+
+#ifdef CCZ_STAMPS
+// diagnostic build only: per-board s_memtime stamps of the last k_step launch (uint64 [B*16])
+int ccz_debug_stamps(ccz_engine *e, void *stream, unsigned long long *out_host)
+{
+    NEED(e);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(out_host, e->d.stamps, (size_t)e->d.B * 16 * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+#endif
 
 } // extern "C"

@@ -75,7 +75,32 @@ struct Dev {
     float *rec_pi;     // [B][pi_cap]
     BoardStats *stats; // [B]
     int32_t *err;      // [1] sticky error bits
+    unsigned long long *stamps; // [B][16] s_memtime stamps; only written by the diagnostic build (-DCCZ_STAMPS)
 };
+
+// In-kernel stamps (diagnostic build only: profiles/sim_stamps.py builds libcczero_stamps.so with -DCCZ_STAMPS;
+// the shipped kernels contain no stamp). One asm statement: s_memtime + its wait, fenced against reordering.
+#ifdef CCZ_STAMPS
+#define CCZ_STAMP(D_, b_, lane_, i_)                                                             \
+    {                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        unsigned long long t_;                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        if ((lane_) == 0) (D_).stamps[(size_t)(b_) * 16 + (i_)] = t_;                            \
+    }
+#define CCZ_GSTAMP(sp_, lane_, i_)                                                                \
+    {                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        unsigned long long t_;                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        if ((lane_) == 0 && (sp_)) (sp_)[i_] = t_;                                               \
+    }
+#else
+#define CCZ_STAMP(D_, b_, lane_, i_)
+#define CCZ_GSTAMP(sp_, lane_, i_)
+#endif
 
 #define CCZ_LEAF_SKIP 3
 
@@ -261,9 +286,11 @@ struct GenResult {
 // is non-null, as an ascending id list (the canonical `board.legal_moves` order).
 // Lane 4p+d generates direction d of piece p; lane j then tests pseudo-move j for king safety.
 // Must be called by all 64 lanes of the wave; sq[90..95] must be 0.
-__device__ inline GenResult gen_legal(const uint8_t *sq, int turn, GenScratch &S, uint16_t *ids_out, int lane)
+__device__ inline GenResult gen_legal(const uint8_t *sq, int turn, GenScratch &S, uint16_t *ids_out, int lane,
+                                   unsigned long long *sp = nullptr)
 {
     GenResult R;
+    (void)sp;
     const int ownbit = turn ? 0 : 1;
 #define OWN(q) ((q) != 0 && (((q) >> 3) == ownbit))
     const int p0 = sq[lane];
@@ -306,6 +333,7 @@ __device__ inline GenResult gen_legal(const uint8_t *sq, int turn, GenScratch &S
     }
     for (int w = lane; w < kMaskWords + 2; w += 64) S.mask[w] = 0u;
     wave_sync();
+    CCZ_GSTAMP(sp, lane, 10)
 
     // ---- phase B: pseudo-legal generation, lane = 4*piece + direction
     int cnt = 0, from = 0;
@@ -373,6 +401,7 @@ __device__ inline GenResult gen_legal(const uint8_t *sq, int turn, GenScratch &S
             }
         }
     }
+    CCZ_GSTAMP(sp, lane, 11)
     const int incl = wave_incl_scan(cnt, lane);
     int npseudo = __shfl(incl, 63);
     const int excl = incl - cnt;
@@ -381,6 +410,7 @@ __device__ inline GenResult gen_legal(const uint8_t *sq, int turn, GenScratch &S
         if (excl + i < kPseudoCap) S.list[excl + i] = (uint16_t)((from << 8) | out[i]);
     wave_sync();
 
+    CCZ_GSTAMP(sp, lane, 12)
     // ---- phase C: king safety, lane per pseudo-move
     for (int j = lane; j < npseudo; j += 64) {
         const int fr = S.list[j] >> 8, to = S.list[j] & 0xff;
@@ -393,6 +423,7 @@ __device__ inline GenResult gen_legal(const uint8_t *sq, int turn, GenScratch &S
     }
     wave_sync();
 
+    CCZ_GSTAMP(sp, lane, 13)
     // ---- phase D: count and list in ascending id order
     const uint32_t w0 = S.mask[lane];
     const uint32_t w1 = lane < 2 ? S.mask[64 + lane] : 0u;
@@ -422,6 +453,7 @@ __device__ inline GenResult gen_legal(const uint8_t *sq, int turn, GenScratch &S
             }
         }
     }
+    CCZ_GSTAMP(sp, lane, 14)
 #undef OWN
     return R;
 }

@@ -91,9 +91,9 @@ struct LeafEval {
 // s_chain[0..chain_len) holds the keys since the last capture incl. the current position (last)
 __device__ inline LeafEval eval_position(const uint8_t *s_sq, int turn, int halfmove, uint64_t key,
                                          const uint64_t *s_chain, int chain_len, GenScratch &S,
-                                         uint16_t *ids_out, int lane, bool &overflow)
+                                         uint16_t *ids_out, int lane, bool &overflow, unsigned long long *sp = nullptr)
 {
-    const GenResult g = gen_legal(s_sq, turn, S, ids_out, lane);
+    const GenResult g = gen_legal(s_sq, turn, S, ids_out, lane, sp);
     overflow = g.overflow;
     int rep = 0;
     for (int i0 = 0; i0 < chain_len; i0 += 64) {
@@ -169,6 +169,7 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
     if (m.chain_len > 64) s_chain[64 + lane] = D.chain[(size_t)b * kChainCap + 64 + lane];
     wave_sync();
 
+    CCZ_STAMP(D, b, lane, 3)
     int32_t *path = D.path + (size_t)b * D.maxd;
     int depth = 0, turn = m.turn, halfmove = m.halfmove, chain_len = m.chain_len;
     uint64_t key = m.key;
@@ -220,6 +221,7 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
         return;
     }
 
+    CCZ_STAMP(D, b, lane, 4)
     // ---- replay the selection path on the LDS board: (1) table lookups in parallel, (2) the inherently
     // serial piece shuffling by one lane, (3) Zobrist deltas in parallel + XOR prefix scan
     if (depth > 0) {
@@ -272,11 +274,18 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
     }
     wave_sync();
 
+    CCZ_STAMP(D, b, lane, 5)
     // ---- leaf: legal moves (net.py:154-157), game end (mcts.py:116-117)
     bool overflow;
+#ifdef CCZ_STAMPS
+    unsigned long long *sp = D.stamps + (size_t)b * 16;
+#else
+    unsigned long long *sp = nullptr;
+#endif
     const LeafEval L = eval_position(s_sq, turn, halfmove, key, s_chain, chain_len, sh.S,
-                                     D.leaf_ids + (size_t)b * kMaxLegal, lane, overflow);
+                                     D.leaf_ids + (size_t)b * kMaxLegal, lane, overflow, sp);
     if (overflow) set_err(D, 4);
+    CCZ_STAMP(D, b, lane, 6)
     if (lane == 0) {
         D.path_len[b] = depth;
         D.leaf_k[b] = L.n_legal > kMaxLegal ? kMaxLegal : L.n_legal;
@@ -288,6 +297,7 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
 
     // ---- evaluator input (net.py:160-177): groups 7 (red now), 15 (black now), 16 (side to move).
     // Staged in LDS: fill (zeros / the turn plane), scatter one fp16 1.0 per piece, stream out as dwords.
+    CCZ_STAMP(D, b, lane, 7)
     if (leaf_in) {
         uint32_t *enc = sh.enc;
         const uint32_t tv = turn ? 0x3C003C00u : 0u;
@@ -407,11 +417,15 @@ __global__ __launch_bounds__(64) void k_step(Dev D, const float *prob, const flo
 {
     __shared__ SelectShared sh;
     const int b = blockIdx.x, lane = threadIdx.x;
+    CCZ_STAMP(D, b, lane, 0)
     const Prefetch P = prefetch_board(D, b, lane); // root board, chain and meta: untouched by the expand phase
     expand_backup_phase(D, b, lane, prob, value, P.m);
+    CCZ_STAMP(D, b, lane, 1)
     __threadfence_block();
     __syncthreads();
+    CCZ_STAMP(D, b, lane, 2)
     select_phase(D, b, lane, leaf_in, sh, P);
+    CCZ_STAMP(D, b, lane, 9)
 }
 
 // ------------------------------------------------------------------ pi from root visits (mcts.py:162-166)
