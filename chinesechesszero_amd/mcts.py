@@ -69,6 +69,8 @@ class MCTS:
         self._synced: list[int] | None = None   # move ids pushed on the engine since its start position
         self._start = None
         self._discard = False
+        self._graph = None
+        self.use_graph = True   # single-board play is launch-bound: replay (evaluator, k_step) as one hipGraph
         owner = getattr(policy_value_fn, "__self__", None)
         if getattr(policy_value_fn, "batched", False):
             self._batched = policy_value_fn
@@ -140,8 +142,24 @@ class MCTS:
         self._sync_root(board)
         interval = max(1, self.n_playout // 100)
         acc = 0
+        e = self._engine
+        fused = self._batched is not None
+        if fused:
+            # launch sequence of a move: select, (evaluator, fused step) x (n-1), evaluator, expand_backup
+            leaf = e.select_leaves()
+            if self.use_graph and self._graph is None and getattr(self._batched, "graph_safe", False) and e.device.type == "cuda":
+                from .selfplay import GraphedStep
+                self._graph = GraphedStep(e, self._batched)
         for i in range(self.n_playout):
-            self.playout(board, red_states, black_states)
+            if not fused:
+                self.playout(board, red_states, black_states)
+            elif i + 1 < self.n_playout:
+                if self._graph is not None:
+                    self._graph.replay()
+                else:
+                    leaf = e.step(*self._batched(leaf))
+            else:
+                e.expand_backup(*self._batched(leaf))
             acc += 1
             if on_playout is not None and (acc >= interval or i == self.n_playout - 1):
                 try:

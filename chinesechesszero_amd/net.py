@@ -198,6 +198,7 @@ class PolicyValueNet:
             return self._infer(leaf_input)
 
     evaluate_leaves.batched = True
+    evaluate_leaves.graph_safe = True   # static shapes, no host sync: may be captured into a hipGraph
 
     # ---- reference surface --------------------------------------------------------------------
     def policy_value(self, state_batch):

@@ -14,12 +14,41 @@ from .engine import SelfPlayEngine
 from .parameters import ALPHA, C_PUCT, EPS
 
 
+class GraphedStep:
+    """hipGraph of one inner iteration ``evaluator(leaf) -> ccz_step`` (capture launch-bound loops in graphs).
+
+    At B = 4096 a step is 47 ms of GPU work and launches do not matter; at small B (single-board play, UCI)
+    the ~130 launches of a batch-1 forward are host-bound, and replaying one captured graph per simulation
+    removes that. The evaluator must be capture-safe (no host sync, static shapes): the MIOpen find step and
+    allocator warm-up therefore run eagerly on a side stream first.
+    """
+
+    def __init__(self, engine: SelfPlayEngine, evaluator, warmup: int = 3):
+        self.engine = engine
+        dev = engine.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):  # results are discarded: the pending leaf is only evaluated, never stepped
+                evaluator(engine.leaf_input)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            prob, value = evaluator(engine.leaf_input)
+            engine.step(prob, value)
+        # capture does not execute: nothing has been applied to the trees yet
+
+    def replay(self):
+        self.graph.replay()
+
+
 class BatchedSelfPlay:
     """``evaluator(leaf_input fp16 [B,17,7,10,9]) -> (prob f32 [B,2086], value f32 [B])`` on the device."""
 
     def __init__(self, evaluator, n_boards: int, n_playout: int = 400, c_puct: float = C_PUCT, eps: float = EPS,
                  alpha: float = ALPHA, temp: float = 1.0, seed: int = 0, board_id_base: int = 0, device: int = 0,
-                 sampling: str = "device", **engine_kw):
+                 sampling: str = "device", use_graph: bool = False, **engine_kw):
         if sampling not in ("device", "numpy"):
             raise ValueError("sampling must be 'device' (Philox on the GPU) or 'numpy' (reference-exact host RNG)")
         self.evaluator = evaluator
@@ -31,6 +60,8 @@ class BatchedSelfPlay:
         self.eps, self.alpha, self.temp = eps, alpha, temp
         # reference-exact host sampling: one legacy RandomState per board (mcts.py:216-224 uses the global one)
         self.rngs = [np.random.RandomState((seed + board_id_base + b) % (2**32)) for b in range(n_boards)] if sampling == "numpy" else None
+        self.use_graph = use_graph
+        self._graph = None
 
     # one lockstep simulation of every board
     def simulate(self):
@@ -47,12 +78,16 @@ class BatchedSelfPlay:
         interval = max(1, self.n_playout // 100)
         acc = 0
         leaf = e.select_leaves()
+        if self.use_graph and self._graph is None:
+            self._graph = GraphedStep(e, self.evaluator)
         for i in range(self.n_playout):
-            prob, value = self.evaluator(leaf)
             if i + 1 < self.n_playout:
-                leaf = e.step(prob, value)
+                if self._graph is not None:
+                    self._graph.replay()
+                else:
+                    leaf = e.step(*self.evaluator(leaf))
             else:
-                e.expand_backup(prob, value)
+                e.expand_backup(*self.evaluator(leaf))
             acc += 1
             if on_playout is not None and (acc >= interval or i == self.n_playout - 1):
                 try:

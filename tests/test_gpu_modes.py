@@ -122,3 +122,29 @@ def test_concurrent_trainer_config5_smoke():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in j
     assert set(j["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+def test_hipgraph_replay_equals_eager_launches():
+    """Replaying (evaluator, k_step) as one hipGraph walks the same trees as eager launches; small-B timing printed."""
+    import time
+    from chinesechesszero_amd.net import PolicyValueNet
+    from chinesechesszero_amd.selfplay import BatchedSelfPlay
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    pvn = PolicyValueNet(device=dev, num_channels=32, resblocks_num=4)
+    res = {}
+    for use_graph in (False, True):
+        sp = BatchedSelfPlay(pvn.evaluate_leaves, 8, n_playout=40, seed=3, use_graph=use_graph)
+        sp.run_move()                       # first move also pays capture / warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        moves = sp.run_move().cpu().numpy()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rc = sp.engine.root_children()
+        sp.engine.check_healthy()
+        res[use_graph] = (moves, rc["visits"].copy(), rc["acts"].copy(), sp.engine.root_positions(), dt)
+    assert np.array_equal(res[False][0], res[True][0])
+    assert np.array_equal(res[False][1], res[True][1]) and np.array_equal(res[False][2], res[True][2])
+    assert np.array_equal(res[False][3], res[True][3])
+    print(f"40 sims x 8 boards: eager {res[False][4] * 1e3:.1f} ms, hipGraph {res[True][4] * 1e3:.1f} ms")
