@@ -160,3 +160,23 @@ def test_trainer_step_reduces_loss_on_fixed_batch():
     # label-smoothed target: loss of the first step matches the formula evaluated by hand
     with pytest.raises(ValueError):
         tr.step(states, pi * 0.5, z)
+
+
+def test_memmap_dataset_reads_the_sink_format(tmp_path):
+    import pickle
+    from chinesechesszero_amd.collect import TupleSink
+    from chinesechesszero_amd.dataset import NpyMemmapDataset
+    sink = TupleSink(str(tmp_path))
+    s = (torch.rand(6, 17, 7, 10, 9) > 0.9).half()
+    p = torch.rand(6, 2086)
+    p = p / p.sum(1, keepdim=True)
+    z = torch.tensor([1., -1, 0, 0, 1, -1])
+    sink.append(s, p, z)
+    sink.flush()
+    ds = pickle.loads(pickle.dumps(NpyMemmapDataset(str(tmp_path))))
+    assert len(ds) == 6
+    st, pi, w = ds[4]
+    assert st.dtype == torch.float16 and torch.equal(st, s[4]) and torch.allclose(pi, p[4]) and float(w) == 1.0
+    loader = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False)
+    b = next(iter(loader))
+    assert b[0].shape == (4, 17, 7, 10, 9) and b[1].shape == (4, 2086) and b[2].shape == (4,)

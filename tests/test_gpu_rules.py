@@ -119,3 +119,86 @@ def test_action_table_and_flip_map_from_library(golden):
     from chinesechesszero_amd import tools
     assert [tools.move_id2move_action[i] for i in range(2086)] == golden["table"]
     assert np.array_equal(tools.flip_map(), golden["data"]["flip_map"])
+
+
+def _random_placements(n, seed):
+    """Random (not necessarily reachable) positions: every piece on a square its type may stand on, kings not
+    facing, side to move not already giving check is NOT required (the generators must agree regardless)."""
+    rs = np.random.RandomState(seed)
+    adv = {1: [3, 5, 13, 21, 23], 0: [84, 86, 76, 66, 68]}
+    bis = {1: [2, 6, 18, 22, 26, 38, 42], 0: [87, 83, 71, 67, 63, 51, 47]}
+    out = []
+    while len(out) < n:
+        sq = np.zeros(90, np.uint8)
+
+        def put(code, choices):
+            free = [s for s in choices if sq[s] == 0]
+            if free:
+                sq[free[rs.randint(len(free))]] = code
+
+        rk = [f + 9 * r for r in range(3) for f in range(3, 6)]
+        bk = [f + 9 * r for r in range(7, 10) for f in range(3, 6)]
+        put(7, rk)
+        put(15, bk)
+        for color, add in ((1, 0), (0, 8)):
+            for _ in range(rs.randint(0, 3)):
+                put(6 + add, adv[color])
+            for _ in range(rs.randint(0, 3)):
+                put(5 + add, bis[color])
+            for t, mx in ((3, 2), (4, 2), (2, 2)):
+                for _ in range(rs.randint(0, mx + 1)):
+                    put(t + add, list(range(90)))
+            own_side = [s for s in range(90) if (s // 9 in (3, 4) if color else s // 9 in (5, 6)) and (s % 9) % 2 == 0]
+            far_side = [s for s in range(90) if (s // 9 >= 5 if color else s // 9 <= 4)]
+            for _ in range(rs.randint(0, 6)):
+                put(1 + add, own_side if rs.rand() < 0.5 else far_side)
+        out.append((sq, int(rs.randint(2)), int(rs.choice([0, 0, 7, 119, 120, 130]))))
+    return out
+
+
+def test_random_piece_placements_match_oracle():
+    from oracle import OracleBoard
+    pos = _random_placements(6000, 11)
+    boards = [OracleBoard.from_array(sq, t, h) for sq, t, h in pos]
+    _compare(boards)
+
+
+def test_perft5_on_gpu_equals_published_count():
+    """Depth-4 frontier (3,290,240 positions) expanded and counted by the HIP kernels alone: perft(5) = 133,312,995."""
+    import torch
+    import ctypes as C
+    from chinesechesszero_amd import _lib
+    from golden_cases import start_position
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    stream = lambda: C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    sq = torch.zeros((1, 96), dtype=torch.uint8, device=dev)
+    sq[0, :90] = torch.from_numpy(start_position()).to(dev)
+    turn = torch.ones(1, dtype=torch.uint8, device=dev)
+    counts = []
+    for depth in range(5):
+        n = sq.shape[0]
+        total = 0
+        kids_sq, kids_turn = [], []
+        for s in range(0, n, 400000):
+            csq, cturn = sq[s:s + 400000].contiguous(), turn[s:s + 400000].contiguous()
+            m = csq.shape[0]
+            mask = torch.zeros((m, 66), dtype=torch.int32, device=dev)
+            cnt = torch.zeros(m, dtype=torch.int32, device=dev)
+            _lib.check(L.ccz_legal_moves(stream(), m, ptr(csq), ptr(cturn), None, ptr(mask), ptr(cnt), None))
+            total += int(cnt.sum().item())
+            if depth < 4:
+                bits = (mask.view(torch.uint8).unsqueeze(-1) >> torch.arange(8, device=dev, dtype=torch.uint8)) & 1
+                idx = bits.reshape(m, -1)[:, :2086].nonzero()          # (parent, move id), ascending
+                child = csq[idx[:, 0]].contiguous()
+                cturn2 = cturn[idx[:, 0]].contiguous()
+                ids = idx[:, 1].to(torch.int32).contiguous()
+                _lib.check(L.ccz_apply_moves(stream(), child.shape[0], ptr(child), ptr(cturn2), ptr(ids), None))
+                kids_sq.append(child)
+                kids_turn.append(cturn2)
+        counts.append(total)
+        if depth < 4:
+            sq, turn = torch.cat(kids_sq), torch.cat(kids_turn)
+            assert sq.shape[0] == total
+    assert counts == [44, 1920, 79666, 3290240, 133312995]
