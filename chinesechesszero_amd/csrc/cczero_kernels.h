@@ -117,7 +117,7 @@ struct SelectShared {
     uint64_t chain[kChainCap];
     GenScratch S;
     union {
-        uint32_t enc[948]; // staging of the 3 live plane groups (945 dwords); used after move generation
+        __align__(16) uint32_t enc[948]; // staging of the 3 live plane groups (945 dwords); used after move generation
         struct {           // deferred make-move of the selection path; dead before move generation starts
             uint16_t mv[kMaxDepth];
             uint8_t from[kMaxDepth], to[kMaxDepth], pc[kMaxDepth], cap[kMaxDepth];
@@ -170,11 +170,11 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
     wave_sync();
 
     CCZ_STAMP(D, b, lane, 3)
-    int32_t *path = D.path + (size_t)b * D.maxd;
+    int4 *path = D.path + (size_t)b * D.maxd;
     int depth = 0, turn = m.turn, halfmove = m.halfmove, chain_len = m.chain_len;
     uint64_t key = m.key;
     bool bad = false;
-    if (lane == 0) path[0] = 0;
+    if (lane == 0) path[0] = make_int4(0, pa.N, __float_as_int(pa.Q), 0);
 
     // ---- PUCT descent (mcts.py:105-111, 41-61)
     for (;;) {
@@ -183,6 +183,7 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
         const double sqrtNp = sqrt((double)pa.N); // np.sqrt(parent.visits): float64
         double best = -__builtin_huge_val();
         int besti = 0x7fffffff, bN = 0, bfc = -1;
+        float bQ = 0.0f;
         uint32_t bw = 0;
         for (int c0 = 0; c0 < nc; c0 += 64) {
             const int i = c0 + lane;
@@ -192,7 +193,7 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
                 // value + c_puct*prob*sqrt(N_parent)/(1+N): float32 product, float64 elsewhere; inf if unvisited
                 const double sc = c.N == 0 ? __builtin_huge_val()
                                            : (double)c.Q + (double)(D.c_puct * c.P) * sqrtNp / (double)(1 + c.N);
-                if (sc > best) { best = sc; besti = i; bN = c.N; bfc = c.fc; bw = w; }
+                if (sc > best) { best = sc; besti = i; bN = c.N; bQ = c.Q; bfc = c.fc; bw = w; }
             }
         }
         // first maximum in insertion order wins (Python max()): wave max of the score, then the lowest index
@@ -205,6 +206,7 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
         besti = __builtin_amdgcn_readlane(besti, owner);
         const int child = pa.fc + besti;
         pa.N = __builtin_amdgcn_readlane(bN, owner);
+        pa.Q = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bQ), owner));
         pa.fc = __builtin_amdgcn_readlane(bfc, owner);
         nb = (uint32_t)__builtin_amdgcn_readlane((int)bw, owner);
         const int mv = (int)(nb & 0xffffu);
@@ -213,7 +215,7 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
         if (lane == 0) sh.pm.mv[depth] = (uint16_t)mv;
         ++depth;
         if (depth >= D.maxd) { bad = true; set_err(D, 2); break; }
-        if (lane == 0) path[depth] = child;
+        if (lane == 0) path[depth] = make_int4(child, pa.N, __float_as_int(pa.Q), 0);
     }
     wave_sync();
     if (bad) {
@@ -302,9 +304,12 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
         uint32_t *enc = sh.enc;
         const uint32_t tv = turn ? 0x3C003C00u : 0u;
 #pragma unroll
-        for (int it = 0; it < 15; ++it) {
+        for (int it = 0; it < 4; ++it) { // 237 x 16 B: zeros for the two piece groups, the turn value from dword 630 on
             const int i = lane + 64 * it;
-            if (i < 945) enc[i] = i >= 630 ? tv : 0u;
+            if (i < 237) {
+                const int d0 = 4 * i;
+                ((uint4 *)enc)[i] = make_uint4(d0 >= 630 ? tv : 0u, d0 + 1 >= 630 ? tv : 0u, d0 + 2 >= 630 ? tv : 0u, d0 + 3 >= 630 ? tv : 0u);
+            }
         }
         wave_sync();
         {
@@ -315,11 +320,21 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
             if (q1) eh[(q1 >> 3) * 630 + ((q1 & 7) - 1) * 90 + 64 + lane] = kHalfOne;
         }
         wave_sync();
+        // three runs of 315 dwords at row offsets 2205 / 4725 / 5040 (dword-aligned only): 16-B LDS reads,
+        // 4 consecutive dword stores per lane (a wave still covers one contiguous KB per instruction group)
         uint32_t *row = (uint32_t *)(leaf_in + (size_t)b * 10710);
 #pragma unroll
-        for (int it = 0; it < 15; ++it) {
+        for (int it = 0; it < 4; ++it) {
             const int i = lane + 64 * it;
-            if (i < 945) row[i + (i < 315 ? 2205 : (i < 630 ? 4725 - 315 : 5040 - 630))] = enc[i];
+            if (i < 237) {
+                const uint4 v = ((const uint4 *)enc)[i];
+                const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int dwi = 4 * i + c;
+                    if (dwi < 945) row[dwi + (dwi < 315 ? 2205 : (dwi < 630 ? 4725 - 315 : 5040 - 630))] = vv[c];
+                }
+            }
         }
     }
 }
@@ -340,17 +355,17 @@ __device__ inline void expand_backup_phase(const Dev &D, int b, int lane, const 
     const int d = D.path_len[b];
     const int k_leaf = D.leaf_k[b];
     const float v_net = value[b];
-    const int32_t *path = D.path + (size_t)b * D.maxd;
+    const int4 *path = D.path + (size_t)b * D.maxd;
     const uint16_t *ids = D.leaf_ids + (size_t)b * kMaxLegal;
     const int id0 = ids[lane], id1 = ids[64 + lane];
-    const int pj = path[lane < D.maxd ? lane : 0];
+    const int4 pj = path[lane < D.maxd ? lane : 0];
     if (status == CCZ_LEAF_SKIP) return;
     BoardMeta *mp = D.meta + b;
     const int half = m0.half;
     const size_t base = ((size_t)b * 2 + half) * (size_t)D.cap;
     NodeA *A = D.nodeA + base;
     uint32_t *Bn = D.nodeB + base;
-    const int leaf = __shfl(pj, d < 64 ? d : 0);
+    const int leaf = __shfl(pj.x, d < 64 ? d : 0);
     float v;
     if (status == CCZ_LEAF_EXPAND) {
         // Node.expand (mcts.py:31-39): one child per legal id, ascending id order
@@ -370,7 +385,7 @@ __device__ inline void expand_backup_phase(const Dev &D, int b, int lane, const 
                 Bn[n0 + 64 + lane] = (uint32_t)id1;
             }
             if (lane == 0) {
-                const int leaf0 = d < 64 ? leaf : path[d];
+                const int leaf0 = d < 64 ? leaf : path[d].x;
                 A[leaf0].fc = n0;
                 Bn[leaf0] = (Bn[leaf0] & 0xffffu) | ((uint32_t)k << 16);
                 mp->n_nodes = n0 + k;
@@ -390,17 +405,16 @@ __device__ inline void expand_backup_phase(const Dev &D, int b, int lane, const 
     }
     // Node.update_recursive(-leaf_value) (mcts.py:73-78,129): leaf gets -v, its parent +v, ...
     for (int j = lane; j <= d; j += 64) {
-        const int node = j < 64 ? pj : path[j];
+        const int4 pr = j < 64 ? pj : path[j]; // {node, N, Q} as the select phase saw them (nothing else writes them)
+        const int node = pr.x;
         const float val = ((d - j) & 1) ? v : -v;
-        int32_t *np_ = &A[node].N;
-        float *qp = &A[node].Q;
-        const int n = *np_ + 1;
-        const float q = *qp;
+        const int n = pr.y + 1;
+        const float q = __int_as_float(pr.z);
         // visits += 1 ; value += 1.0*(leaf_value - value)/visits   in float32 (mcts.py:68-71)
         float delta = val - q;
         delta = delta / (float)n;
-        *np_ = n;
-        *qp = q + delta;
+        A[node].N = n;
+        A[node].Q = q + delta;
     }
 }
 
