@@ -123,6 +123,7 @@ int ccz_create(const ccz_config *cfg, ccz_engine **out)
     // nodes per pool half: every playout creates <= ~k children; the retained subtree adds to it
     const int n_play = cfg->n_playout > 0 ? cfg->n_playout : 400;
     d.cap = cfg->max_nodes > 0 ? cfg->max_nodes : (n_play + 64) * 256;
+    if (d.cap < 130) d.cap = 130; // root + one full expansion (the root's children are prefetched unconditionally)
     d.maxd = cfg->max_depth > 0 ? cfg->max_depth : kMaxDepth;
     if (d.maxd > kMaxDepth) { delete e; return fail(-1, "ccz_create: max_depth %d exceeds the compiled limit %d", d.maxd, kMaxDepth); }
     if (d.maxd < 64) { delete e; return fail(-1, "ccz_create: max_depth must be >= 64"); }
@@ -157,6 +158,7 @@ int ccz_create(const ccz_config *cfg, ccz_engine **out)
     ALLOC(d.rec_pi, B * d.pi_cap);
     ALLOC(d.stats, B);
     ALLOC(d.err, 4);
+    ALLOC(d.half, 4);
     ALLOC(d.stamps, B * 16);
     ALLOC(e->st_k, B);
     ALLOC(e->st_visits, B * kMaxLegal);
@@ -272,6 +274,8 @@ int ccz_finish_move(ccz_engine *e, void *stream, const int32_t *forced_moves_dev
     NEED(e);
     hipLaunchKernelGGL(k_finish_move, dim3(e->d.B), dim3(64), 0, (hipStream_t)stream, e->d, forced_moves_dev, temps_dev,
                        moves_out_dev, keep_tree ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_flip_half, dim3(1), dim3(1), 0, (hipStream_t)stream, e->d);
     HIP_TRY(hipGetLastError());
     return 0;
 }

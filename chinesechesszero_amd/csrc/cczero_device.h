@@ -76,6 +76,8 @@ struct Dev {
     float *rec_pi;     // [B][pi_cap]
     BoardStats *stats; // [B]
     int32_t *err;      // [1] sticky error bits
+    int32_t *half;     // [1] pool half holding every live tree: flipped once per move for ALL boards, so that tree
+                       // addresses (root = node 0, its children = nodes 1..k) are known before any load returns
     unsigned long long *stamps; // [B][16] s_memtime stamps; only written by the diagnostic build (-DCCZ_STAMPS)
 };
 

@@ -52,6 +52,7 @@ __device__ inline void init_board(const Dev &D, int b, int lane, int turn, int h
         m.winner = -1;
         m.pi_used = 0;
         if (new_game_no) m.game_no += 1;
+        m.half = (uint8_t)*D.half;
         D.meta[b] = m;
         D.chain[(size_t)b * kChainCap] = k;
         const size_t base = ((size_t)b * 2 + m.half) * (size_t)D.cap;
@@ -130,6 +131,25 @@ struct Prefetch {
     BoardMeta m;
     uint32_t sqw;      // lane < 24: dword `lane` of the root mailbox
     uint64_t c0;       // chain key `lane` (keys 64.. are fetched on demand: > 64 plies without a capture is rare)
+    int half;          // live pool half (one global word, the same for all boards)
+    NodeA root;        // node 0 of the live half
+    uint32_t rootw;
+    NodeA kid;         // lane i: node 1 + i = child i of the root (the root's children always start at node 1)
+    uint32_t kidw;
+};
+
+// what the expand+backup phase of this launch changed at the top of the tree (the prefetched root and
+// root-children records predate those stores)
+struct TopPatch {
+    bool active;       // a backup ran
+    bool root_expanded;// the root itself was the leaf and received children 1..k
+    bool kid_expanded; // the depth-1 path node was the leaf and received children n0..n0+k
+    int k, first_id, n0;
+    int rootN;
+    float rootQ;
+    int node1, N1;     // path node at depth 1 (if depth >= 1) with its updated N, Q
+    float Q1;
+    bool has1;
 };
 
 __device__ __forceinline__ Prefetch prefetch_board(const Dev &D, int b, int lane)
@@ -139,13 +159,20 @@ __device__ __forceinline__ Prefetch prefetch_board(const Dev &D, int b, int lane
     P.sqw = lane < 24 ? ((const uint32_t *)(D.root_sq + (size_t)b * 96))[lane] : 0u;
     const uint64_t *ch = D.chain + (size_t)b * kChainCap;
     P.c0 = ch[lane];
+    P.half = *D.half;
+    const size_t base = ((size_t)b * 2 + P.half) * (size_t)D.cap;
+    P.root = D.nodeA[base];
+    P.rootw = D.nodeB[base];
+    P.kid = D.nodeA[base + 1 + lane];
+    P.kidw = D.nodeB[base + 1 + lane];
     return P;
 }
 
 // One wave: PUCT descent from the root of board b, leaf rules, evaluator input. Per tree level there is
 // ONE dependent global load round (the children's 16-B NodeA records + their move/count words); the
 // chosen child's own N / first_child / count are broadcast from the winning lane, not re-read.
-__device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *leaf_in, SelectShared &sh, const Prefetch &P)
+__device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *leaf_in, SelectShared &sh, const Prefetch &P,
+                                    const TopPatch &tp)
 {
     uint8_t *s_sq = sh.sq;
     uint64_t *s_chain = sh.chain;
@@ -154,11 +181,18 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
         if (lane == 0) D.leaf_status[b] = CCZ_LEAF_SKIP;
         return;
     }
-    const size_t base = ((size_t)b * 2 + m.half) * (size_t)D.cap;
+    const size_t base = ((size_t)b * 2 + P.half) * (size_t)D.cap;
     const NodeA *A = D.nodeA + base;
     const uint32_t *Bn = D.nodeB + base;
-    NodeA pa = A[0];
-    uint32_t nb = Bn[0];
+    // the root record was requested together with everything else at the top of the kernel; what this
+    // launch's backup changed in it is patched in from registers
+    NodeA pa = P.root;
+    uint32_t nb = P.rootw;
+    if (tp.active) {
+        pa.N = tp.rootN;
+        pa.Q = tp.rootQ;
+        if (tp.root_expanded) { pa.fc = 1; nb = (nb & 0xffffu) | ((uint32_t)tp.k << 16); }
+    }
     if (lane < 24) {
         uint32_t v = P.sqw;
         if (lane == 22) v &= 0x0000ffffu;
@@ -188,8 +222,21 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
         for (int c0 = 0; c0 < nc; c0 += 64) {
             const int i = c0 + lane;
             if (i < nc) {
-                const NodeA c = A[pa.fc + i];
-                const uint32_t w = Bn[pa.fc + i];
+                NodeA c;
+                uint32_t w;
+                if (depth == 0 && c0 == 0 && pa.fc == 1) { // root children: prefetched (+ this launch's backup)
+                    c = P.kid;
+                    w = P.kidw;
+                    if (tp.root_expanded) { c.N = 0; c.Q = 0.0f; c.fc = -1; w = (uint32_t)tp.first_id; }
+                    else if (tp.has1 && 1 + i == tp.node1) {
+                        c.N = tp.N1;
+                        c.Q = tp.Q1;
+                        if (tp.kid_expanded) { c.fc = tp.n0; w = (w & 0xffffu) | ((uint32_t)tp.k << 16); }
+                    }
+                } else {
+                    c = A[pa.fc + i];
+                    w = Bn[pa.fc + i];
+                }
                 // value + c_puct*prob*sqrt(N_parent)/(1+N): float32 product, float64 elsewhere; inf if unvisited
                 const double sc = c.N == 0 ? __builtin_huge_val()
                                            : (double)c.Q + (double)(D.c_puct * c.P) * sqrtNp / (double)(1 + c.N);
@@ -343,13 +390,19 @@ __global__ __launch_bounds__(64) void k_select(Dev D, uint16_t *leaf_in)
 {
     __shared__ SelectShared sh;
     const Prefetch P = prefetch_board(D, blockIdx.x, threadIdx.x);
-    select_phase(D, blockIdx.x, threadIdx.x, leaf_in, sh, P);
+    TopPatch none;
+    none.active = false; none.root_expanded = false; none.kid_expanded = false; none.k = 0; none.first_id = 0; none.n0 = 0;
+    none.rootN = 0; none.rootQ = 0.0f; none.node1 = -1; none.N1 = 0; none.Q1 = 0.0f; none.has1 = false;
+    select_phase(D, blockIdx.x, threadIdx.x, leaf_in, sh, P, none);
 }
 
 // ------------------------------------------------------------------ K2: expand + backup
-__device__ inline void expand_backup_phase(const Dev &D, int b, int lane, const float *prob, const float *value,
-                                           const BoardMeta &m0)
+__device__ inline TopPatch expand_backup_phase(const Dev &D, int b, int lane, const float *prob, const float *value,
+                                               const BoardMeta &m0, int half)
 {
+    TopPatch tp;
+    tp.active = false; tp.root_expanded = false; tp.kid_expanded = false; tp.k = 0; tp.first_id = 0; tp.n0 = 0; tp.rootN = 0;
+    tp.rootQ = 0.0f; tp.node1 = -1; tp.N1 = 0; tp.Q1 = 0.0f; tp.has1 = false;
     // everything that does not depend on another load is requested first
     const int status = D.leaf_status[b];
     const int d = D.path_len[b];
@@ -359,9 +412,8 @@ __device__ inline void expand_backup_phase(const Dev &D, int b, int lane, const 
     const uint16_t *ids = D.leaf_ids + (size_t)b * kMaxLegal;
     const int id0 = ids[lane], id1 = ids[64 + lane];
     const int4 pj = path[lane < D.maxd ? lane : 0];
-    if (status == CCZ_LEAF_SKIP) return;
+    if (status == CCZ_LEAF_SKIP) return tp;
     BoardMeta *mp = D.meta + b;
-    const int half = m0.half;
     const size_t base = ((size_t)b * 2 + half) * (size_t)D.cap;
     NodeA *A = D.nodeA + base;
     uint32_t *Bn = D.nodeB + base;
@@ -384,6 +436,11 @@ __device__ inline void expand_backup_phase(const Dev &D, int b, int lane, const 
                 A[n0 + 64 + lane] = NodeA{0, 0.0f, pr[id1], -1};
                 Bn[n0 + 64 + lane] = (uint32_t)id1;
             }
+            tp.root_expanded = d == 0;
+            tp.kid_expanded = d == 1;
+            tp.n0 = n0;
+            tp.k = k;
+            tp.first_id = __shfl(id0, 0);
             if (lane == 0) {
                 const int leaf0 = d < 64 ? leaf : path[d].x;
                 A[leaf0].fc = n0;
@@ -404,6 +461,8 @@ __device__ inline void expand_backup_phase(const Dev &D, int b, int lane, const 
         D.leaf_status[b] = CCZ_LEAF_SKIP; // consumed: a repeated call must not back the same leaf up twice
     }
     // Node.update_recursive(-leaf_value) (mcts.py:73-78,129): leaf gets -v, its parent +v, ...
+    int myN = 0;
+    float myQ = 0.0f;
     for (int j = lane; j <= d; j += 64) {
         const int4 pr = j < 64 ? pj : path[j]; // {node, N, Q} as the select phase saw them (nothing else writes them)
         const int node = pr.x;
@@ -415,13 +474,22 @@ __device__ inline void expand_backup_phase(const Dev &D, int b, int lane, const 
         delta = delta / (float)n;
         A[node].N = n;
         A[node].Q = q + delta;
+        if (j < 64) { myN = n; myQ = q + delta; }
     }
+    tp.active = true;
+    tp.rootN = __builtin_amdgcn_readlane(myN, 0);
+    tp.rootQ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myQ), 0));
+    tp.has1 = d >= 1;
+    tp.node1 = __builtin_amdgcn_readlane(pj.x, 1);
+    tp.N1 = __builtin_amdgcn_readlane(myN, 1);
+    tp.Q1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myQ), 1));
+    return tp;
 }
 
 __global__ __launch_bounds__(64) void k_expand_backup(Dev D, const float *prob, const float *value)
 {
     const BoardMeta m0 = D.meta[blockIdx.x];
-    expand_backup_phase(D, blockIdx.x, threadIdx.x, prob, value, m0);
+    (void)expand_backup_phase(D, blockIdx.x, threadIdx.x, prob, value, m0, *D.half);
 }
 
 // ------------------------------------------------------------------ fused step: expand+backup of the pending leaf, then the next select
@@ -433,12 +501,12 @@ __global__ __launch_bounds__(64) void k_step(Dev D, const float *prob, const flo
     const int b = blockIdx.x, lane = threadIdx.x;
     CCZ_STAMP(D, b, lane, 0)
     const Prefetch P = prefetch_board(D, b, lane); // root board, chain and meta: untouched by the expand phase
-    expand_backup_phase(D, b, lane, prob, value, P.m);
+    const TopPatch tp = expand_backup_phase(D, b, lane, prob, value, P.m, P.half);
     CCZ_STAMP(D, b, lane, 1)
     __threadfence_block();
     __syncthreads();
     CCZ_STAMP(D, b, lane, 2)
-    select_phase(D, b, lane, leaf_in, sh, P);
+    select_phase(D, b, lane, leaf_in, sh, P, tp);
     CCZ_STAMP(D, b, lane, 9)
 }
 
@@ -482,7 +550,7 @@ __global__ __launch_bounds__(64) void k_root_children(Dev D, int32_t *k_out, uin
     __shared__ int32_t s_vis[kMaxLegal];
     __shared__ double s_pi[kMaxLegal];
     const BoardMeta m = D.meta[b];
-    const size_t base = ((size_t)b * 2 + m.half) * (size_t)D.cap;
+    const size_t base = ((size_t)b * 2 + *D.half) * (size_t)D.cap;
     const NodeA *A = D.nodeA + base;
     const uint32_t *Bn = D.nodeB + base;
     const NodeA root = A[0];
@@ -528,7 +596,12 @@ __global__ __launch_bounds__(64) void k_finish_move(Dev D, const int32_t *forced
     BoardMeta m = D.meta[b];
     if (moves_out && lane == 0) moves_out[b] = -1;
     if (m.over) return;
-    const size_t baseOld = ((size_t)b * 2 + m.half) * (size_t)D.cap;
+    const int oh = *D.half, nh = oh ^ 1; // every board moves to the other pool half (the host flips the word afterwards)
+    const size_t baseOld = ((size_t)b * 2 + oh) * (size_t)D.cap;
+    {   // whatever happens below, the new half holds a valid (empty) tree for this board
+        const size_t bn = ((size_t)b * 2 + nh) * (size_t)D.cap;
+        if (lane == 0) { D.nodeA[bn] = NodeA{0, 0.0f, 1.0f, -1}; D.nodeB[bn] = 0u; }
+    }
     const NodeA *A = D.nodeA + baseOld;
     const uint32_t *Bn = D.nodeB + baseOld;
     const NodeA root = A[0];
@@ -605,7 +678,6 @@ __global__ __launch_bounds__(64) void k_finish_move(Dev D, const int32_t *forced
 
     // ---- MCTS.update_with_move (mcts.py:168-178): re-root on the chosen child, subtree copied
     // breadth-first into the other pool half (children of a node stay contiguous)
-    const int nh = m.half ^ 1;
     const size_t baseNew = ((size_t)b * 2 + nh) * (size_t)D.cap;
     NodeA *NA = D.nodeA + baseNew;
     uint32_t *NB = D.nodeB + baseNew;
@@ -790,4 +862,9 @@ __global__ void k_apply_moves(int n, uint8_t *sq, uint8_t *turn, const int32_t *
     turn[i] ^= 1;
 }
 
+} // namespace ccz
+
+namespace ccz {
+// one thread, after k_finish_move: all live trees now sit in the other pool half
+__global__ void k_flip_half(Dev D) { *D.half ^= 1; }
 } // namespace ccz

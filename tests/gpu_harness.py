@@ -108,7 +108,10 @@ class Lockstep:
 
     def compare_roots(self):
         rc = self.e.root_children()
+        over = self.e.game_status()["over"]
         for b in range(self.B):
+            if over[b]:
+                continue  # a finished board has no live tree (its pool half is recycled by the global flip)
             acts, visits, q, prior = self.mcts[b].root_children()
             k = len(acts)
             assert rc["k"][b] == k, (b, rc["k"][b], k)
