@@ -351,12 +351,9 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
         uint32_t *enc = sh.enc;
         const uint32_t tv = turn ? 0x3C003C00u : 0u;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) { // 237 x 16 B: zeros for the two piece groups, the turn value from dword 630 on
+        for (int it = 0; it < 15; ++it) {
             const int i = lane + 64 * it;
-            if (i < 237) {
-                const int d0 = 4 * i;
-                ((uint4 *)enc)[i] = make_uint4(d0 >= 630 ? tv : 0u, d0 + 1 >= 630 ? tv : 0u, d0 + 2 >= 630 ? tv : 0u, d0 + 3 >= 630 ? tv : 0u);
-            }
+            if (i < 945) enc[i] = i >= 630 ? tv : 0u;
         }
         wave_sync();
         {
@@ -367,21 +364,11 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
             if (q1) eh[(q1 >> 3) * 630 + ((q1 & 7) - 1) * 90 + 64 + lane] = kHalfOne;
         }
         wave_sync();
-        // three runs of 315 dwords at row offsets 2205 / 4725 / 5040 (dword-aligned only): 16-B LDS reads,
-        // 4 consecutive dword stores per lane (a wave still covers one contiguous KB per instruction group)
         uint32_t *row = (uint32_t *)(leaf_in + (size_t)b * 10710);
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
+        for (int it = 0; it < 15; ++it) {
             const int i = lane + 64 * it;
-            if (i < 237) {
-                const uint4 v = ((const uint4 *)enc)[i];
-                const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int dwi = 4 * i + c;
-                    if (dwi < 945) row[dwi + (dwi < 315 ? 2205 : (dwi < 630 ? 4725 - 315 : 5040 - 630))] = vv[c];
-                }
-            }
+            if (i < 945) row[i + (i < 315 ? 2205 : (i < 630 ? 4725 - 315 : 5040 - 630))] = enc[i];
         }
     }
 }
