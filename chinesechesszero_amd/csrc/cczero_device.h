@@ -62,7 +62,7 @@ struct Dev {
     BoardMeta *meta;   // [B]
     uint8_t *root_sq;  // [B][96]
     uint64_t *chain;   // [B][128]
-    int4 *path;        // [B][maxd] selection path: {node, N, Q bits, -} as seen by the select phase, so
+    int32_t *path;     // [B][maxd] selection path: {node, N, Q bits, -} as seen by the select phase, so
                        // that the backup needs no dependent load of the node records
     int32_t *path_len; // [B] depth of the leaf (path holds depth+1 nodes)
     uint16_t *leaf_ids;   // [B][128]

@@ -204,11 +204,11 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
     wave_sync();
 
     CCZ_STAMP(D, b, lane, 3)
-    int4 *path = D.path + (size_t)b * D.maxd;
+    int32_t *path = D.path + (size_t)b * D.maxd;
     int depth = 0, turn = m.turn, halfmove = m.halfmove, chain_len = m.chain_len;
     uint64_t key = m.key;
     bool bad = false;
-    if (lane == 0) path[0] = make_int4(0, pa.N, __float_as_int(pa.Q), 0);
+    if (lane == 0) path[0] = 0;
 
     // ---- PUCT descent (mcts.py:105-111, 41-61)
     for (;;) {
@@ -262,7 +262,7 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
         if (lane == 0) sh.pm.mv[depth] = (uint16_t)mv;
         ++depth;
         if (depth >= D.maxd) { bad = true; set_err(D, 2); break; }
-        if (lane == 0) path[depth] = make_int4(child, pa.N, __float_as_int(pa.Q), 0);
+        if (lane == 0) path[depth] = child;
     }
     wave_sync();
     if (bad) {
@@ -395,16 +395,16 @@ __device__ inline TopPatch expand_backup_phase(const Dev &D, int b, int lane, co
     const int d = D.path_len[b];
     const int k_leaf = D.leaf_k[b];
     const float v_net = value[b];
-    const int4 *path = D.path + (size_t)b * D.maxd;
+    const int32_t *path = D.path + (size_t)b * D.maxd;
     const uint16_t *ids = D.leaf_ids + (size_t)b * kMaxLegal;
     const int id0 = ids[lane], id1 = ids[64 + lane];
-    const int4 pj = path[lane < D.maxd ? lane : 0];
+    const int pj = path[lane < D.maxd ? lane : 0];
     if (status == CCZ_LEAF_SKIP) return tp;
     BoardMeta *mp = D.meta + b;
     const size_t base = ((size_t)b * 2 + half) * (size_t)D.cap;
     NodeA *A = D.nodeA + base;
     uint32_t *Bn = D.nodeB + base;
-    const int leaf = __shfl(pj.x, d < 64 ? d : 0);
+    const int leaf = __shfl(pj, d < 64 ? d : 0);
     float v;
     if (status == CCZ_LEAF_EXPAND) {
         // Node.expand (mcts.py:31-39): one child per legal id, ascending id order
@@ -429,7 +429,7 @@ __device__ inline TopPatch expand_backup_phase(const Dev &D, int b, int lane, co
             tp.k = k;
             tp.first_id = __shfl(id0, 0);
             if (lane == 0) {
-                const int leaf0 = d < 64 ? leaf : path[d].x;
+                const int leaf0 = d < 64 ? leaf : path[d];
                 A[leaf0].fc = n0;
                 Bn[leaf0] = (Bn[leaf0] & 0xffffu) | ((uint32_t)k << 16);
                 mp->n_nodes = n0 + k;
@@ -451,11 +451,10 @@ __device__ inline TopPatch expand_backup_phase(const Dev &D, int b, int lane, co
     int myN = 0;
     float myQ = 0.0f;
     for (int j = lane; j <= d; j += 64) {
-        const int4 pr = j < 64 ? pj : path[j]; // {node, N, Q} as the select phase saw them (nothing else writes them)
-        const int node = pr.x;
+        const int node = j < 64 ? pj : path[j];
         const float val = ((d - j) & 1) ? v : -v;
-        const int n = pr.y + 1;
-        const float q = __int_as_float(pr.z);
+        const int n = A[node].N + 1;
+        const float q = A[node].Q;
         // visits += 1 ; value += 1.0*(leaf_value - value)/visits   in float32 (mcts.py:68-71)
         float delta = val - q;
         delta = delta / (float)n;
@@ -467,7 +466,7 @@ __device__ inline TopPatch expand_backup_phase(const Dev &D, int b, int lane, co
     tp.rootN = __builtin_amdgcn_readlane(myN, 0);
     tp.rootQ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myQ), 0));
     tp.has1 = d >= 1;
-    tp.node1 = __builtin_amdgcn_readlane(pj.x, 1);
+    tp.node1 = __builtin_amdgcn_readlane(pj, 1);
     tp.N1 = __builtin_amdgcn_readlane(myN, 1);
     tp.Q1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myQ), 1));
     return tp;
