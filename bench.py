@@ -152,7 +152,7 @@ def main():
         torch.manual_seed(0)
         pvn = PolicyValueNet(device=dev, num_channels=a.channels, resblocks_num=a.blocks)
         pvn.refresh_inference_copy()
-        evaluator = pvn.evaluate_leaves
+        evaluator = pvn.evaluate_leaves_logits  # compact boundary: logits in, the engine gathers the legal priors
     else:
         evaluator = uniform_evaluator
     sp = BatchedSelfPlay(evaluator, B, n_playout=n, seed=0, board_id_base=rank * B, device=local_rank,
@@ -187,6 +187,10 @@ def main():
                 rb.append(s.to(dev), p.to(dev), z.to(dev))
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
+    logits_in = bool(getattr(evaluator, "returns_logits", False))
+    import ctypes as _C
+    from chinesechesszero_amd._lib import check as check_rc
+    ptr_of = lambda t: _C.c_void_p(t.data_ptr())
     step_no = [0]
     state = {"leaf": None}
 
@@ -202,13 +206,18 @@ def main():
                 e0, e1, e2 = ev(), ev(), ev()
                 e0.record()
             prob, value = evaluator(state["leaf"])
+            if logits_in:  # the softmax+gather of the legal priors belongs to the evaluator side of the split
+                e.gather_priors(prob, value)
             if timed:
                 e1.record()
             if last_of_move:
-                e.expand_backup(prob, value)
+                if logits_in:
+                    check_rc(e.L.ccz_expand_backup_compact(e.h, e._stream(), ptr_of(value)))
+                else:
+                    e.expand_backup(prob, value)
                 state["leaf"] = None
             else:
-                state["leaf"] = e.step(prob, value)
+                state["leaf"] = e.step_compact(value) if logits_in else e.step(prob, value)
             if timed:
                 e2.record()
                 if not last_of_move:

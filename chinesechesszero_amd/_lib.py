@@ -68,6 +68,9 @@ PROTOTYPES = {
     "ccz_zero_leaf_input": (C.c_int, [_P, _P, _P]),
     "ccz_expand_backup": (C.c_int, [_P, _P, _P, _P]),
     "ccz_step": (C.c_int, [_P, _P, _P, _P, _P]),
+    "ccz_gather_priors": (C.c_int, [_P, _P, _P, C.c_int32]),
+    "ccz_step_compact": (C.c_int, [_P, _P, _P, _P]),
+    "ccz_expand_backup_compact": (C.c_int, [_P, _P, _P]),
     "ccz_finish_move": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32]),
     "ccz_root_children": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "ccz_root_pi": (C.c_int, [_P, _P, _P, _P]),

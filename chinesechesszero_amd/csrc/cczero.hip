@@ -159,6 +159,7 @@ int ccz_create(const ccz_config *cfg, ccz_engine **out)
     ALLOC(d.stats, B);
     ALLOC(d.err, 4);
     ALLOC(d.half, 4);
+    ALLOC(d.prior128, B * kMaxLegal);
     ALLOC(d.stamps, B * 16);
     ALLOC(e->st_k, B);
     ALLOC(e->st_visits, B * kMaxLegal);
@@ -253,7 +254,7 @@ int ccz_expand_backup(ccz_engine *e, void *stream, const float *prob_dev, const 
 {
     NEED(e);
     if (!prob_dev || !value_dev) return fail(-1, "ccz_expand_backup: null prob/value");
-    hipLaunchKernelGGL(k_expand_backup, dim3(e->d.B), dim3(64), 0, (hipStream_t)stream, e->d, prob_dev, value_dev);
+    hipLaunchKernelGGL(k_expand_backup<false>, dim3(e->d.B), dim3(64), 0, (hipStream_t)stream, e->d, prob_dev, value_dev);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -262,8 +263,41 @@ int ccz_step(ccz_engine *e, void *stream, const float *prob_dev, const float *va
 {
     NEED(e);
     if (!prob_dev || !value_dev) return fail(-1, "ccz_step: null prob/value");
-    hipLaunchKernelGGL(k_step, dim3(e->d.B), dim3(64), 0, (hipStream_t)stream, e->d, prob_dev, value_dev,
+    hipLaunchKernelGGL(k_step<false>, dim3(e->d.B), dim3(64), 0, (hipStream_t)stream, e->d, prob_dev, value_dev,
                        (uint16_t *)leaf_input_f16_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ccz_gather_priors(ccz_engine *e, void *stream, const void *logits_dev, int32_t logits_f16)
+{
+    NEED(e);
+    if (!logits_dev) return fail(-1, "ccz_gather_priors: null logits");
+    hipStream_t s = (hipStream_t)stream;
+    if (logits_f16)
+        hipLaunchKernelGGL(k_softmax_gather<_Float16>, dim3(e->d.B), dim3(64), 0, s, e->d, (const _Float16 *)logits_dev);
+    else
+        hipLaunchKernelGGL(k_softmax_gather<float>, dim3(e->d.B), dim3(64), 0, s, e->d, (const float *)logits_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ccz_step_compact(ccz_engine *e, void *stream, const float *value_dev, void *leaf_input_f16_dev)
+{
+    NEED(e);
+    if (!value_dev) return fail(-1, "ccz_step_compact: null value");
+    hipLaunchKernelGGL(k_step<true>, dim3(e->d.B), dim3(64), 0, (hipStream_t)stream, e->d, (const float *)e->d.prior128, value_dev,
+                       (uint16_t *)leaf_input_f16_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ccz_expand_backup_compact(ccz_engine *e, void *stream, const float *value_dev)
+{
+    NEED(e);
+    if (!value_dev) return fail(-1, "ccz_expand_backup_compact: null value");
+    hipLaunchKernelGGL(k_expand_backup<true>, dim3(e->d.B), dim3(64), 0, (hipStream_t)stream, e->d, (const float *)e->d.prior128,
+                       value_dev);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -76,6 +76,7 @@ struct Dev {
     float *rec_pi;     // [B][pi_cap]
     BoardStats *stats; // [B]
     int32_t *err;      // [1] sticky error bits
+    float *prior128;   // [B][128] priors of the leaf's legal moves (compact evaluator boundary, ccz_*_logits)
     int32_t *half;     // [1] pool half holding every live tree: flipped once per move for ALL boards, so that tree
                        // addresses (root = node 0, its children = nodes 1..k) are known before any load returns
     unsigned long long *stamps; // [B][16] s_memtime stamps; only written by the diagnostic build (-DCCZ_STAMPS)
@@ -172,6 +173,32 @@ __device__ __forceinline__ uint64_t wave_readlane64(uint64_t x, int l)
     const int lo = __builtin_amdgcn_readlane((int)(x & 0xffffffffull), l);
     const int hi = __builtin_amdgcn_readlane((int)(x >> 32), l);
     return ((uint64_t)(unsigned int)hi << 32) | (unsigned int)lo;
+}
+
+__device__ __forceinline__ float wave_max_f32(float x)
+{
+    const int ninf = __float_as_int(-__builtin_huge_valf());
+#define CCZ_FMAX_STEP(ctrl_, rmask_) x = fmaxf(x, __int_as_float(CCZ_DPP(ninf, __float_as_int(x), ctrl_, rmask_)));
+    CCZ_FMAX_STEP(0x111, 0xf)
+    CCZ_FMAX_STEP(0x112, 0xf)
+    CCZ_FMAX_STEP(0x114, 0xf)
+    CCZ_FMAX_STEP(0x118, 0xf)
+    CCZ_FMAX_STEP(0x142, 0xa)
+    CCZ_FMAX_STEP(0x143, 0xc)
+#undef CCZ_FMAX_STEP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+__device__ __forceinline__ float wave_sum_f32(float x)
+{
+#define CCZ_FADD_STEP(ctrl_, rmask_) x += __int_as_float(CCZ_DPP(0, __float_as_int(x), ctrl_, rmask_));
+    CCZ_FADD_STEP(0x111, 0xf)
+    CCZ_FADD_STEP(0x112, 0xf)
+    CCZ_FADD_STEP(0x114, 0xf)
+    CCZ_FADD_STEP(0x118, 0xf)
+    CCZ_FADD_STEP(0x142, 0xa)
+    CCZ_FADD_STEP(0x143, 0xc)
+#undef CCZ_FADD_STEP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
 }
 
 // maximum over the 64 lanes of a double (no NaNs), returned in every lane

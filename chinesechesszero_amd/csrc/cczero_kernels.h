@@ -384,6 +384,8 @@ __global__ __launch_bounds__(64) void k_select(Dev D, uint16_t *leaf_in)
 }
 
 // ------------------------------------------------------------------ K2: expand + backup
+// prob: dense [B][2086] priors (compact == false) or compact [B][128] priors aligned with leaf_ids (compact == true)
+template <bool COMPACT>
 __device__ inline TopPatch expand_backup_phase(const Dev &D, int b, int lane, const float *prob, const float *value,
                                                const BoardMeta &m0, int half)
 {
@@ -398,6 +400,9 @@ __device__ inline TopPatch expand_backup_phase(const Dev &D, int b, int lane, co
     const int32_t *path = D.path + (size_t)b * D.maxd;
     const uint16_t *ids = D.leaf_ids + (size_t)b * kMaxLegal;
     const int id0 = ids[lane], id1 = ids[64 + lane];
+    // compact priors need no second, id-dependent load round: they are requested here with everything else
+    float cp0 = 0.0f, cp1 = 0.0f;
+    if (COMPACT) { cp0 = prob[(size_t)b * kMaxLegal + lane]; cp1 = prob[(size_t)b * kMaxLegal + 64 + lane]; }
     const int pj = path[lane < D.maxd ? lane : 0];
     if (status == CCZ_LEAF_SKIP) return tp;
     BoardMeta *mp = D.meta + b;
@@ -416,11 +421,11 @@ __device__ inline TopPatch expand_backup_phase(const Dev &D, int b, int lane, co
         } else {
             const float *pr = prob + (size_t)b * kNMoves;
             if (lane < k) {
-                A[n0 + lane] = NodeA{0, 0.0f, pr[id0], -1};
+                A[n0 + lane] = NodeA{0, 0.0f, COMPACT ? cp0 : pr[id0], -1};
                 Bn[n0 + lane] = (uint32_t)id0;
             }
             if (64 + lane < k) {
-                A[n0 + 64 + lane] = NodeA{0, 0.0f, pr[id1], -1};
+                A[n0 + 64 + lane] = NodeA{0, 0.0f, COMPACT ? cp1 : pr[id1], -1};
                 Bn[n0 + 64 + lane] = (uint32_t)id1;
             }
             tp.root_expanded = d == 0;
@@ -472,28 +477,61 @@ __device__ inline TopPatch expand_backup_phase(const Dev &D, int b, int lane, co
     return tp;
 }
 
+template <bool COMPACT>
 __global__ __launch_bounds__(64) void k_expand_backup(Dev D, const float *prob, const float *value)
 {
     const BoardMeta m0 = D.meta[blockIdx.x];
-    (void)expand_backup_phase(D, blockIdx.x, threadIdx.x, prob, value, m0, *D.half);
+    (void)expand_backup_phase<COMPACT>(D, blockIdx.x, threadIdx.x, prob, value, m0, *D.half);
 }
 
 // ------------------------------------------------------------------ fused step: expand+backup of the pending leaf, then the next select
 // Saves one launch boundary and the re-read of the board's tree head per simulation. The phases
 // touch the same nodes from different lanes, so a workgroup barrier (one wave) separates them.
+template <bool COMPACT>
 __global__ __launch_bounds__(64) void k_step(Dev D, const float *prob, const float *value, uint16_t *leaf_in)
 {
     __shared__ SelectShared sh;
     const int b = blockIdx.x, lane = threadIdx.x;
     CCZ_STAMP(D, b, lane, 0)
     const Prefetch P = prefetch_board(D, b, lane); // root board, chain and meta: untouched by the expand phase
-    const TopPatch tp = expand_backup_phase(D, b, lane, prob, value, P.m, P.half);
+    const TopPatch tp = expand_backup_phase<COMPACT>(D, b, lane, prob, value, P.m, P.half);
     CCZ_STAMP(D, b, lane, 1)
     __threadfence_block();
     __syncthreads();
     CCZ_STAMP(D, b, lane, 2)
     select_phase(D, b, lane, leaf_in, sh, P, tp);
     CCZ_STAMP(D, b, lane, 9)
+}
+
+// ------------------------------------------------------------------ compact evaluator boundary: logits -> priors of the legal moves
+// exp(log_softmax(logits))[legal ids] (net.py:202-205) for every board in one pass: the wave reads its 2086
+// logits once (coalesced), reduces max and sum on the DPP network, and writes only the <= 128 priors the
+// expansion will use, aligned with leaf_ids. Replaces two full [B,2086] torch passes (log_softmax, exp) and
+// turns the expansion's scattered 4-byte gather (one 64-B line per legal move) into one coalesced 512-B read.
+template <typename T>
+__global__ __launch_bounds__(64) void k_softmax_gather(Dev D, const T *logits)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    __shared__ float row[kNMoves + 2];
+    if (D.leaf_status[b] != CCZ_LEAF_EXPAND) return;
+    const int k = D.leaf_k[b];
+    const uint16_t *ids = D.leaf_ids + (size_t)b * kMaxLegal;
+    const int id0 = ids[lane], id1 = ids[64 + lane];
+    const T *src = logits + (size_t)b * kNMoves;
+    float mx = -__builtin_huge_valf();
+    for (int i = lane; i < kNMoves; i += 64) {
+        const float x = (float)src[i];
+        row[i] = x;
+        mx = fmaxf(mx, x);
+    }
+    mx = wave_max_f32(mx);
+    float sum = 0.0f;
+    for (int i = lane; i < kNMoves; i += 64) sum += __expf(row[i] - mx);
+    sum = wave_sum_f32(sum);
+    wave_sync();
+    float *out = D.prior128 + (size_t)b * kMaxLegal;
+    if (lane < k) out[lane] = __expf(row[id0] - mx) / sum;
+    if (64 + lane < k) out[64 + lane] = __expf(row[id1] - mx) / sum;
 }
 
 // ------------------------------------------------------------------ pi from root visits (mcts.py:162-166)

@@ -105,6 +105,33 @@ class SelfPlayEngine:
         check(self.L.ccz_step(self.h, self._stream(), _ptr(prob), _ptr(value), _ptr(self.leaf_input)))
         return self.leaf_input
 
+    def _check_logits(self, logits, value):
+        if logits.dtype not in (torch.float16, torch.float32) or value.dtype != torch.float32:
+            raise TypeError("logits must be float16/float32 and value float32")
+        if tuple(logits.shape) != (self.B, NMOVES) or value.numel() != self.B:
+            raise ValueError(f"logits must be [{self.B},{NMOVES}] and value [{self.B}]")
+        if not (logits.is_cuda and value.is_cuda and logits.is_contiguous() and value.is_contiguous()):
+            raise ValueError("logits/value must be contiguous device tensors")
+        return 1 if logits.dtype == torch.float16 else 0
+
+    def step_logits(self, logits: torch.Tensor, value: torch.Tensor) -> torch.Tensor:
+        """Compact boundary: policy-head LOGITS in; the engine takes exp(log_softmax) of the legal ids itself."""
+        self.gather_priors(logits, value)
+        return self.step_compact(value)
+
+    def expand_backup_logits(self, logits: torch.Tensor, value: torch.Tensor):
+        self.gather_priors(logits, value)
+        check(self.L.ccz_expand_backup_compact(self.h, self._stream(), _ptr(value)))
+
+    def gather_priors(self, logits: torch.Tensor, value: torch.Tensor):
+        """exp(log_softmax(logits)) of the pending leaf's legal ids -> the engine's [B,128] prior row."""
+        f16 = self._check_logits(logits, value)
+        check(self.L.ccz_gather_priors(self.h, self._stream(), _ptr(logits), f16))
+
+    def step_compact(self, value: torch.Tensor) -> torch.Tensor:
+        check(self.L.ccz_step_compact(self.h, self._stream(), _ptr(value), _ptr(self.leaf_input)))
+        return self.leaf_input
+
     # ------------------------------------------------------------------ once per move
     def finish_move(self, forced_moves=None, temps=None, keep_tree: bool = True) -> torch.Tensor:
         """Record pi, choose (or accept) the move, re-root, push, detect game end. Returns moves int32[B] (device)."""

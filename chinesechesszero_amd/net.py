@@ -138,7 +138,7 @@ class InferenceNet(nn.Module):
         return F.relu_(y)
 
     @torch.no_grad()
-    def forward(self, leaf_input: torch.Tensor):
+    def forward(self, leaf_input: torch.Tensor, return_logits: bool = False):
         B = leaf_input.shape[0]
         x = leaf_input.view(B, PLAYS * PIECES, 10, 9)
         if self.live_only:
@@ -152,9 +152,11 @@ class InferenceNet(nn.Module):
         pol = h[:, :PLAYS].reshape(B, PLAYS * 90)          # NCHW flatten order, as torch.reshape in net.py:98
         val = h[:, PLAYS:].reshape(B, PIECES * 90)
         logits = F.linear(pol, self.policy_fc_w, self.policy_fc_b)
-        prob = torch.exp(F.log_softmax(logits.float(), dim=1))
         v = F.relu_(F.linear(val, self.value_fc1_w, self.value_fc1_b))
         v = torch.tanh(F.linear(v, self.value_fc2_w, self.value_fc2_b).float()).view(B)
+        if return_logits:  # compact boundary: the engine applies exp(log_softmax) to the legal ids only
+            return logits.contiguous(), v.contiguous()
+        prob = torch.exp(F.log_softmax(logits.float(), dim=1))
         return prob.contiguous(), v.contiguous()
 
 
@@ -199,6 +201,21 @@ class PolicyValueNet:
 
     evaluate_leaves.batched = True
     evaluate_leaves.graph_safe = True   # static shapes, no host sync: may be captured into a hipGraph
+
+    @torch.no_grad()
+    def evaluate_leaves_logits(self, leaf_input: torch.Tensor):
+        """Same as :meth:`evaluate_leaves` but returns the policy head's logits ([B,2086], fp16 on the GPU): the
+        engine's ``ccz_step_logits`` turns them into priors of the legal moves only."""
+        if self._infer is None:
+            self.refresh_inference_copy()
+        if os.environ.get("CCZ_MIOPEN_FIND", "1") == "0":
+            return self._infer(leaf_input, return_logits=True)
+        with torch.backends.cudnn.flags(enabled=True, benchmark=True):
+            return self._infer(leaf_input, return_logits=True)
+
+    evaluate_leaves_logits.batched = True
+    evaluate_leaves_logits.graph_safe = True
+    evaluate_leaves_logits.returns_logits = True
 
     # ---- reference surface --------------------------------------------------------------------
     def policy_value(self, state_batch):

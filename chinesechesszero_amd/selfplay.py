@@ -36,7 +36,10 @@ class GraphedStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             prob, value = evaluator(engine.leaf_input)
-            engine.step(prob, value)
+            if getattr(evaluator, "returns_logits", False):
+                engine.step_logits(prob, value)
+            else:
+                engine.step(prob, value)
         # capture does not execute: nothing has been applied to the trees yet
 
     def replay(self):
@@ -68,7 +71,7 @@ class BatchedSelfPlay:
         e = self.engine
         leaf = e.select_leaves()
         prob, value = self.evaluator(leaf)
-        e.expand_backup(prob, value)
+        (e.expand_backup_logits if getattr(self.evaluator, "returns_logits", False) else e.expand_backup)(prob, value)
 
     def run_move(self, on_playout=None):
         """n_playout simulations then one move on every board. Returns the moves (device int32 [B]).
@@ -80,14 +83,17 @@ class BatchedSelfPlay:
         leaf = e.select_leaves()
         if self.use_graph and self._graph is None:
             self._graph = GraphedStep(e, self.evaluator)
+        logits = getattr(self.evaluator, "returns_logits", False)
+        step = e.step_logits if logits else e.step
+        last = e.expand_backup_logits if logits else e.expand_backup
         for i in range(self.n_playout):
             if i + 1 < self.n_playout:
                 if self._graph is not None:
                     self._graph.replay()
                 else:
-                    leaf = e.step(*self.evaluator(leaf))
+                    leaf = step(*self.evaluator(leaf))
             else:
-                e.expand_backup(*self.evaluator(leaf))
+                last(*self.evaluator(leaf))
             acc += 1
             if on_playout is not None and (acc >= interval or i == self.n_playout - 1):
                 try:

@@ -143,6 +143,15 @@ int ccz_expand_backup(ccz_engine *e, void *stream, const float *prob_dev, const 
 int ccz_step(ccz_engine *e, void *stream, const float *prob_dev, const float *value_dev,
              void *leaf_input_f16_dev);
 
+/* Compact evaluator boundary: the evaluator hands over the policy head's LOGITS (float32 or float16
+ * [B,2086], before log_softmax). ccz_gather_priors computes exp(log_softmax(logits)) for the pending leaf's
+ * legal ids only (net.py:202-205 use exactly those) in one pass per board into an engine-owned [B,128] row;
+ * ccz_step_compact / ccz_expand_backup_compact are ccz_step / ccz_expand_backup reading that row. Two full
+ * [B,2086] passes less on the evaluator side and no scattered prior gather inside the simulator kernel. */
+int ccz_gather_priors(ccz_engine *e, void *stream, const void *logits_dev, int32_t logits_f16);
+int ccz_step_compact(ccz_engine *e, void *stream, const float *value_dev, void *leaf_input_f16_dev);
+int ccz_expand_backup_compact(ccz_engine *e, void *stream, const float *value_dev);
+
 /* ---- once per move ------------------------------------------------------------------------ */
 /* Replaces MCTS.get_move_probs' tail (mcts.py:162-166), MCTS_AI.get_action's choice
  * (mcts.py:216-224), MCTS.update_with_move (mcts.py:168-178) and the per-move part of

@@ -148,3 +148,28 @@ def test_hipgraph_replay_equals_eager_launches():
     assert np.array_equal(res[False][1], res[True][1]) and np.array_equal(res[False][2], res[True][2])
     assert np.array_equal(res[False][3], res[True][3])
     print(f"40 sims x 8 boards: eager {res[False][4] * 1e3:.1f} ms, hipGraph {res[True][4] * 1e3:.1f} ms")
+
+
+def test_logits_boundary_gathers_the_same_priors():
+    """ccz_gather_priors + compact step == exp(log_softmax(logits))[legal ids] fed through the dense boundary."""
+    from chinesechesszero_amd.engine import SelfPlayEngine
+    dev = torch.device("cuda", 0)
+    B = 64
+    g = torch.Generator(device=dev).manual_seed(5)
+    for dtype in (torch.float32, torch.float16):
+        ea, eb = SelfPlayEngine(B, n_playout=16, seed=1), SelfPlayEngine(B, n_playout=16, seed=1)
+        la, lb = ea.select_leaves(), eb.select_leaves()
+        for it in range(12):
+            logits = (torch.randn((B, 2086), device=dev, generator=g) * 3).to(dtype).contiguous()
+            value = torch.tanh(torch.randn(B, device=dev, generator=g)).contiguous()
+            prob = torch.exp(torch.log_softmax(logits.float(), dim=1)).contiguous()
+            la = ea.step_logits(logits, value)
+            lb = eb.step(prob, value)
+            assert torch.equal(la, lb), it          # same leaves selected (priors agree far below PUCT gaps here)
+        ra, rb = ea.root_children(), eb.root_children()
+        assert np.array_equal(ra["k"], rb["k"]) and np.array_equal(ra["acts"], rb["acts"])
+        assert np.array_equal(ra["visits"], rb["visits"])
+        assert np.allclose(ra["prior"], rb["prior"], rtol=2e-6, atol=1e-12)
+        assert np.allclose(ra["q"], rb["q"], rtol=0, atol=1e-6)
+        ea.check_healthy()
+        eb.check_healthy()
