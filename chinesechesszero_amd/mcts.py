@@ -75,7 +75,7 @@ class MCTS:
         if getattr(policy_value_fn, "batched", False):
             self._batched = policy_value_fn
         elif owner is not None and hasattr(owner, "evaluate_leaves") and getattr(policy_value_fn, "__name__", "") == "policy_value_fn":
-            self._batched = owner.evaluate_leaves
+            self._batched = getattr(owner, "evaluate_leaves_logits", owner.evaluate_leaves)
         else:
             self._batched = None
 
@@ -122,6 +122,9 @@ class MCTS:
         leaf = e.select_leaves()
         if self._batched is not None:
             prob, value = self._batched(leaf)
+            if getattr(self._batched, "returns_logits", False):
+                e.expand_backup_logits(prob, value)
+                return
         else:
             info = e.leaf_info()
             sq, turn = _planes_to_squares(leaf[0].float().cpu().numpy())
@@ -144,6 +147,7 @@ class MCTS:
         acc = 0
         e = self._engine
         fused = self._batched is not None
+        logits = fused and getattr(self._batched, "returns_logits", False)
         if fused:
             # launch sequence of a move: select, (evaluator, fused step) x (n-1), evaluator, expand_backup
             leaf = e.select_leaves()
@@ -157,9 +161,9 @@ class MCTS:
                 if self._graph is not None:
                     self._graph.replay()
                 else:
-                    leaf = e.step(*self._batched(leaf))
+                    leaf = (e.step_logits if logits else e.step)(*self._batched(leaf))
             else:
-                e.expand_backup(*self._batched(leaf))
+                (e.expand_backup_logits if logits else e.expand_backup)(*self._batched(leaf))
             acc += 1
             if on_playout is not None and (acc >= interval or i == self.n_playout - 1):
                 try:
