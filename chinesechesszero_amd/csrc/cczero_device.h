@@ -433,7 +433,7 @@ __device__ inline GenResult gen_legal(const uint8_t *sq, int turn, GenScratch &S
     }
     CCZ_GSTAMP(sp, lane, 11)
     const int incl = wave_incl_scan(cnt, lane);
-    int npseudo = __shfl(incl, 63);
+    int npseudo = __builtin_amdgcn_readlane(incl, 63);
     const int excl = incl - cnt;
     if (npseudo > kPseudoCap) { R.overflow = true; npseudo = kPseudoCap; }
     for (int i = 0; i < cnt; ++i)
@@ -459,8 +459,8 @@ __device__ inline GenResult gen_legal(const uint8_t *sq, int turn, GenScratch &S
     const uint32_t w1 = lane < 2 ? S.mask[64 + lane] : 0u;
     const int c0 = __popc(w0), c1 = __popc(w1);
     const int incl0 = wave_incl_scan(c0, lane);
-    const int total0 = __shfl(incl0, 63);
-    const int c64 = __shfl(c1, 0), c65 = __shfl(c1, 1);
+    const int total0 = __builtin_amdgcn_readlane(incl0, 63);
+    const int c64 = __builtin_amdgcn_readlane(c1, 0), c65 = __builtin_amdgcn_readlane(c1, 1);
     R.n_legal = total0 + c64 + c65;
     if (R.n_legal > kMaxLegal) R.overflow = true;
     if (ids_out) {

@@ -409,7 +409,7 @@ __device__ inline TopPatch expand_backup_phase(const Dev &D, int b, int lane, co
     const size_t base = ((size_t)b * 2 + half) * (size_t)D.cap;
     NodeA *A = D.nodeA + base;
     uint32_t *Bn = D.nodeB + base;
-    const int leaf = __shfl(pj, d < 64 ? d : 0);
+    const int leaf = __builtin_amdgcn_readlane(pj, __builtin_amdgcn_readfirstlane(d < 64 ? d : 0));
     float v;
     if (status == CCZ_LEAF_EXPAND) {
         // Node.expand (mcts.py:31-39): one child per legal id, ascending id order
@@ -432,7 +432,7 @@ __device__ inline TopPatch expand_backup_phase(const Dev &D, int b, int lane, co
             tp.kid_expanded = d == 1;
             tp.n0 = n0;
             tp.k = k;
-            tp.first_id = __shfl(id0, 0);
+            tp.first_id = __builtin_amdgcn_readlane(id0, 0);
             if (lane == 0) {
                 const int leaf0 = d < 64 ? leaf : path[d];
                 A[leaf0].fc = n0;
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(64) void k_finish_move(Dev D, const int32_t *forced
             int nc = 0;
             if (valid) { rec = NA[i]; nc = (int)(NB[i] >> 16); }
             const int incl = wave_incl_scan(nc, lane);
-            const int total = __shfl(incl, 63);
+            const int total = __builtin_amdgcn_readlane(incl, 63);
             if (n_new + total > D.cap) { fail = true; break; }
             const int dst = n_new + incl - nc;
             s_cnt[lane] = nc;
