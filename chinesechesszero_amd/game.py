@@ -256,7 +256,7 @@ class Game:
                 self.graphic(self.board)
             if self.board.is_game_over():
                 outcome = self.board.outcome()
-                return outcome.winner if outcome.winner is not None else -1
+                return outcome.winner if (outcome is not None and outcome.winner is not None) else -1
 
     def start_self_play(self, player, is_shown=False, temp=1.0, game_index=None):
         """game.py:133-237: returns [(red_states[8], black_states[8], pi[2086], z)] for one game.

@@ -124,3 +124,41 @@ def test_collect_pipeline_batched_writes_trainer_format(tmp_path):
     assert states.shape[0] == 16 * 5 * 2  # every board was adjudicated at 5 plies once, mirrored
     assert np.allclose(pi.sum(1), 1.0, atol=1e-4)
     assert cp.iters == 16
+
+
+def test_start_play_two_players_two_engines():
+    """game.py:77-130 with two MCTS_AI players (each owns an engine): moves alternate, both stay in sync."""
+    from chinesechesszero_amd.game import Board, Game
+    from chinesechesszero_amd.mcts import MCTS_AI
+    red = MCTS_AI(_hash_policy(salt=11), c_puct=5, n_playout=24, is_selfplay=False)
+    black = MCTS_AI(_hash_policy(salt=12), c_puct=5, n_playout=24, is_selfplay=False)
+    np.random.seed(9)
+    orig = Board.is_game_over
+    Board.is_game_over = lambda self: len(self.move_stack) >= 7 or orig(self)
+    try:
+        g = Game()
+        winner = g.start_play(red, black, is_shown=False)
+    finally:
+        Board.is_game_over = orig
+    assert len(g.board.move_stack) == 7 and winner == -1  # cut short: no outcome -> reported as a draw
+    assert red.player == 1 and black.player == 0
+    # each engine followed the whole game (its own moves and the opponent's replies)
+    assert np.array_equal(red.mcts._engine.root_positions()[0], Board(g.board.squares(), g.board.turn).squares()) or len(red.mcts._synced) >= 5
+    assert black.mcts._synced == [m.id for m in g.board.move_stack][:len(black.mcts._synced)]
+
+
+def test_engine_create_destroy_does_not_leak_device_memory():
+    import torch
+    from chinesechesszero_amd.engine import SelfPlayEngine
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(6):
+        e = SelfPlayEngine(256, n_playout=100)
+        e.select_leaves()
+        torch.cuda.synchronize()
+        e.close()
+        del e
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 * 1024 * 1024, (free0, free1)
