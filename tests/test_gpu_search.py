@@ -163,3 +163,108 @@ def test_device_sampler_distribution():
     assert np.all(np.abs(counts - expect) < 6 * np.sqrt(expect) + 6)
     assert len(np.unique(moves)) > 20
     e.check_healthy()
+
+
+def _legal_count(sq, turn):
+    from oracle import OracleBoard
+    return len(OracleBoard.from_array(sq, turn, 0).legal_ids())
+
+
+def test_wide_nodes_more_than_64_children():
+    """Positions with > 64 legal moves: second 64-lane pass of select / expand / sampling, big re-root blocks."""
+    from gpu_harness import Lockstep
+    from golden_cases import sq as S
+    from oracle import OracleBoard
+    import oracle
+    b = np.zeros(90, np.uint8)
+    for name, pc in {"e1": 7, "a2": 3, "i7": 3, "b4": 2, "h5": 2, "c3": 4, "g6": 4, "a6": 1, "c7": 1, "e6": 1, "g7": 1, "i6": 1,
+                     "d0": 6, "f0": 6, "c0": 5, "g0": 5, "d9": 15, "e8": 14, "a9": 11}.items():
+        b[S(name)] = pc
+    k0 = _legal_count(b, 1)
+    assert k0 > 64, k0
+    B = 3
+    e = _engine(B, 160, seed=8)
+    boards = []
+    for i in range(B):
+        e.set_position(i, b, 1, 0)
+        boards.append(OracleBoard.from_array(b, 1, 0))
+    ls = Lockstep(e, boards, kind="hash_sharp", salts=[31, 32, 33])
+    for ply in range(2):
+        ls.run_fused(160, check_leaf=True)
+        rc = ls.compare_roots()
+        if ply == 0:
+            assert rc["k"][0] == k0
+            # device sampler over k > 64 children agrees with its CPU twin
+            pi = e.root_pi(temps=1.0)
+            moves = e.finish_move(temps=np.ones(B)).cpu().numpy()
+            for i in range(B):
+                k = int(rc["k"][i])
+                want = oracle.det_pi(rc["visits"][i][:k], 1.0)
+                assert np.array_equal(pi[i][:k].view(np.uint64), want.view(np.uint64))
+                idx, _ = oracle.det_sample(8, i, 0, want, 0.25, 0.2)
+                assert moves[i] == rc["acts"][i][idx]
+                ls.mcts[i].update_with_move(int(moves[i]))
+                ls.boards[i].push_id(int(moves[i]))
+    ls.compare_roots()
+    e.check_healthy()
+
+
+def test_deep_paths_beyond_one_wave():
+    """Selection paths deeper than 64 plies: chunked path replay, backup lanes wrapping, repetition / sixty-move leaves."""
+    import torch
+    from gpu_harness import planes_to_squares
+    from golden_cases import sq as S
+    from oracle import OracleBoard, OracleMCTS
+    from oracle.evaluators import position_hash
+    b = np.zeros(90, np.uint8)
+    # kings + five pawns each: pawn pushes are irreversible, so long lines do not die of repetition early
+    for name, pc in {"d0": 7, "a3": 1, "c3": 1, "e3": 1, "g3": 1, "i3": 1, "f9": 15, "a6": 9, "c6": 9, "e6": 9, "g6": 9, "i6": 9}.items():
+        b[S(name)] = pc
+    B, n = 2, 1000
+    e = _engine(B, n, seed=2)
+    boards, mcts = [], []
+    for i in range(B):
+        e.set_position(i, b, 1 - i, 0)
+        boards.append(OracleBoard.from_array(b, 1 - i, 0))
+        mcts.append(OracleMCTS(None, c_puct=5, n_playout=0))
+
+    def evaluate(sq, turn, salt):
+        """prior mass 0.97 on one hash-chosen legal move: PUCT digs one long principal line"""
+        ob = OracleBoard.from_array(sq, int(turn), 0)
+        ids = ob.legal_ids()
+        P = np.full(2086, 0.0, np.float32)
+        if ids:
+            P[ids] = np.float32(0.03 / len(ids))
+            P[ids[int(position_hash(sq[None, :], np.array([turn]), salt)[0] % np.uint64(len(ids)))]] = np.float32(0.97)
+        return P, np.float32(0.0)
+
+    e.select_leaves()
+    for it in range(n):
+        planes = e.leaf_input.float().cpu().numpy()
+        info = e.leaf_info()
+        sq, turn = planes_to_squares(planes)
+        P = np.zeros((B, 2086), np.float32)
+        V = np.zeros(B, np.float32)
+        for i in range(B):
+            leaf, depth = mcts[i].select(boards[i])
+            assert depth == info["depth"][i] and np.array_equal(leaf.squares(), sq[i]), (it, i, depth, info["depth"][i])
+            end, tie = leaf.is_game_over(), leaf.is_tie()
+            assert info["status"][i] == (0 if (not end and not tie) else (1 if (end and tie) else 2)), (it, i)
+            P[i], V[i] = evaluate(sq[i], turn[i], 5 + i)
+            ids = leaf.legal_ids()
+            mcts[i].expand_backup(leaf, ids, P[i][ids], V[i])
+        tp, tv = torch.from_numpy(P).to(e.device), torch.from_numpy(V).to(e.device)
+        if it + 1 < n:
+            e.step(tp, tv)
+        else:
+            e.expand_backup(tp, tv)
+    st = e.stats()
+    assert st["depth_peak"] >= 64, st["depth_peak"]
+    assert st["terminal_leaves"] > 0
+    rc = e.root_children()
+    for i in range(B):
+        acts, visits, q, prior = mcts[i].root_children()
+        k = len(acts)
+        assert np.array_equal(rc["visits"][i][:k], visits)
+        assert np.array_equal(rc["q"][i][:k].view(np.uint32), q.view(np.uint32))
+    e.check_healthy()
