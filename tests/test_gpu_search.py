@@ -268,3 +268,64 @@ def test_deep_paths_beyond_one_wave():
         assert np.array_equal(rc["visits"][i][:k], visits)
         assert np.array_equal(rc["q"][i][:k].view(np.uint32), q.view(np.uint32))
     e.check_healthy()
+
+
+def test_long_quiet_history_chain_and_sixty_move_rule():
+    """> 64 plies without a capture: the history-chain tail beyond the prefetched 64 keys, repetition counting over
+    it, and the sixty-move rule ending the game exactly when the oracle says so."""
+    from gpu_harness import Lockstep
+    from oracle import OracleBoard
+    rs = np.random.RandomState(21)
+    B = 2
+    e = _engine(B, 60, seed=4)
+    boards = [OracleBoard() for _ in range(B)]
+    # a quiet random walk: no captures, never ending the game, 100 plies
+    for ply in range(100):
+        forced = []
+        for b in range(B):
+            ob = boards[b]
+            cands = []
+            for m in ob.legal_ids():
+                c = ob.copy()
+                was = c.halfmove
+                c.push_id(m)
+                if c.halfmove == was + 1 and not c.is_game_over():
+                    cands.append(m)
+            m = cands[rs.randint(len(cands))]
+            forced.append(m)
+            ob.push_id(m)
+        e.finish_move(forced_moves=np.array(forced, np.int32), keep_tree=False)
+    assert all(ob.halfmove == 100 for ob in boards)
+    assert np.array_equal(e.root_positions(), np.stack([ob.squares() for ob in boards]))
+    ls = Lockstep(e, boards, kind="hash_sharp", salts=[61, 62])
+    ls.run_fused(60, check_leaf=True)      # leaf status (repetition over the long chain) checked at every step
+    ls.compare_roots()
+    # keep playing quiet moves: the engine must flag the game over exactly at the oracle's sixty-move point
+    over_at = [None] * B
+    for ply in range(30):
+        forced = np.full(B, -1, np.int32)
+        for b in range(B):
+            ob = boards[b]
+            if over_at[b] is not None:
+                continue
+            cands = [m for m in ob.legal_ids() if ob.squares()[oracle_to(m)] == 0]
+            m = cands[rs.randint(len(cands))]
+            forced[b] = m
+            ob.push_id(m)
+            ls.mcts[b].update_with_move(-1)
+            if ob.is_game_over():
+                over_at[b] = ob.halfmove
+        e.finish_move(forced_moves=forced, keep_tree=False)
+        st = e.game_status()
+        for b in range(B):
+            assert bool(st["over"][b]) == (over_at[b] is not None), (ply, b, st["over"][b], over_at[b])
+        if all(x is not None for x in over_at):
+            break
+    assert all(x is not None and x <= 120 for x in over_at)
+    assert list(e.game_status()["winner"]) == [-1 if boards[b].outcome().winner is None else int(boards[b].outcome().winner) for b in range(B)]
+    e.check_healthy()
+
+
+def oracle_to(mid):
+    import oracle
+    return oracle.lib().xq_move_to(int(mid))
