@@ -56,6 +56,7 @@ extern "C" {
 #define CCZ_LEAF_EXPAND 0 /* non-terminal: children are created from the evaluator's priors */
 #define CCZ_LEAF_DRAW 1   /* game over and is_tie(): leaf value 0.0   (mcts.py:120-122)   */
 #define CCZ_LEAF_LOSS 2   /* side to move has no legal move: leaf value -1.0 (mcts.py:123-126) */
+#define CCZ_LEAF_NONE 3   /* no pending leaf: board finished, leaf already backed up, or nothing selected yet */
 
 typedef struct ccz_engine ccz_engine;
 
@@ -159,10 +160,14 @@ int ccz_expand_backup_compact(ccz_engine *e, void *stream, const float *value_de
  * record (position, turn, pi), choose the move, re-root the tree on the chosen child (subtree
  * kept), make the move on the root position, detect the end of the game and its winner.
  *   forced_moves_dev: int32 [B] or NULL. entry >= 0: play that move id (host-exact numpy sampling
- *     or match play); entry < 0 or NULL: sample on the device stream Philox(seed, board id).
+ *     or match play); a forced move that is not a child of the root (root never searched, or an
+ *     opponent's reply the tree never saw) gives a fresh root, as update_with_move does
+ *     (mcts.py:176-178). entry < 0 or NULL: sample on the device stream Philox(seed, board id).
  *   temps_dev: float64 [B] or NULL (NULL: schedule of game.py:159 from cfg.temp).
  *   moves_out_dev: int32 [B] or NULL, receives the move played.
- *   keep_tree: 1 = self-play tree reuse (mcts.py:222-224); 0 = discard (mcts.py:228-229). */
+ *   keep_tree: 1 = self-play tree reuse (mcts.py:222-224); 0 = discard (mcts.py:228-229).
+ * All live trees move to the other half of their node pool in this call (one flip for every board),
+ * which is what lets the simulation kernel request a root's children before any load has returned. */
 int ccz_finish_move(ccz_engine *e, void *stream, const int32_t *forced_moves_dev,
                     const double *temps_dev, int32_t *moves_out_dev, int32_t keep_tree);
 
@@ -181,7 +186,7 @@ int ccz_game_status(ccz_engine *e, void *stream, uint8_t *over_host, int8_t *win
                     int32_t *plies_host, uint8_t *turn_host);
 /* root positions (syncs): sq_host uint8 [B*96] */
 int ccz_root_positions(ccz_engine *e, void *stream, uint8_t *sq_host);
-/* leaf bookkeeping of the last ccz_select_leaves (syncs; tests): status uint8[B], k int32[B],
+/* leaf bookkeeping of the last ccz_select_leaves / ccz_step (syncs; tests): status uint8[B] (CCZ_LEAF_*), k int32[B],
  * ids uint16[B*128], depth int32[B]; any pointer may be NULL. */
 int ccz_leaf_info(ccz_engine *e, void *stream, uint8_t *status_host, int32_t *k_host,
                   uint16_t *ids_host, int32_t *depth_host);
