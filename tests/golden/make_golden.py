@@ -88,6 +88,21 @@ def endgame_capture_to_bare():
     return b
 
 
+def wide_open_80_moves():
+    b = _empty()
+    for name, pc in {"e1": 7, "a2": 3, "i7": 3, "b4": 2, "h5": 2, "c3": 4, "g6": 4, "a6": 1, "c7": 1, "e6": 1, "g7": 1, "i6": 1,
+                     "d0": 6, "f0": 6, "c0": 5, "g0": 5, "d9": 15, "e8": 14, "a9": 11}.items():
+        b[sq(name)] = pc
+    return b
+
+
+def pawns_and_kings():
+    b = _empty()
+    for name, pc in {"d0": 7, "a3": 1, "c3": 1, "e3": 1, "g3": 1, "i3": 1, "f9": 15, "a6": 9, "c6": 9, "e6": 9, "g6": 9, "i6": 9}.items():
+        b[sq(name)] = pc
+    return b
+
+
 def endgame_rook_knight():
     b = _empty()
     b[sq("e0")] = 7
@@ -114,9 +129,12 @@ CASES = [
     dict(name="bare_n150", start="capture_to_bare", turn=1, halfmove=3, ev="hash", n=150, plies=2, temps=[1.0, 1.0], seed=9, selfplay=True),
     dict(name="rookknight_black_n250", start="rook_knight", turn=0, halfmove=100, ev="hash_sharp", n=250, plies=4, temps=[1.0, 0.5, 1.0, 0.5], seed=10, selfplay=True),
     dict(name="rookknight_uniform_n120", start="rook_knight", turn=1, halfmove=0, ev="uniform", n=120, plies=3, temps=[1.0, 1.0, 1.0], seed=11, selfplay=True),
+    dict(name="wide80_sharp_n300", start="wide80", turn=1, halfmove=0, ev="hash_sharp", n=300, plies=2, temps=[1.0, 0.5], seed=12, selfplay=True),
+    dict(name="pawns_black_n400", start="pawns", turn=0, halfmove=0, ev="hash_sharp", n=400, plies=3, temps=[1.0, 1.0, 0.5], seed=13, selfplay=True),
 ]
 
-STARTS = {"two_rooks": endgame_two_rooks, "capture_to_bare": endgame_capture_to_bare, "rook_knight": endgame_rook_knight}
+STARTS = {"two_rooks": endgame_two_rooks, "capture_to_bare": endgame_capture_to_bare, "rook_knight": endgame_rook_knight,
+          "wide80": wide_open_80_moves, "pawns": pawns_and_kings}
 
 
 def make_board(case):

@@ -17,6 +17,9 @@ STARTS = {
     "two_rooks": _place({"d0": 7, "a7": 3, "b8": 3, "e9": 15}),
     "capture_to_bare": _place({"e0": 7, "d0": 6, "e1": 9, "d9": 15, "c9": 13}),
     "rook_knight": _place({"e0": 7, "e1": 6, "c2": 4, "h4": 3, "d9": 15, "e8": 14, "a5": 11, "g6": 9}),
+    "wide80": _place({"e1": 7, "a2": 3, "i7": 3, "b4": 2, "h5": 2, "c3": 4, "g6": 4, "a6": 1, "c7": 1, "e6": 1, "g7": 1, "i6": 1,
+                      "d0": 6, "f0": 6, "c0": 5, "g0": 5, "d9": 15, "e8": 14, "a9": 11}),
+    "pawns": _place({"d0": 7, "a3": 1, "c3": 1, "e3": 1, "g3": 1, "i3": 1, "f9": 15, "a6": 9, "c6": 9, "e6": 9, "g6": 9, "i6": 9}),
 }
 
 START_ROWS = ["RNBAKABNR", ".........", ".C.....C.", "P.P.P.P.P", ".........",

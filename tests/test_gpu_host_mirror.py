@@ -162,3 +162,30 @@ def test_engine_create_destroy_does_not_leak_device_memory():
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 * 1024 * 1024, (free0, free1)
+
+
+def test_collect_pipeline_single_board_host_path(tmp_path):
+    """collect.py:133-176 in its own control flow: one self-play game through Game/MCTS_AI on a B=1 engine,
+    preprocess + flip_data on the host, rows appended in the trainer's format."""
+    from chinesechesszero_amd.collect import CollectPipeline
+    from chinesechesszero_amd.game import Board
+    from chinesechesszero_amd.tools import flip_map
+    cp = CollectPipeline(init_model=None, n_boards=1, n_playout=12, data_dir=str(tmp_path), num_channels=16, resblocks_num=1)
+    orig = Board.is_game_over
+    Board.is_game_over = lambda self: len(self.move_stack) >= 5 or orig(self)
+    np.random.seed(4)
+    try:
+        iters = cp.collect_data()
+    finally:
+        Board.is_game_over = orig
+    assert iters == 1 and cp.episode_len == 5
+    states = np.load(tmp_path / "states.npy")
+    pi = np.load(tmp_path / "mcts.npy")
+    z = np.load(tmp_path / "winners.npy")
+    assert states.shape == (10, 17, 7, 10, 9) and pi.shape == (10, 2086) and z.shape == (10,)
+    fm = flip_map()
+    for t in range(5):
+        assert np.array_equal(states[5 + t], states[t][:, :, :, ::-1])       # np.flip(axis=2) of every group
+        assert np.allclose(pi[5 + t], pi[t][fm]) and z[5 + t] == z[t]
+        assert np.all(states[t][16] == (1 if t % 2 == 0 else 0))               # side-to-move plane (fixed mode)
+    assert np.allclose(pi.sum(1), 1.0, atol=1e-6)

@@ -64,7 +64,7 @@ def _make_eval(name):
     return f
 
 
-@pytest.mark.parametrize("idx", range(11))
+@pytest.mark.parametrize("idx", range(13))
 def test_search_trace_matches_reference(golden, idx):
     """Visit counts, Q, priors bit-exact; pi to 1e-12; sampled moves identical under np.random.seed."""
     case = golden["meta"]["cases"][idx]
