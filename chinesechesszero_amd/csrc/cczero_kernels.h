@@ -405,6 +405,7 @@ __device__ inline TopPatch expand_backup_phase(const Dev &D, int b, int lane, co
     if (COMPACT) { cp0 = prob[(size_t)b * kMaxLegal + lane]; cp1 = prob[(size_t)b * kMaxLegal + 64 + lane]; }
     const int pj = path[lane < D.maxd ? lane : 0];
     if (status == CCZ_LEAF_SKIP) return tp;
+    CCZ_STAMP(D, b, lane, 8)
     BoardMeta *mp = D.meta + b;
     const size_t base = ((size_t)b * 2 + half) * (size_t)D.cap;
     NodeA *A = D.nodeA + base;
@@ -453,6 +454,7 @@ __device__ inline TopPatch expand_backup_phase(const Dev &D, int b, int lane, co
         D.leaf_status[b] = CCZ_LEAF_SKIP; // consumed: a repeated call must not back the same leaf up twice
     }
     // Node.update_recursive(-leaf_value) (mcts.py:73-78,129): leaf gets -v, its parent +v, ...
+    CCZ_STAMP(D, b, lane, 15)
     int myN = 0;
     float myQ = 0.0f;
     for (int j = lane; j <= d; j += 64) {

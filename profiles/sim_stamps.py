@@ -37,14 +37,15 @@ for _ in range(n // 2):
     leaf = e.step(p, v)
 L = _lib.lib()
 L.ccz_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-names = ["prefetch+expand+backup", "fence", "root->LDS", "descent", "replay(make-move)", "gen A: ballots, occupancy words", "gen B: pseudo-moves",
+names = ["kernarg + first load round (meta, leaf, root, kids, chain)", "expand: prior row + child stores", "backup: path node loads + N/Q stores", "fence", "root->LDS", "descent", "replay(make-move)", "gen A: ballots, occupancy words", "gen B: pseudo-moves",
          "gen: scan+compact", "gen C: king safety+id", "gen D: mask->ids", "repetition+status", "leaf bookkeeping", "encode+store"]
-idx = [0, 1, 2, 3, 4, 5, 10, 11, 12, 13, 14, 6, 7, 9]
+idx = [0, 8, 15, 1, 2, 3, 4, 5, 10, 11, 12, 13, 14, 6, 7, 9]
 acc = np.zeros(len(names))
 tot = 0.0
+compact = os.environ.get("CCZ_DENSE", "0") != "1"   # default: the compact prior boundary, as bench.py uses it
 for it in range(20):
     p, v = ev(leaf)
-    leaf = e.step(p, v)
+    leaf = e.step_logits(torch.log(p).contiguous(), v) if compact else e.step(p, v)
     st = np.zeros((B, 16), np.uint64)
     L.ccz_debug_stamps(e.h, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), C.c_void_p(st.ctypes.data))
     t = st[:, idx].astype(np.int64)
