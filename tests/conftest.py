@@ -10,7 +10,17 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _ensure_built():
+    """A fresh checkout has no libcczero.so (built artefacts are git-ignored): build it once if hipcc is here."""
+    so = os.path.join(ROOT, "chinesechesszero_amd", "libcczero.so")
+    if not os.path.exists(so) and os.path.exists("/opt/rocm/bin/hipcc"):
+        sys.path.insert(0, ROOT)
+        import __graft_entry__
+        __graft_entry__.build()
+
+
 def pytest_configure(config):
+    _ensure_built()
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long-running CPU check")
 
