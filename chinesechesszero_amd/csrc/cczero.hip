@@ -128,7 +128,7 @@ int ccz_create(const ccz_config *cfg, ccz_engine **out)
     if (d.maxd > kMaxDepth) { delete e; return fail(-1, "ccz_create: max_depth %d exceeds the compiled limit %d", d.maxd, kMaxDepth); }
     if (d.maxd < 64) { delete e; return fail(-1, "ccz_create: max_depth must be >= 64"); }
     d.max_plies = cfg->max_plies > 0 ? cfg->max_plies : 2048;
-    d.pi_cap = d.max_plies * 48;
+    d.pi_cap = d.max_plies * 80; // sparse pi entries: opening positions have 44 legal moves, open middlegames 50-70
     d.c_puct = cfg->c_puct;
     d.eps = (double)cfg->eps;
     d.alpha = (double)cfg->alpha;
