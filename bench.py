@@ -180,7 +180,7 @@ def main():
         sp.finish_move()
         st = e.game_status()
         if st["over"].any() or world > 1:
-            s, p, z = e.harvest() if st["over"].any() else (e.leaf_input[:0], torch.empty((0, 2086), device=dev), torch.empty((0,), device=dev))
+            s, p, z = e.harvest(max_rows=1 << 21) if st["over"].any() else (e.leaf_input[:0], torch.empty((0, 2086), device=dev), torch.empty((0,), device=dev))
             if gather is not None:
                 s, p, z = gather.gather(s.to(xdev), p.to(xdev), z.to(xdev))
             if trainer is not None and s.shape[0]:

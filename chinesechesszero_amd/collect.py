@@ -171,10 +171,15 @@ class CollectPipeline:
             st = self.selfplay.engine.game_status()
             done = int(st["over"].sum())
             if done or gatherer is not None:
-                s, p, z = self.selfplay.harvest()
-                if gatherer is not None:
-                    s, p, z = gatherer.gather(s, p, z)
-                self.sink.append(s, p, z, games=done)
+                chunks = list(self.selfplay.harvest_chunks()) if done else []
+                if gatherer is not None:  # every rank issues the same number of collectives: pad with empty chunks
+                    n_chunks = torch.tensor([len(chunks)], device=self.selfplay.engine.device)
+                    torch.distributed.all_reduce(n_chunks, op=torch.distributed.ReduceOp.MAX)
+                    e = self.selfplay.engine
+                    empty = (e.leaf_input[:0], torch.empty((0, 2086), device=e.device), torch.empty((0,), device=e.device))
+                    chunks = [gatherer.gather(*(chunks[i] if i < len(chunks) else empty)) for i in range(int(n_chunks.item()))]
+                for i, (s, p, z) in enumerate(chunks):
+                    self.sink.append(s, p, z, games=done if i == 0 else 0)
         self.selfplay.engine.check_healthy()
         self.sink.flush()
         self.iters = self.sink.games

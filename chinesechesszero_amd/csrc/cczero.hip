@@ -423,20 +423,23 @@ int ccz_harvest(ccz_engine *e, void *stream, void *states_f16_dev, float *pi_dev
     std::vector<long long> base((size_t)B, -1);
     std::vector<uint8_t> mask((size_t)B, 0);
     int64_t rows = 0;
+    bool any = false;
+    // finished boards are taken in index order while their rows fit the caller's buffers; the rest stay
+    // finished and are picked up by the next call (many boards can reach the ply cap in the same move)
     for (int b = 0; b < B; ++b)
         if (e->h_meta[b].over) {
+            const int64_t add = (int64_t)e->h_meta[b].ply * mul;
+            if (rows + add > capacity_rows) {
+                if (!any) return fail(-5, "ccz_harvest: the first finished game needs %lld rows, capacity %lld", (long long)add, (long long)capacity_rows);
+                break;
+            }
             base[b] = rows;
             mask[b] = 1;
-            rows += (int64_t)e->h_meta[b].ply * mul;
+            any = true;
+            rows += add;
         }
     if (rows_host) *rows_host = rows;
-    if (rows == 0) {
-        // finished games without records (cannot happen in self-play) are simply restarted
-        bool any = false;
-        for (int b = 0; b < B; ++b) any = any || mask[b];
-        if (!any) return 0;
-    }
-    if (rows > capacity_rows) return fail(-5, "ccz_harvest: %lld rows needed, capacity %lld", (long long)rows, (long long)capacity_rows);
+    if (!any) return 0;
     if (rows > 0 && (!states_f16_dev || !pi_dev || !z_dev)) return fail(-1, "ccz_harvest: null output buffer");
     if (rows > 0) {
         HIP_TRY(hipMemcpyAsync(e->st_rowbase, base.data(), (size_t)B * 8, hipMemcpyHostToDevice, s));

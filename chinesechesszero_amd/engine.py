@@ -199,19 +199,46 @@ class SelfPlayEngine:
             raise CczError(f"engine error flags {e}: " + "; ".join(msgs))
 
     # ------------------------------------------------------------------ training tuples
-    def harvest(self):
-        """Tuples of all finished games -> (states fp16 [R,17,7,10,9], pi f32 [R,2086], z f32 [R]); restarts those boards."""
+    def harvest_chunks(self, max_rows: int = 1 << 19):
+        """Yield (states fp16 [R,17,7,10,9], pi f32 [R,2086], z f32 [R]) chunks of at most ``max_rows`` rows until no
+        finished game is left; harvested boards restart. (2^19 rows = 15.6 GB: many boards can reach the ply cap in
+        the same move, so the rows of one harvest are bounded by the buffer, not by the number of finished games.)"""
+        while True:
+            rows = C.c_int64(0)
+            check(self.L.ccz_harvest_rows(self.h, self._stream(), C.byref(rows)))
+            total = int(rows.value)
+            if total == 0:
+                return
+            cap = min(total, int(max_rows))
+            while True:
+                states = torch.empty((cap, 17, 7, 10, 9), dtype=torch.float16, device=self.device)
+                pi = torch.empty((cap, NMOVES), dtype=torch.float32, device=self.device)
+                z = torch.empty((cap,), dtype=torch.float32, device=self.device)
+                got = C.c_int64(0)
+                rc = self.L.ccz_harvest(self.h, self._stream(), _ptr(states), _ptr(pi), _ptr(z), cap, C.byref(got))
+                if rc == -5 and cap < total:  # one single game is longer than the chunk: grow to fit it
+                    cap = min(total, cap * 2)
+                    continue
+                check(rc)
+                break
+            R = int(got.value)
+            yield states[:R], pi[:R], z[:R]
+
+    def harvest(self, max_rows: int = 1 << 19):
+        """Tuples of all finished games -> (states fp16 [R,17,7,10,9], pi f32 [R,2086], z f32 [R]); restarts those
+        boards. Raises if more than ``max_rows`` rows are pending: iterate :meth:`harvest_chunks` instead."""
         rows = C.c_int64(0)
         check(self.L.ccz_harvest_rows(self.h, self._stream(), C.byref(rows)))
-        R = int(rows.value)
-        states = torch.empty((R, 17, 7, 10, 9), dtype=torch.float16, device=self.device)
-        pi = torch.empty((R, NMOVES), dtype=torch.float32, device=self.device)
-        z = torch.empty((R,), dtype=torch.float32, device=self.device)
-        got = C.c_int64(0)
-        check(self.L.ccz_harvest(self.h, self._stream(), _ptr(states) if R else None, _ptr(pi) if R else None,
-                                 _ptr(z) if R else None, R, C.byref(got)))
-        assert got.value == R
-        return states, pi, z
+        if rows.value > max_rows:
+            raise CczError(f"{rows.value} rows pending (> {max_rows}): use harvest_chunks() to bound device memory")
+        chunks = list(self.harvest_chunks(max_rows))
+        if not chunks:
+            return (torch.empty((0, 17, 7, 10, 9), dtype=torch.float16, device=self.device),
+                    torch.empty((0, NMOVES), dtype=torch.float32, device=self.device),
+                    torch.empty((0,), dtype=torch.float32, device=self.device))
+        if len(chunks) == 1:
+            return chunks[0]
+        return tuple(torch.cat([c[i] for c in chunks]) for i in range(3))
 
 
 # ---------------------------------------------------------------------- stateless batch rules

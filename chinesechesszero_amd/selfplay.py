@@ -129,3 +129,6 @@ class BatchedSelfPlay:
 
     def harvest(self):
         return self.engine.harvest()
+
+    def harvest_chunks(self, max_rows: int = 1 << 19):
+        return self.engine.harvest_chunks(max_rows)

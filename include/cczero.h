@@ -197,7 +197,8 @@ int ccz_harvest_rows(ccz_engine *e, void *stream, int64_t *rows_host);
 /* Replaces game.py:208-237 (z assignment) + collect.py:64-131 (preprocess, flip_data) for every
  * finished board: writes rows (state fp16 [17,7,10,9], pi float32 [2086], z float32) into the
  * caller's device buffers, game by game (samples, then their mirror images), then starts a new
- * game on those boards. capacity_rows must be >= ccz_harvest_rows. Syncs. */
+ * game on those boards. Finished boards are taken in index order while their rows fit capacity_rows;
+ * the others stay finished for the next call (loop until ccz_harvest_rows reports 0). Syncs. */
 int ccz_harvest(ccz_engine *e, void *stream, void *states_f16_dev, float *pi_dev, float *z_dev,
                 int64_t capacity_rows, int64_t *rows_host);
 

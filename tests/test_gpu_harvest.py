@@ -139,3 +139,34 @@ def test_staggered_restart_and_stats():
     assert stats["games"] >= 32 * 2 and rows >= 32 * 2 * 10 * 2
     assert stats["truncated_games"] == stats["games"]
     sp.engine.check_healthy()
+
+
+def test_harvest_in_chunks_bounded_by_capacity():
+    """All boards reach the ply cap in the same move: the rows come out in capacity-bounded chunks, nothing lost."""
+    from chinesechesszero_amd._lib import CczError
+    from chinesechesszero_amd.selfplay import BatchedSelfPlay
+    from chinesechesszero_amd.net import uniform_evaluator
+    B, cap = 24, 6
+    sp = BatchedSelfPlay(uniform_evaluator, B, n_playout=4, seed=9, max_plies=cap)
+    for _ in range(cap + 1):
+        sp.run_move()
+    st = sp.engine.game_status()
+    assert st["over"].all() and (st["plies"] == cap).all()
+    with pytest.raises(CczError, match="harvest_chunks"):
+        sp.engine.harvest(max_rows=40)
+    total = 0
+    sizes = []
+    for s, p, z in sp.harvest_chunks(max_rows=40):      # 12 rows per game -> 3 games per chunk
+        assert s.shape[0] <= 40 and s.shape[0] % (2 * cap) == 0
+        assert torch.allclose(p.sum(1), torch.ones_like(p[:, 0]), atol=1e-5)
+        sizes.append(s.shape[0])
+        total += s.shape[0]
+    assert total == B * cap * 2 and sizes == [36] * 8
+    st = sp.engine.game_status()
+    assert st["over"].sum() == 0 and st["plies"].sum() == 0
+    # a single game longer than the chunk still comes out (the buffer grows to fit it)
+    for _ in range(cap + 1):
+        sp.run_move()
+    got = sum(s.shape[0] for s, _, _ in sp.harvest_chunks(max_rows=5))
+    assert got == B * cap * 2
+    sp.engine.check_healthy()
