@@ -26,12 +26,19 @@ from .tools import flip_map, log
 
 
 class TupleSink:
-    """Append-only store of training rows in the trainer's on-disk format (convert.py:84-99)."""
+    """Append-only store of training rows in the trainer's on-disk format (convert.py:84-99).
+
+    ``append`` streams every batch of rows to a shard file (host memory stays bounded by one batch: a 4096-board
+    run produces tens of GB of rows); ``flush`` merges old files + shards into ``states.npy / mcts.npy /
+    winners.npy / meta.json`` through memory maps, the same two-pass shape the reference's HDF5 -> .npy
+    converter has (convert.py:21-107).
+    """
 
     def __init__(self, out_dir: str = DATA_DIR, pi_dtype=np.float32):
         self.out_dir = out_dir
-        self.pi_dtype = pi_dtype
-        self._states, self._pi, self._z = [], [], []
+        self.pi_dtype = np.dtype(pi_dtype)
+        self._shards: list[tuple[str, int]] = []
+        self._next = 0
         self.games = 0
         os.makedirs(out_dir, exist_ok=True)
         meta = os.path.join(out_dir, "meta.json")
@@ -42,35 +49,55 @@ class TupleSink:
     def append(self, states, pi, z, games: int = 1):
         to_np = lambda t: t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
         s, p, w = to_np(states), to_np(pi), to_np(z)
-        if len(s) == 0:
-            return
-        self._states.append(s.astype(np.float16).reshape(-1, 17, 7, 10, 9))
-        self._pi.append(p.astype(self.pi_dtype).reshape(-1, 2086))
-        self._z.append(w.astype(np.float32).reshape(-1))
         self.games += games
+        if len(w) == 0:
+            return
+        base = os.path.join(self.out_dir, f".shard_{os.getpid()}_{self._next:06d}")
+        self._next += 1
+        np.save(base + "_s.npy", s.astype(np.float16, copy=False).reshape(-1, 17, 7, 10, 9))
+        np.save(base + "_p.npy", p.astype(self.pi_dtype, copy=False).reshape(-1, 2086))
+        np.save(base + "_z.npy", w.astype(np.float32, copy=False).reshape(-1))
+        self._shards.append((base, int(len(w))))
 
     def rows(self) -> int:
-        return int(sum(len(z) for z in self._z))
+        return int(sum(n for _, n in self._shards))
 
-    def flush(self):
-        """Rewrite the three .npy files with everything collected so far (+ what was on disk)."""
-        paths = {k: os.path.join(self.out_dir, k + ".npy") for k in ("states", "mcts", "winners")}
-        old = [np.load(paths[k]) for k in ("states", "mcts", "winners")] if all(os.path.exists(p) for p in paths.values()) else None
-        parts = [self._states, self._pi, self._z]
-        if old is not None:
-            parts = [[o] + p for o, p in zip(old, parts)]
-        if not parts[2]:
+    def flush(self) -> int:
+        """Merge what is on disk with the pending shards; returns the total number of rows stored."""
+        names = {"states": ("_s.npy", np.float16, (17, 7, 10, 9)), "mcts": ("_p.npy", self.pi_dtype, (2086,)),
+                 "winners": ("_z.npy", np.float32, ())}
+        paths = {k: os.path.join(self.out_dir, k + ".npy") for k in names}
+        have_old = all(os.path.exists(p) for p in paths.values())
+        n_old = int(np.load(paths["winners"], mmap_mode="r").shape[0]) if have_old else 0
+        total = n_old + self.rows()
+        if total == 0:
             return 0
-        arrs = [np.concatenate(p) for p in parts]
-        for k, a in zip(("states", "mcts", "winners"), arrs):
-            np.save(paths[k], a)
+        if self._shards:
+            for k, (suffix, dtype, tail) in names.items():
+                if have_old and np.load(paths[k], mmap_mode="r").dtype != np.dtype(dtype):
+                    raise ValueError(f"{paths[k]} holds another dtype than this sink writes")
+                tmp = paths[k] + ".tmp"
+                out = np.lib.format.open_memmap(tmp, mode="w+", dtype=dtype, shape=(total,) + tail)
+                pos = 0
+                if have_old:
+                    old = np.load(paths[k], mmap_mode="r")
+                    out[:n_old] = old
+                    pos = n_old
+                    del old
+                for base, n in self._shards:
+                    out[pos:pos + n] = np.load(base + suffix, mmap_mode="r")
+                    pos += n
+                out.flush()
+                del out
+                os.replace(tmp, paths[k])
+            for base, _ in self._shards:
+                for suffix, _, _ in names.values():
+                    os.remove(base + suffix)
+            self._shards = []
         with open(os.path.join(self.out_dir, "meta.json"), "w") as f:
-            json.dump({"iters": self.games, "total_samples": int(len(arrs[2])), "state_shape": [17, 7, 10, 9],
-                       "state_dtype": "float16", "mcts_dtype": str(arrs[1].dtype), "winner_dtype": "float32"}, f)
-        self._states, self._pi, self._z = [arrs[0]], [arrs[1]], [arrs[2]]
-        if old is not None:  # everything is on disk now; keep nothing twice
-            self._states, self._pi, self._z = [], [], []
-        return int(len(arrs[2]))
+            json.dump({"iters": self.games, "total_samples": total, "state_shape": [17, 7, 10, 9], "state_dtype": "float16",
+                       "mcts_dtype": str(self.pi_dtype), "winner_dtype": "float32"}, f)
+        return total
 
 
 class CollectPipeline:
