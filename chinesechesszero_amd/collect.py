@@ -198,7 +198,8 @@ class CollectPipeline:
             st = self.selfplay.engine.game_status()
             done = int(st["over"].sum())
             if done or gatherer is not None:
-                chunks = list(self.selfplay.harvest_chunks()) if done else []
+                # with an all-gather every rank ends up holding world x chunk rows: keep chunks at ~1 GB per rank
+                chunks = list(self.selfplay.harvest_chunks(1 << 15 if gatherer is not None else 1 << 19)) if done else []
                 if gatherer is not None:  # every rank issues the same number of collectives: pad with empty chunks
                     n_chunks = torch.tensor([len(chunks)], device=self.selfplay.engine.device)
                     torch.distributed.all_reduce(n_chunks, op=torch.distributed.ReduceOp.MAX)
