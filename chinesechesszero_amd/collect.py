@@ -198,16 +198,32 @@ class CollectPipeline:
             st = self.selfplay.engine.game_status()
             done = int(st["over"].sum())
             if done or gatherer is not None:
+                e = self.selfplay.engine
                 # with an all-gather every rank ends up holding world x chunk rows: keep chunks at ~1 GB per rank
-                chunks = list(self.selfplay.harvest_chunks(1 << 15 if gatherer is not None else 1 << 19)) if done else []
-                if gatherer is not None:  # every rank issues the same number of collectives: pad with empty chunks
-                    n_chunks = torch.tensor([len(chunks)], device=self.selfplay.engine.device)
-                    torch.distributed.all_reduce(n_chunks, op=torch.distributed.ReduceOp.MAX)
-                    e = self.selfplay.engine
-                    empty = (e.leaf_input[:0], torch.empty((0, 2086), device=e.device), torch.empty((0,), device=e.device))
-                    chunks = [gatherer.gather(*(chunks[i] if i < len(chunks) else empty)) for i in range(int(n_chunks.item()))]
-                for i, (s, p, z) in enumerate(chunks):
-                    self.sink.append(s, p, z, games=done if i == 0 else 0)
+                it = iter(self.selfplay.harvest_chunks(1 << 15 if gatherer is not None else 1 << 19)) if done else iter(())
+                first = True
+                while True:
+                    chunk = next(it, None)
+                    if gatherer is None:
+                        if chunk is None:
+                            break
+                        self.sink.append(*chunk, games=done if first else 0)
+                    else:
+                        # ranks finish different numbers of games: keep exchanging until nobody has rows left
+                        more = torch.tensor([0 if chunk is None else 1], device=gatherer.device)
+                        torch.distributed.all_reduce(more, op=torch.distributed.ReduceOp.MAX)
+                        if int(more.item()) == 0:
+                            break
+                        if chunk is None:
+                            chunk = (e.leaf_input[:0], torch.empty((0, 2086), device=e.device), torch.empty((0,), device=e.device))
+                        s, p, z = gatherer.gather(*(t.to(gatherer.device) for t in chunk))
+                        if gatherer.rank == 0:  # the union of the shards goes to ONE store, as N collectors -> one data file
+                            self.sink.append(s, p, z, games=0)
+                    first = False
+                if gatherer is not None:
+                    n_done = torch.tensor([done], device=gatherer.device)
+                    torch.distributed.all_reduce(n_done)
+                    self.sink.games += int(n_done.item())
         self.selfplay.engine.check_healthy()
         self.sink.flush()
         self.iters = self.sink.games

@@ -112,3 +112,81 @@ def test_model_hot_reload_broadcast_world2():
         p.join(timeout=60)
     assert all(r[1] for r in res), res
     assert res[0][2] == res[1][2] and res[0][3] == res[1][3] == 1.0  # rank 1 now holds rank 0's weights and BN stats
+
+
+class _FakeEngine:
+    def __init__(self):
+        self.device = torch.device("cpu")
+        self.leaf_input = torch.zeros((4, 17, 7, 10, 9), dtype=torch.float16)
+        self.over = np.zeros(4, np.uint8)
+
+    def game_status(self):
+        return {"over": self.over.copy()}
+
+    def check_healthy(self):
+        pass
+
+
+class _FakeSelfPlay:
+    """Stands in for BatchedSelfPlay on the CPU: scripted finished games, chunked rows."""
+
+    def __init__(self, rank, script):
+        self.engine = _FakeEngine()
+        self.rank = rank
+        self.script = script  # per move: list of chunk sizes this rank harvests
+        self.move = -1
+
+    def run_move(self):
+        self.move += 1
+        self.engine.over[:] = 0
+        self.engine.over[:len(self.script[self.move])] = 1 if self.script[self.move] else 0
+
+    def harvest_chunks(self, max_rows):
+        for i, n in enumerate(self.script[self.move]):
+            s, p, z = _rows(self.rank * 10 + self.move * 3 + i, n)
+            yield s, p, z
+        self.engine.over[:] = 0
+
+
+def _collect_worker(rank, world, port, tmp, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from chinesechesszero_amd.collect import CollectPipeline
+        from chinesechesszero_amd.replay import TupleGatherer
+        cp = CollectPipeline.__new__(CollectPipeline)
+        from chinesechesszero_amd.collect import TupleSink
+        cp.sink = TupleSink(os.path.join(tmp, f"rank{rank}"))
+        cp.iters = 0
+        cp.n_boards = 4
+        cp.load_model = lambda: None
+        # rank 0: move 0 -> two chunks (5, 2 rows); move 1 -> nothing; rank 1: move 0 -> nothing; move 1 -> three chunks
+        script = {0: [[5, 2], []], 1: [[], [3, 1, 4]]}[rank]
+        cp.selfplay = _FakeSelfPlay(rank, script)
+        g = TupleGatherer(4, "cpu")
+        cp.collect_batched(2, gatherer=g)
+        n = int(np.load(os.path.join(tmp, f"rank{rank}", "winners.npy")).shape[0]) if os.path.exists(os.path.join(tmp, f"rank{rank}", "winners.npy")) else 0
+        q.put((rank, True, n, cp.iters))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, False, traceback.format_exc()[-1500:], 0))
+
+
+def test_collect_batched_gather_loop_world2(tmp_path):
+    """Ranks finish different numbers of games in different moves: the exchange loop stays aligned and the union
+    of the shards lands in rank 0's store (what N reference collectors would append to one data file)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_collect_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] for r in res), res
+    assert res[0][2] == 5 + 2 + 3 + 1 + 4 and res[1][2] == 0   # rank 0 stores the union, rank 1 nothing
+    assert res[0][3] == res[1][3] == 2 + 3                     # finished "games" (boards flagged over) counted globally
