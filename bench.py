@@ -250,6 +250,17 @@ def main():
         dt = float(t.item())
     s1 = e.stats()
     e.check_healthy()
+    # what a HIP-event pair reports around a trivial kernel on this stream (the floor included in avg_launch_us)
+    tiny = torch.zeros(64, device=dev)
+    fl = []
+    for _ in range(64):
+        a0, a1 = ev(), ev()
+        a0.record()
+        tiny.add_(1.0)
+        a1.record()
+        fl.append((a0, a1))
+    torch.cuda.synchronize()
+    event_floor_us = float(np.median([x.elapsed_time(y) for x, y in fl])) * 1e3
 
     sims = s1["sims"] - s0["sims"]
     exp = max(1, s1["expansions"] - s0["expansions"])
@@ -293,7 +304,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_step (fused expand+backup+select+movegen+encode)",
                          "achieved": (ach or 0) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": (ach or 0) / HBM_PEAK,
                          "traffic": traffic, "algorithmic_bytes_per_launch": a_step * B, "avg_launch_us": t_step * 1e6,
-                         "k_bar": kbar, "d_bar": dbar},
+                         "k_bar": kbar, "d_bar": dbar, "event_floor_us": event_floor_us},
             "survey_a_sim_bytes": a_sim_survey,
             "step_split_us": {"k_step": t_step * 1e6, "evaluator": t_net * 1e6},
             "trainer_updates": (train_steps[0] if trainer is not None else 0),
