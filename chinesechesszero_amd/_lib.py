@@ -39,7 +39,7 @@ class Config(C.Structure):
         ("n_boards", C.c_int32), ("n_playout", C.c_int32), ("c_puct", C.c_float), ("eps", C.c_float),
         ("alpha", C.c_float), ("temp", C.c_float), ("max_nodes", C.c_int32), ("max_depth", C.c_int32),
         ("max_plies", C.c_int32), ("flags", C.c_uint32), ("seed", C.c_uint64), ("board_id_base", C.c_uint64),
-        ("device", C.c_int32), ("reserved", C.c_int32),
+        ("device", C.c_int32), ("reserve_nodes", C.c_int32),
     ]
 
 
@@ -48,7 +48,7 @@ class Stats(C.Structure):
         ("sims", C.c_int64), ("moves", C.c_int64), ("games", C.c_int64), ("truncated_games", C.c_int64),
         ("nodes_peak", C.c_int64), ("depth_peak", C.c_int64), ("sum_depth", C.c_int64), ("sum_children", C.c_int64),
         ("expansions", C.c_int64), ("terminal_leaves", C.c_int64), ("error_flags", C.c_int32), ("reserved", C.c_int32),
-        ("hbm_bytes", C.c_int64),
+        ("hbm_bytes", C.c_int64), ("pruned_subtrees", C.c_int64),
     ]
 
 

@@ -47,12 +47,13 @@ struct __align__(8) BoardMeta {
 };
 
 struct BoardStats {
-    unsigned long long sims, moves, games, truncated, sum_depth, sum_children, expansions, terminal;
+    unsigned long long sims, moves, games, truncated, sum_depth, sum_children, expansions, terminal, pruned;
     int32_t nodes_peak, depth_peak;
 };
 
 struct Dev {
     int32_t B, cap, maxd, max_plies, pi_cap;
+    int32_t reserve;   // nodes of every pool half kept free at re-root time for the next move's expansions
     float c_puct;
     double eps, alpha, temp;
     uint32_t flags;

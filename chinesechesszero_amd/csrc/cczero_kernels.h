@@ -711,8 +711,13 @@ __global__ __launch_bounds__(64) void k_finish_move(Dev D, const int32_t *forced
     if (keep_tree) {
         if (lane == 0) { NA[0] = A[root.fc + ci]; NB[0] = Bn[root.fc + ci]; }
         __syncthreads();
-        int head = 0;
-        bool fail = false;
+        int head = 0, pruned = 0;
+        // The kept subtree may use the pool up to `budget`, leaving room for a whole move of new expansions.
+        // Breadth-first order copies the tree level by level, so when the budget runs out it is the DEEPEST nodes
+        // that lose their children (they become unexpanded leaves again, keeping N, Q, P): bounded memory with a
+        // graceful loss at the bottom of very concentrated trees instead of failed expansions later (counted in
+        // stats.pruned_subtrees; the reference's Python tree is unbounded, DESIGN.md "caps").
+        const int budget = D.cap - D.reserve;
         while (head < n_new) {
             const int i = head + lane;
             const bool valid = i < n_new;
@@ -720,13 +725,17 @@ __global__ __launch_bounds__(64) void k_finish_move(Dev D, const int32_t *forced
             int nc = 0;
             if (valid) { rec = NA[i]; nc = (int)(NB[i] >> 16); }
             const int incl = wave_incl_scan(nc, lane);
-            const int total = __builtin_amdgcn_readlane(incl, 63);
-            if (n_new + total > D.cap) { fail = true; break; }
+            const bool keep = nc > 0 && n_new + incl <= budget;   // a prefix of the lanes: incl is non-decreasing
+            const bool drop = nc > 0 && !keep;
+            const uint64_t km = __ballot(keep);
+            const int total = km ? __builtin_amdgcn_readlane(incl, __builtin_amdgcn_readfirstlane(63 - __builtin_clzll(km))) : 0;
             const int dst = n_new + incl - nc;
-            s_cnt[lane] = nc;
-            if (nc > 0) { s_src[lane] = rec.fc; s_dst[lane] = dst; NA[i].fc = dst; }
+            s_cnt[lane] = keep ? nc : 0;
+            if (keep) { s_src[lane] = rec.fc; s_dst[lane] = dst; NA[i].fc = dst; }
+            if (drop) { NA[i].fc = -1; NB[i] = NB[i] & 0xffffu; }
+            pruned += __popcll(__ballot(drop));
             __syncthreads();
-            uint64_t todo = __ballot(nc > 0);
+            uint64_t todo = km;
             while (todo) {
                 const int L = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
@@ -738,10 +747,7 @@ __global__ __launch_bounds__(64) void k_finish_move(Dev D, const int32_t *forced
             n_new += total;
             __syncthreads();
         }
-        if (fail) { // cannot happen when cap >= the source pool; fall back to a fresh root loudly
-            if (lane == 0) set_err(D, 1);
-            n_new = 0;
-        }
+        if (pruned && lane == 0) D.stats[b].pruned += (unsigned long long)pruned;
     }
     if (!keep_tree || n_new == 0) {
         if (lane == 0) { NA[0] = NodeA{0, 0.0f, 1.0f, -1}; NB[0] = 0u; }

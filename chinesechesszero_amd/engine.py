@@ -30,7 +30,7 @@ class SelfPlayEngine:
     def __init__(self, n_boards: int, n_playout: int = 400, c_puct: float = 5, eps: float = 0.25,
                  alpha: float = 0.2, temp: float = 1.0, seed: int = 0, board_id_base: int = 0,
                  device: int = 0, max_nodes: int = 0, max_depth: int = 0, max_plies: int = 0,
-                 reference_quirks: bool = False, mirror: bool = True):
+                 reference_quirks: bool = False, mirror: bool = True, reserve_nodes: int = 0):
         self.L = _lib.lib()
         if not torch.cuda.is_available():
             raise CczError("no GPU visible to PyTorch-ROCm; the engine has no CPU fallback")
@@ -42,7 +42,7 @@ class SelfPlayEngine:
         cfg = Config(n_boards=self.B, n_playout=self.n_playout, c_puct=float(c_puct), eps=float(eps),
                      alpha=float(alpha), temp=float(temp), max_nodes=int(max_nodes), max_depth=int(max_depth),
                      max_plies=int(max_plies), flags=flags, seed=int(seed) & (2**64 - 1),
-                     board_id_base=int(board_id_base), device=int(device), reserved=0)
+                     board_id_base=int(board_id_base), device=int(device), reserve_nodes=int(reserve_nodes))
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             check(self.L.ccz_create(C.byref(cfg), C.byref(h)))

@@ -67,14 +67,16 @@ typedef struct ccz_config {
     float eps;             /* parameters.py:10 EPS   = 0.25 (Dirichlet mixing weight)            */
     float alpha;           /* parameters.py:12 ALPHA = 0.2                                       */
     float temp;            /* game.py:133 temp=1.0 ; schedule of game.py:159 applied per board   */
-    int32_t max_nodes;     /* tree nodes per board per pool half (0 = derive from n_playout)     */
+    int32_t max_nodes;     /* tree nodes per board per pool half (0 = 512 x (n_playout + 64))    */
     int32_t max_depth;     /* selection path capacity (0 = 512)                                  */
     int32_t max_plies;     /* recorded plies per game before adjudicating a draw (0 = 2048)      */
     uint32_t flags;        /* CCZ_FLAG_*                                                         */
     uint64_t seed;         /* device-mode sampling: Philox key                                   */
     uint64_t board_id_base;/* global id of board 0 (rank * n_boards): RNG streams independent of GPU count */
     int32_t device;        /* HIP device ordinal                                                 */
-    int32_t reserved;
+    int32_t reserve_nodes; /* pool nodes kept free at re-root time for the next move's expansions
+                              (0 = min(128 x n_playout, max_nodes / 2)); the kept subtree is pruned
+                              bottom-up to max_nodes - reserve_nodes                            */
 } ccz_config;
 
 typedef struct ccz_stats {
@@ -91,6 +93,8 @@ typedef struct ccz_stats {
     int32_t error_flags;     /* sticky device error bits (CCZ_ERR_*), 0 = healthy                */
     int32_t reserved;
     int64_t hbm_bytes;       /* device memory held by the engine                                 */
+    int64_t pruned_subtrees; /* nodes whose children were dropped at re-root time to keep the kept
+                                subtree within the pool budget (0 in normal runs)                 */
 } ccz_stats;
 
 #define CCZ_ERR_NODE_POOL 1   /* a board ran out of tree nodes (raise max_nodes)                 */

@@ -39,8 +39,10 @@ for mv in range(moves):
         assert torch.allclose(p.sum(1), torch.ones_like(p[:, 0]), atol=1e-4)
         rows += s.shape[0]
         games += int(over.sum())
-    if mv % 20 == 19:
-        print(f"move {mv + 1}: {games} games, {rows} rows, {time.perf_counter() - t0:.0f} s", flush=True)
+    if mv % 5 == 4:
+        _s = e.stats()
+        print(f"move {mv + 1}: {games} games, {rows} rows, nodes_peak {_s['nodes_peak']}, depth_peak {_s['depth_peak']}, "
+              f"{time.perf_counter() - t0:.0f} s", flush=True)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 st = e.stats()

@@ -173,3 +173,35 @@ def test_logits_boundary_gathers_the_same_priors():
         assert np.allclose(ra["q"], rb["q"], rtol=0, atol=1e-6)
         ea.check_healthy()
         eb.check_healthy()
+
+
+def test_reroot_budget_prunes_deepest_levels_instead_of_failing():
+    """A kept subtree larger than the pool budget loses its deepest children at re-root time (they become leaves
+    again); the top of the tree, the visit counts of the new root and the health flags are untouched."""
+    from chinesechesszero_amd.engine import SelfPlayEngine
+    from test_gpu_soak import LinearEvaluator
+    B, n = 6, 300
+    ev = LinearEvaluator(torch.device("cuda", 0), seed=2, sharp=14.0)
+    e = SelfPlayEngine(B, n_playout=n, max_nodes=40000, reserve_nodes=37000, seed=3)   # kept subtree budget: 3000 nodes
+    pruned_before = 0
+    for move in range(6):
+        leaf = e.select_leaves()
+        for i in range(n):
+            p, v = ev(leaf)
+            if i + 1 < n:
+                leaf = e.step(p, v)
+            else:
+                e.expand_backup(p, v)
+        rc = e.root_children()
+        best = [int(np.argmax(rc["visits"][b][:rc["k"][b]])) for b in range(B)]      # keep as much of the tree as possible
+        forced = np.array([rc["acts"][b][best[b]] for b in range(B)], np.int32)
+        kept_visits = np.array([rc["visits"][b][best[b]] for b in range(B)])
+        e.finish_move(forced_moves=forced)
+        after = e.root_children()
+        assert np.array_equal(after["root_visits"], kept_visits)                       # the new root keeps its statistics
+        st = e.stats()
+        assert st["error_flags"] == 0, st
+        assert st["nodes_peak"] <= 40000
+        pruned_before = st["pruned_subtrees"]
+    assert pruned_before > 0, "the budget was never hit: the test does not exercise pruning"
+    e.check_healthy()
