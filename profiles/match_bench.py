@@ -52,13 +52,14 @@ with tempfile.TemporaryDirectory() as d:
         if stt["over"].any():
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            s, p, z = sp.harvest()
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            sink.append(s, p, z, games=int(stt["over"].sum()))
-            t_harvest += t2 - t1
-            t_sink += time.perf_counter() - t2
-            rows += s.shape[0]
+            for s, p, z in sp.harvest_chunks(1 << 17):
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                sink.append(s, p, z, games=0)
+                t_harvest += t2 - t1
+                t_sink += time.perf_counter() - t2
+                rows += s.shape[0]
+                t1 = time.perf_counter()
     t3 = time.perf_counter()
     n_written = sink.flush()
     t_sink += time.perf_counter() - t3

@@ -34,10 +34,12 @@ for mv in range(moves):
         lengths += st["plies"][over].tolist()
         decisive += int((st["winner"][over] >= 0).sum())
         truncated += int(((st["plies"][over] >= max_plies) & (st["winner"][over] < 0)).sum())
-        s, p, z = sp.harvest()
-        assert s.shape[0] == 2 * int(st["plies"][over].sum())
-        assert torch.allclose(p.sum(1), torch.ones_like(p[:, 0]), atol=1e-4)
-        rows += s.shape[0]
+        got = 0
+        for s, p, z in sp.harvest_chunks(1 << 17):     # bounded device buffers whatever the burst size
+            assert torch.allclose(p.sum(1), torch.ones_like(p[:, 0]), atol=1e-4)
+            got += s.shape[0]
+        assert got == 2 * int(st["plies"][over].sum())
+        rows += got
         games += int(over.sum())
     if mv % 5 == 4:
         _s = e.stats()
