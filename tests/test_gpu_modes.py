@@ -205,3 +205,38 @@ def test_reroot_budget_prunes_deepest_levels_instead_of_failing():
         pruned_before = st["pruned_subtrees"]
     assert pruned_before > 0, "the budget was never hit: the test does not exercise pruning"
     e.check_healthy()
+
+
+@pytest.mark.parametrize("B,n", [(1, 1), (37, 1), (37, 2), (5, 3), (129, 7)])
+def test_odd_sizes_and_minimal_playouts(B, n):
+    """Board counts that are not multiples of anything and the degenerate n_playout = 1 (root expanded, no child
+    visited: pi is uniform over the legal moves, mcts.py:165)."""
+    from chinesechesszero_amd.selfplay import BatchedSelfPlay
+    from chinesechesszero_amd.net import uniform_evaluator
+    sp = BatchedSelfPlay(uniform_evaluator, B, n_playout=n, seed=B * 10 + n, max_plies=9)
+    for move in range(12):
+        rc_before = None
+        if move == 0:
+            leaf = sp.engine.select_leaves()
+            for i in range(n):
+                p, v = uniform_evaluator(leaf)
+                if i + 1 < n:
+                    leaf = sp.engine.step(p, v)
+                else:
+                    sp.engine.expand_backup(p, v)
+            rc_before = sp.engine.root_children()
+            assert np.all(rc_before["k"] == 44) and np.all(rc_before["root_visits"] == n)
+            assert np.all(rc_before["visits"].sum(1) == n - 1)
+            pi = sp.engine.root_pi(temps=1.0)
+            if n == 1:
+                assert np.allclose(pi[:, :44], 1.0 / 44, atol=1e-12)
+            moves = sp.finish_move().cpu().numpy()
+        else:
+            moves = sp.run_move().cpu().numpy()
+        st = sp.engine.game_status()
+        assert np.all((moves >= 0) | (st["plies"] >= 9) | (st["over"] == 1))
+        if st["over"].any():
+            s, p, z = sp.harvest()
+            assert s.shape[0] == 2 * int(st["plies"][st["over"] == 1].sum())
+    sp.engine.check_healthy()
+    assert sp.engine.stats()["games"] >= B
