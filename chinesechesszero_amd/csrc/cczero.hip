@@ -14,6 +14,7 @@
 
 #include "cczero_kernels.h"
 #include "cczero_netops.h"
+#include "cczero_conv.h"
 
 using namespace ccz;
 
@@ -527,7 +528,37 @@ int ccz_bias_act_f16(void *stream, void *y_dev, const void *bias_dev, const void
     return 0;
 }
 
+int ccz_conv3x3_c256_f16(void *stream, const void *x_dev, const void *w_dev, const void *bias_f32_dev, const void *residual_dev, void *y_dev,
+                         int64_t n_pixels, int32_t relu)
+{
+    if (!x_dev || !w_dev || !bias_f32_dev || !y_dev || n_pixels < 0 || n_pixels % 90 || n_pixels > (int64_t)INT32_MAX / 2)
+        return fail(-1, "ccz_conv3x3_c256_f16: bad arguments (n_pixels must be boards * 90)");
+    if ((((uintptr_t)x_dev) | ((uintptr_t)w_dev) | ((uintptr_t)bias_f32_dev) | ((uintptr_t)residual_dev) | ((uintptr_t)y_dev)) & 15)
+        return fail(-1, "ccz_conv3x3_c256_f16: pointers must be 16-byte aligned");
+    if (x_dev == y_dev) return fail(-1, "ccz_conv3x3_c256_f16: the output may alias the residual but not the input");
+    if (n_pixels == 0) return 0;
+    const unsigned tiles = (unsigned)((n_pixels + kCvBM - 1) / kCvBM);
+#ifndef CCZ_STAMPS
+    relu = relu ? 1 : 0; // the diagnostic build passes ablation switches in bits 8.. (profiles/conv_microbench.py)
+#endif
+    if (residual_dev)
+        hipLaunchKernelGGL(k_conv3x3_c256<true>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev,
+                           (const float *)bias_f32_dev, (const _Float16 *)residual_dev, (_Float16 *)y_dev, (int)n_pixels, (int)relu);
+    else
+        hipLaunchKernelGGL(k_conv3x3_c256<false>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev,
+                           (const float *)bias_f32_dev, (const _Float16 *)nullptr, (_Float16 *)y_dev, (int)n_pixels, (int)relu);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 #ifdef CCZ_STAMPS
+// diagnostic build only: cycle stamps of the last ccz_conv3x3_c256_f16 launch (uint64 [2048][2][16])
+int ccz_debug_conv_stamps(unsigned long long *out_host)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_cv_stamps), sizeof(unsigned long long) * 2048 * 2 * 16));
+    return 0;
+}
 // diagnostic build only: per-board s_memtime stamps of the last k_step launch (uint64 [B*16])
 int ccz_debug_stamps(ccz_engine *e, void *stream, unsigned long long *out_host)
 {

@@ -107,6 +107,8 @@ class InferenceNet(nn.Module):
                 bs.append(nn.Parameter(b.to(dtype), requires_grad=False))
         self.ws = nn.ParameterList(ws)
         self.bs = nn.ParameterList(bs)
+        # float32 copies of the tower biases for the fused convolution kernel (bias is added to the fp32 accumulator)
+        self.bs32 = nn.ParameterList([nn.Parameter(b.detach().float().clone(), requires_grad=False) for b in bs])
         # both 1x1 head convs in one GEMM: 17 policy + 7 value output channels
         wp, bp = _fold(net.policy_conv, net.policy_bn)
         wv, bv = _fold(net.value_conv, net.value_bn)
@@ -137,6 +139,32 @@ class InferenceNet(nn.Module):
             y = y + residual
         return F.relu_(y)
 
+    FUSED_MIN_BOARDS = 64  # below this the 256-pixel tiles of the fused kernel leave most of the chip idle
+
+    def _use_fused_tower(self, x) -> bool:
+        """The hand-written MFMA convolution (libcczero ccz_conv3x3_c256_f16) covers the tower's shape only:
+        fp16 NHWC on the GPU, 256 channels. ``CCZ_FUSED_CONV=0`` selects the MIOpen + epilogue path for A/B runs."""
+        if os.environ.get("CCZ_FUSED_CONV", "1") == "0":
+            return False
+        return bool(x.is_cuda and x.dtype == torch.float16 and x.shape[1] == 256 and x.shape[0] >= self.FUSED_MIN_BOARDS
+                    and x.is_contiguous(memory_format=torch.channels_last))
+
+    def _tower_fused(self, x):
+        """40 residual blocks = 80 launches of one kernel: conv3x3 + bias [+ x] + ReLU each (reference net.py:20-43)."""
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        n_pixels = x.shape[0] * 90
+        y = torch.empty_like(x)
+        xp, yp = C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr())
+        for i in range(0, len(self.ws), 2):
+            _lib.check(L.ccz_conv3x3_c256_f16(stream, xp, C.c_void_p(self.ws[i].data_ptr()), C.c_void_p(self.bs32[i].data_ptr()),
+                                              None, yp, n_pixels, 1))
+            _lib.check(L.ccz_conv3x3_c256_f16(stream, yp, C.c_void_p(self.ws[i + 1].data_ptr()), C.c_void_p(self.bs32[i + 1].data_ptr()),
+                                              xp, xp, n_pixels, 1))  # output written over the residual input
+        return x
+
     @torch.no_grad()
     def forward(self, leaf_input: torch.Tensor, return_logits: bool = False):
         B = leaf_input.shape[0]
@@ -145,9 +173,12 @@ class InferenceNet(nn.Module):
             x = torch.cat([x[:, 49:56], x[:, 105:119]], dim=1)
         x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
         x = self._epilogue(F.conv2d(x, self.stem_w, None, padding=1), self.stem_b)
-        for i in range(0, len(self.ws), 2):
-            y = self._epilogue(F.conv2d(x, self.ws[i], None, padding=1), self.bs[i])
-            x = self._epilogue(F.conv2d(y, self.ws[i + 1], None, padding=1), self.bs[i + 1], x)
+        if self._use_fused_tower(x):
+            x = self._tower_fused(x)
+        else:
+            for i in range(0, len(self.ws), 2):
+                y = self._epilogue(F.conv2d(x, self.ws[i], None, padding=1), self.bs[i])
+                x = self._epilogue(F.conv2d(y, self.ws[i + 1], None, padding=1), self.bs[i + 1], x)
         h = F.relu_(F.conv2d(x, self.head_w, self.head_b))
         pol = h[:, :PLAYS].reshape(B, PLAYS * 90)          # NCHW flatten order, as torch.reshape in net.py:98
         val = h[:, PLAYS:].reshape(B, PIECES * 90)

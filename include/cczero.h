@@ -229,6 +229,16 @@ int ccz_apply_moves(void *stream, int32_t n, uint8_t *sq_dev, uint8_t *turn_dev,
 int ccz_bias_act_f16(void *stream, void *y_dev, const void *bias_dev, const void *residual_dev,
                      int64_t rows, int32_t channels);
 
+/* A whole tower convolution in one kernel (MFMA implicit GEMM, hand-written for gfx950): 3x3, padding 1,
+ * 256 -> 256 channels over boards of 10 x 9, NHWC fp16 in and out, fp32 accumulate:
+ *   y[p, co] = act( bias[co] + sum_{ky,kx,ci} w[co, ky, kx, ci] * x[p + 9*(ky-1) + (kx-1), ci] [+ residual[p, co]] )
+ * with taps that leave the board contributing zero; act = ReLU when relu != 0 (reference net.py:20-43,
+ * ResBlock conv -> BN(folded) -> [+x] -> ReLU; replaces F.conv2d + ccz_bias_act_f16 for these layers).
+ * x, y, residual: [n_pixels, 256] fp16 (n_pixels = boards * 90); w: [256, 3, 3, 256] fp16 (the memory of a
+ * channels-last [co, ci, 3, 3] tensor); bias: float32 [256]. y may alias residual, not x. */
+int ccz_conv3x3_c256_f16(void *stream, const void *x_dev, const void *w_dev, const void *bias_f32_dev,
+                         const void *residual_dev, void *y_dev, int64_t n_pixels, int32_t relu);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,112 @@
+"""The evaluator's tower convolution kernel (ccz_conv3x3_c256_f16, hand-written MFMA implicit GEMM) against a
+float32 torch convolution of the same fp16-rounded operands, and the fused tower against the reference
+architecture (net.py:20-43, 53-110). Tolerances: fp32 accumulation, one fp16 rounding of the result (two with a residual)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _conv(x, w, bias32, res, y, relu):
+    from chinesechesszero_amd import _lib
+    s = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(_lib.lib().ccz_conv3x3_c256_f16(s, C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(bias32.data_ptr()),
+                                               C.c_void_p(res.data_ptr()) if res is not None else None, C.c_void_p(y.data_ptr()),
+                                               x.shape[0] * 90, relu))
+    return y
+
+
+@pytest.mark.parametrize("boards", [1, 2, 3, 17, 64, 257])
+def test_conv_kernel_matches_fp32_convolution(boards):
+    """Tile edges fall inside boards (256 pixels per tile, 90 per board); the last tile is partial for every size here."""
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(boards)
+    cl = torch.channels_last
+    x = (torch.randn(boards, 256, 10, 9, generator=g) * 0.7).to(dev).half().contiguous(memory_format=cl)
+    r = (torch.randn(boards, 256, 10, 9, generator=g) * 0.7).to(dev).half().contiguous(memory_format=cl)
+    w = (torch.randn(256, 256, 3, 3, generator=g) * 0.03).to(dev).half().contiguous(memory_format=cl)
+    b = (torch.randn(256, generator=g) * 0.2).to(dev)
+    ref = F.conv2d(x.float(), w.float(), b, padding=1)
+    for res, relu in ((None, 1), (r, 1), (None, 0), (r, 0)):
+        y = torch.full_like(x, float("nan"))
+        _conv(x, w, b, res, y, relu)
+        want = ref if res is None else ref + res.float()
+        if relu:
+            want = F.relu(want)
+        err = (y.float() - want).abs().max().item()
+        assert err < 4e-3 * max(1.0, want.abs().max().item()), (boards, res is not None, relu, err)
+    # the output may be written over the residual input (how the tower uses it)
+    y = r.clone(memory_format=torch.preserve_format)
+    _conv(x, w, b, y, y, 1)
+    want = F.relu(ref + r.float())
+    assert (y.float() - want).abs().max().item() < 4e-3 * max(1.0, want.abs().max().item())
+
+
+def test_conv_kernel_board_edges_are_zero_padded_per_board():
+    """A single hot pixel in a corner must not leak into the neighbouring board or wrap around a file edge:
+    with all-ones weights the output is the 3x3 box count of the hot pixels of THAT board."""
+    dev = torch.device("cuda", 0)
+    cl = torch.channels_last
+    x = torch.zeros(4, 256, 10, 9, device=dev, dtype=torch.float16).contiguous(memory_format=cl)
+    x[0, 0, 9, 8] = 1   # last pixel of board 0
+    x[1, 0, 0, 0] = 1   # first pixel of board 1
+    x[2, 0, 4, 8] = 1   # right edge, middle rank
+    x[3, 0, 5, 0] = 1   # left edge
+    w = torch.zeros(256, 256, 3, 3, device=dev, dtype=torch.float16).contiguous(memory_format=cl)
+    w[:, 0] = 1
+    b = torch.zeros(256, device=dev)
+    y = _conv(x, w, b, None, torch.empty_like(x), 0)
+    want = F.conv2d(x.float(), w.float(), None, padding=1)
+    assert torch.equal(y.float(), want)
+    assert y[0, 5].sum().item() == 4 and y[1, 5].sum().item() == 4 and y[2, 5].sum().item() == 6
+
+
+def test_conv_kernel_rejects_bad_arguments():
+    from chinesechesszero_amd import _lib
+    dev = torch.device("cuda", 0)
+    x = torch.zeros(90 * 256, device=dev, dtype=torch.float16)
+    b = torch.zeros(256, device=dev)
+    L = _lib.lib()
+    s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    p = C.c_void_p(x.data_ptr())
+    assert L.ccz_conv3x3_c256_f16(s, p, p, C.c_void_p(b.data_ptr()), None, p, 90, 1) < 0          # y aliases x
+    assert L.ccz_conv3x3_c256_f16(s, p, p, C.c_void_p(b.data_ptr()), None, C.c_void_p(x.data_ptr() + 16), 89, 1) < 0  # not boards * 90
+    assert L.ccz_conv3x3_c256_f16(s, None, p, C.c_void_p(b.data_ptr()), None, p, 90, 1) < 0
+
+
+def test_fused_tower_matches_reference_architecture_and_miopen_path(monkeypatch):
+    """256-channel tower (the only width the kernel serves), 3 blocks, 70 boards: fused path vs fp32 reference
+    architecture, and vs the MIOpen + epilogue path it replaces."""
+    from chinesechesszero_amd.net import InferenceNet, Net
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(5)
+    net = Net(256, 3).to(dev).eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 2)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.1)
+    B = 70
+    x = torch.zeros(B, 17, 7, 10, 9, device=dev)
+    x[:, 7] = (torch.rand(B, 7, 10, 9, device=dev) > 0.9).float()
+    x[:, 15] = (torch.rand(B, 7, 10, 9, device=dev) > 0.9).float()
+    x[::2, 16] = 1
+    with torch.no_grad():
+        logp, v = net(x)
+        inf = InferenceNet(net).to(dev).eval()
+        assert inf._use_fused_tower(torch.empty(B, 256, 10, 9, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last))
+        p_f, v_f = inf(x.half())
+        monkeypatch.setenv("CCZ_FUSED_CONV", "0")
+        p_m, v_m = inf(x.half())
+        monkeypatch.delenv("CCZ_FUSED_CONV")
+        lg_f, _ = inf(x.half(), return_logits=True)
+    assert (logp.exp() - p_f).abs().max().item() < 2e-3 and (v.view(-1) - v_f).abs().max().item() < 2e-2
+    assert (p_m - p_f).abs().max().item() < 2e-3 and (v_m - v_f).abs().max().item() < 2e-2
+    assert torch.allclose(p_f.sum(1), torch.ones(B, device=dev), atol=1e-3)
+    assert lg_f.shape == (B, 2086)
+    # small batches stay on the MIOpen path
+    assert not inf._use_fused_tower(torch.empty(8, 256, 10, 9, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last))
