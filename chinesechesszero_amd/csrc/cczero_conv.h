@@ -8,7 +8,7 @@
 //
 //   * D[co, pixel] = W[co, k] . X[k, pixel], k = (tap, ci): weights are the MFMA A operand (rows ->
 //     accumulator registers), pixels the B operand (columns -> lanes), so each lane ends up holding 4
-//     consecutive output channels of ONE pixel per register group: packed 8-byte NHWC stores.
+//     consecutive output channels of ONE pixel per register group.
 //   * one workgroup = 256 consecutive pixels x all 256 output channels; 8 waves as 2 (co) x 4 (pixels),
 //     a 128 x 64 accumulator block (4 x 2 tiles of v_mfma_f32_32x32x16_f16) per wave.
 //   * K order = 4 input-channel chunks of 64 (outer) x 9 taps x 2 halves of 32 (inner) = 72 half-steps.
@@ -18,9 +18,16 @@
 //     staged per half-step, into a ring of five 16 KB half-tiles, three half-steps ahead.
 //   * both operands arrive by global_load_lds (16 B per lane, no VGPR round trip) into XOR-swizzled rows
 //     (swizzle applied to the SOURCE address and to the read address): conflict-free ds_read_b128.
-//   * the two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) run one barrier apart: while one group
-//     issues its 16 MFMAs of a half-step, the other reads fragments and issues the DMA loads. DMA loads stay in
-//     flight across barriers (raw s_barrier + counted s_waitcnt vmcnt, never 0 inside the loop).
+//   * software pipeline, one barrier per half-step: the fragments of the next 8-MFMA group are read while the
+//     current group issues; DMA loads stay in flight across barriers (raw s_barrier + counted s_waitcnt vmcnt,
+//     never 0 inside the loop).
+//   * epilogue: each wave transposes its 64 pixel x 128 channel block through its own LDS region, so that the
+//     residual is read and the output written as whole 256-byte pixel-row segments.
+//
+// Measured alternatives that did NOT pay (profiles/conv_ab.py, one device, interleaved): staggering the DMA issue of
+// the two wave groups (-4.5 %), running the groups half a half-step apart (-2 %), s_setprio around the MFMA groups
+// (-11 %), sched_group_barrier-pinned interleave (-1.5 %), fragments read a whole half-step ahead into three
+// register sets (0 %), 16 zero rows (one per bank slot) for the masked lanes (-1 %).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -38,13 +45,14 @@ constexpr int kCvARows = 288;         // staged slab rows (276 used)
 constexpr int kCvABytes = kCvARows * 128;
 constexpr int kCvWBytes = 256 * 64;   // one half-step of weights: 256 output channels x 32 k
 constexpr int kCvRing = 5;
-constexpr int kCvWOff = 2 * kCvABytes;
-constexpr int kCvZeroOff = kCvWOff + kCvRing * kCvWBytes;
+constexpr int kCvAhead = 3;           // weight half-tiles in flight ahead of the one being read
+constexpr int kCvAOff = kCvRing * kCvWBytes; // LDS: [weight ring | slab 0 | slab 1 | zero row]; the ring first, so that
+                                             // the four weight reads of a k-sub share one address register (+ immediates)
+constexpr int kCvZeroOff = kCvAOff + 2 * kCvABytes;
 constexpr int kCvLds = kCvZeroOff + 128;
 constexpr int kCvERow = 272;          // epilogue transpose: bytes per pixel row of a wave's 64 x 128 block (256 + pad)
-constexpr int kCvAhead = 3;           // weight half-tiles in flight ahead of the one being read
-
 static_assert(8 * 64 * kCvERow <= kCvLds, "epilogue transpose must fit the operand buffers");
+
 typedef __attribute__((address_space(3))) void *cv_lds_ptr;
 typedef const __attribute__((address_space(1))) void *cv_glb_ptr;
 
@@ -55,11 +63,9 @@ __device__ __forceinline__ void cv_glds16(const void *src, unsigned char *lds_wa
 
 // the activation-slab DMA of the next chunk is spread over half-steps 2, 4, 6, 8, 10 of the current one
 __host__ __device__ constexpr int cv_act_pass(int u) { return (u >= 2 && u <= 10 && !(u & 1)) ? (u - 2) / 2 : -1; }
-__host__ __device__ constexpr int cv_vmcnt(int u)
-{
-    // DMA loads issued after the half-tile the NEXT half-step reads: 2 x 2 weight loads + the slab loads of this and the previous half-step
-    return 4 + (cv_act_pass(u) >= 0 ? 1 : 0) + (cv_act_pass((u + 17) % 18) >= 0 ? 1 : 0);
-}
+// DMA loads younger than the half-tile the NEXT half-step reads (issue order per half-step: slab piece, 2 weight loads):
+// 2 x 2 weight loads + the slab pieces of this and the previous half-step
+__host__ __device__ constexpr int cv_vmcnt(int u) { return 4 + (cv_act_pass(u) >= 0 ? 1 : 0) + (cv_act_pass((u + 17) % 18) >= 0 ? 1 : 0); }
 template <int N> __device__ __forceinline__ void cv_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 struct CvCtx {
@@ -70,13 +76,19 @@ struct CvCtx {
     int wave_dst;            // w * 1024
     int h;                   // lane >> 5
     int a_off[2];            // weight fragment offsets inside a ring slot (k-sub 0 / 1)
-    int brow[2];             // slab row of this lane's pixel (j = 0 / 1) at tap offset 0
+    int brow;                // slab row of this lane's pixel of tile j = 0 at tap offset 0 (tile 1: + 32)
     unsigned vmask[2];
     int dbg;                 // diagnostic build (-DCCZ_STAMPS) only: ablation switches from bits 8.. of the relu argument
 };
+// slab addressing of one tap, shared by both pixel tiles and all four k-subs of the tap
+struct CvTap {
+    int base; // LDS offset of the row of tile 0 at this tap
+    int sw16; // (((row >> 1) & 7) ^ h) << 4: swizzled position of chunk h
+};
+
 #ifdef CCZ_STAMPS
 #define CV_DBG(c, bit) ((c).dbg & (bit))
-// diagnostic build: per-workgroup cycle stamps of waves 0 and 4 (one of each wave group), [block][2][16]
+// diagnostic build: per-workgroup cycle stamps of waves 0 and 4, [block][2][16] (profiles/conv_stamps.py)
 __device__ unsigned long long g_cv_stamps[2048 * 2 * 16];
 __device__ __forceinline__ unsigned long long cv_stamp()
 {
@@ -86,29 +98,39 @@ __device__ __forceinline__ unsigned long long cv_stamp()
     __builtin_amdgcn_sched_barrier(0);
     return t;
 }
-#define CV_SEG(c, acc_) do { if (CV_DBG(c, 16)) { unsigned long long t_ = cv_stamp(); (acc_) += t_ - seg_t; seg_t = t_; } } while (0)
 #else
 #define CV_DBG(c, bit) 0
-#define CV_SEG(c, acc_) do { } while (0)
 #endif
+
+template <int TAP> __device__ __forceinline__ CvTap cv_tap(const CvCtx &c, int abase)
+{
+    constexpr int delta = 9 * (TAP / 3 - 1) + (TAP % 3 - 1);
+    int br = c.brow;
+    asm volatile("" : "+v"(br)); // keep this arithmetic in the loop: hoisted for all nine taps it costs ~40 VGPRs
+    const int row = br + delta;
+    CvTap t;
+    t.base = abase + row * 128;
+    t.sw16 = (((row >> 1) & 7) ^ c.h) << 4;
+    return t;
+}
 
 // fragments of k-sub Q (16 k) of half-step (TAP, KH): 4 weight tiles (A operand) + 2 pixel tiles (B operand)
 template <int TAP, int KH, int Q>
-__device__ __forceinline__ void cv_read_frags(const CvCtx &c, int abase, int wslot, cv_half8 (&a)[4], cv_half8 (&b)[2])
+__device__ __forceinline__ void cv_read_frags(const CvCtx &c, const CvTap &t, int ring_slot, cv_half8 (&a)[4], cv_half8 (&b)[2])
 {
-    constexpr int delta = 9 * (TAP / 3 - 1) + (TAP % 3 - 1);
     const unsigned char *const lds = c.lds;
+    if (CV_DBG(c, 64)) return; // ablation: keep the stale fragments
+    if (!CV_DBG(c, 256)) {
+        const unsigned char *wa = lds + (ring_slot * kCvWBytes + c.a_off[Q]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = *(const cv_half8 *)(lds + (CV_DBG(c, 4) ? kCvZeroOff : wslot + c.a_off[Q] + i * 2048));
+        for (int i = 0; i < 4; ++i) a[i] = *(const cv_half8 *)(wa + i * 2048);
+    }
+    if (CV_DBG(c, 512)) return;
+    const int off0 = t.base + (t.sw16 ^ ((4 * KH + 2 * Q) << 4));
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        int br = c.brow[j];
-        asm volatile("" : "+v"(br)); // keep the per-tap address arithmetic in the loop (hoisted, it costs ~40 VGPRs)
-        const int row = br + delta;
-        const int t = (((row >> 1) & 7) ^ c.h) << 4;
-        // branch-free select between the slab row and the zero row (a tap that leaves the board)
-        const int keep = CV_DBG(c, 4) ? 0 : -(int)((c.vmask[j] >> TAP) & 1u);
-        const int off = ((abase + row * 128 + (t ^ ((4 * KH + 2 * Q) << 4)) - kCvZeroOff) & keep) + kCvZeroOff;
+        const bool ok = (c.vmask[j] >> TAP) & 1u; // a tap that leaves the board reads the zero row
+        const int off = ok ? off0 + j * 4096 : kCvZeroOff;
         b[j] = *(const cv_half8 *)(lds + off);
     }
 }
@@ -128,52 +150,44 @@ __device__ __forceinline__ void cv_mfma8(const CvCtx &c, cv_f32x16 (&acc)[4][2],
     }
 }
 
-// One half-step (32 k of one tap): on entry (a0, b0) hold its k-sub 0 fragments.
+// One half-step (32 k of one tap): on entry (a0, b0) hold its k-sub 0 fragments and `tap` its slab addressing.
 //   DMA issue (slab piece of the next chunk, weights 3 half-steps ahead) | read k-sub 1 -> (a1, b1) | 8 MFMA on (a0, b0)
 //   | counted vmcnt + barrier: the NEXT half-step's weights are now visible | read next k-sub 0 -> (a0, b0) | 8 MFMA on (a1, b1)
 template <int U>
-__device__ __forceinline__ void cv_halfstep(const CvCtx &c, cv_f32x16 (&acc)[4][2], int chunk, int &ring_rd, int &ring_wr,
-                                            cv_half8 (&a0)[4], cv_half8 (&b0)[2], cv_half8 (&a1)[4], cv_half8 (&b1)[2], unsigned long long (&seg)[6])
+__device__ __forceinline__ void cv_halfstep(const CvCtx &c, cv_f32x16 (&acc)[4][2], int chunk, int &ring_rd, int &ring_wr, CvTap &tap,
+                                            cv_half8 (&a0)[4], cv_half8 (&b0)[2], cv_half8 (&a1)[4], cv_half8 (&b1)[2])
 {
-#ifdef CCZ_STAMPS
-    unsigned long long seg_t = CV_DBG(c, 16) ? cv_stamp() : 0ull;
-#endif
-    constexpr int tap = U >> 1, kh = U & 1;
+    constexpr int TAP = U >> 1, KH = U & 1;
     unsigned char *const lds = c.lds;
 
     constexpr int pass = cv_act_pass(U);
     if constexpr (pass >= 0) if (!CV_DBG(c, 2)) {
         const int nxt = (chunk + 1) & 3; // the last chunk re-stages chunk 0 into the free buffer (keeps every count static)
-        cv_glds16(c.X + (c.xsrc[pass] + nxt * 64), lds + ((chunk + 1) & 1) * kCvABytes + (pass < 4 ? pass * 64 : 224) * 128 + c.wave_dst);
+        cv_glds16(c.X + (c.xsrc[pass] + nxt * 64), lds + kCvAOff + ((chunk + 1) & 1) * kCvABytes + (pass < 4 ? pass * 64 : 224) * 128 + c.wave_dst);
     }
     if (!CV_DBG(c, 1)) {
         // weights of half-step (this + kCvAhead); past the end of the tile the loads wrap to the start (unused)
         constexpr int U2 = (U + kCvAhead) % 18;
-        constexpr int tap2 = U2 >> 1, kh2 = U2 & 1;
         const int chunk2 = (chunk + (U + kCvAhead >= 18 ? 1 : 0)) & 3;
-        const _Float16 *s = c.wsrc + tap2 * kCvC + chunk2 * 64 + kh2 * 32;
-        unsigned char *d = lds + kCvWOff + ring_wr * kCvWBytes + c.wave_dst;
+        const _Float16 *s = c.wsrc + (U2 >> 1) * kCvC + chunk2 * 64 + (U2 & 1) * 32;
+        unsigned char *d = lds + ring_wr * kCvWBytes + c.wave_dst;
         cv_glds16(s, d);
         cv_glds16(s + 128l * (9 * kCvC), d + 8192);
     }
-    cv_read_frags<tap, kh, 1>(c, (chunk & 1) * kCvABytes, kCvWOff + ring_rd * kCvWBytes, a1, b1);
-    CV_SEG(c, seg[0]);
+    cv_read_frags<TAP, KH, 1>(c, tap, ring_rd, a1, b1);
     cv_mfma8(c, acc, a0, b0);
-    CV_SEG(c, seg[1]);
 
     ring_rd = ring_rd + 1 == kCvRing ? 0 : ring_rd + 1;
     ring_wr = ring_wr + 1 == kCvRing ? 0 : ring_wr + 1;
     cv_wait_vm<cv_vmcnt(U)>();
-    CV_SEG(c, seg[2]);
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
+    if (!CV_DBG(c, 32)) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    CV_SEG(c, seg[3]);
 
     constexpr int Un = (U + 1) % 18;
-    cv_read_frags<(Un >> 1), (Un & 1), 0>(c, ((chunk + (U == 17 ? 1 : 0)) & 1) * kCvABytes, kCvWOff + ring_rd * kCvWBytes, a0, b0);
+    if constexpr (KH == 1) tap = cv_tap<(Un >> 1)>(c, kCvAOff + ((chunk + (U == 17 ? 1 : 0)) & 1) * kCvABytes);
+    cv_read_frags<(Un >> 1), (Un & 1), 0>(c, tap, ring_rd, a0, b0);
     cv_mfma8(c, acc, a1, b1);
-    CV_SEG(c, seg[4]);
 }
 
 template <bool RES>
@@ -211,11 +225,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) c.a_off[q] = (wm * 128 + r) * 64 + (((2 * q + h) ^ ((r >> 2) & 3)) << 4);
+    c.brow = kCvHalo + wn * 64 + r;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int local = wn * 64 + j * 32 + r;
-        c.brow[j] = kCvHalo + local;
-        const int pos = (int)((p0 + local) % 90), rank = pos / 9, file = pos - rank * 9;
+        const int pos = (int)((p0 + wn * 64 + j * 32 + r) % 90), rank = pos / 9, file = pos - rank * 9;
         unsigned m = 0;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -239,11 +252,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict
     // ---- prologue: slab of chunk 0, weight half-tiles 0..2
     if (tid < 32) *(uint32_t *)(lds + kCvZeroOff + tid * 4) = 0u;
 #pragma unroll
-    for (int it = 0; it < 5; ++it) cv_glds16(X + c.xsrc[it], lds + (it < 4 ? it * 64 : 224) * 128 + c.wave_dst);
+    for (int it = 0; it < 5; ++it) cv_glds16(X + c.xsrc[it], lds + kCvAOff + (it < 4 ? it * 64 : 224) * 128 + c.wave_dst);
 #pragma unroll
     for (int u = 0; u < kCvAhead; ++u) {
         const _Float16 *s = c.wsrc + (u >> 1) * kCvC + (u & 1) * 32;
-        unsigned char *d = lds + kCvWOff + u * kCvWBytes + c.wave_dst;
+        unsigned char *d = lds + u * kCvWBytes + c.wave_dst;
         cv_glds16(s, d);
         cv_glds16(s + 128l * (9 * kCvC), d + 8192);
     }
@@ -254,26 +267,25 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict
     __builtin_amdgcn_sched_barrier(0);
 
     int ring_rd = 0, ring_wr = kCvAhead;
-    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
     cv_half8 a0[4], b0[2], a1[4], b1[2];
-    cv_read_frags<0, 0, 0>(c, 0, kCvWOff, a0, b0);
+    CvTap tap = cv_tap<0>(c, kCvAOff);
+    cv_read_frags<0, 0, 0>(c, tap, 0, a0, b0);
 #ifdef CCZ_STAMPS
     const unsigned long long st_loop0 = cv_stamp(), st_real0 = __builtin_amdgcn_s_memrealtime();
 #endif
     for (int chunk = 0; chunk < 4; ++chunk) {
-#define CV_HS(u) cv_halfstep<u>(c, acc, chunk, ring_rd, ring_wr, a0, b0, a1, b1, seg)
+#define CV_HS(u) cv_halfstep<u>(c, acc, chunk, ring_rd, ring_wr, tap, a0, b0, a1, b1)
         CV_HS(0); CV_HS(1); CV_HS(2); CV_HS(3); CV_HS(4); CV_HS(5); CV_HS(6); CV_HS(7); CV_HS(8);
         CV_HS(9); CV_HS(10); CV_HS(11); CV_HS(12); CV_HS(13); CV_HS(14); CV_HS(15); CV_HS(16); CV_HS(17);
 #undef CV_HS
     }
-    cv_wait_vm<0>();                            // the wrapped-around DMA loads must land before the LDS is released
+    cv_wait_vm<0>(); // the wrapped-around DMA loads must land before the LDS is reused / released
 #ifdef CCZ_STAMPS
     const unsigned long long st_loop1 = cv_stamp(), st_real1 = __builtin_amdgcn_s_memrealtime();
 #endif
 
     // ---- epilogue. Accumulator layout: lane = pixel (column r of tile j), register group g = output channels
-    // 8g + 4h .. + 3 of 32-row tile i. Each wave transposes its 64 pixel x 128 channel block through its own LDS region
-    // (272-byte rows) so that the residual is read and the output written as whole 256-byte pixel-row segments.
+    // 8g + 4h .. + 3 of 32-row tile i. Wave-private 272-byte-row LDS image of the 64 x 128 block, then whole rows out.
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier(); // every wave is done with the operand buffers
     __builtin_amdgcn_sched_barrier(0);
@@ -332,7 +344,6 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict
     if (blockIdx.x < 2048 && (tid == 0 || tid == 256)) {
         unsigned long long *o = g_cv_stamps + (blockIdx.x * 2 + (tid >> 8)) * 16;
         o[0] = st_loop0; o[1] = st_loop1; o[2] = st_end; o[3] = st_real0; o[4] = st_real1;
-        for (int k = 0; k < 5; ++k) o[5 + k] = seg[k];
         o[10] = st_prolog;
     }
 #endif

@@ -1,0 +1,76 @@
+"""A/B timing of builds of the tower convolution kernel in ONE process on ONE device (interleaved rounds).
+
+usage: python profiles/conv_ab.py libcczero.so libcczero_ab_x.so ... [--boards 4096] [--rounds 7] [--iters 10] [--res 1]
+Each library is dlopen'ed separately (after torch: one shared HIP runtime); every round times `iters` back-to-back
+launches of each library's ccz_conv3x3_c256_f16 with HIP events; the report is the median and minimum over rounds.
+The first library is also checked against a float32 torch convolution on a sample of boards, the others against the first.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import statistics
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load(name):
+    L = C.CDLL(os.path.join(ROOT, "chinesechesszero_amd", name))
+    L.ccz_conv3x3_c256_f16.restype = C.c_int
+    L.ccz_conv3x3_c256_f16.argtypes = [C.c_void_p] * 6 + [C.c_int64, C.c_int32]
+    return L
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("libs", nargs="+")
+    ap.add_argument("--boards", type=int, default=4096)
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--res", type=int, default=1)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(1)
+    cl = torch.channels_last
+    B = a.boards
+    x = (torch.randn(B, 256, 10, 9, generator=g) * 0.5).to(dev).half().contiguous(memory_format=cl)
+    res = (torch.randn(B, 256, 10, 9, generator=g) * 0.5).to(dev).half().contiguous(memory_format=cl)
+    w = (torch.randn(256, 256, 3, 3, generator=g) * 0.03).to(dev).half().contiguous(memory_format=cl)
+    bias = (torch.randn(256, generator=g) * 0.1).to(dev)
+    libs = [(n, load(n)) for n in a.libs]
+    ys = [torch.empty_like(x) for _ in libs]
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(L, y):
+        rc = L.ccz_conv3x3_c256_f16(s, x.data_ptr(), w.data_ptr(), bias.data_ptr(), res.data_ptr() if a.res else None, y.data_ptr(), B * 90, 1)
+        assert rc == 0
+
+    for (n, L), y in zip(libs, ys):
+        run(L, y)
+    torch.cuda.synchronize()
+    sample = sorted({0, 1, B // 2, B - 1})
+    ref = F.conv2d(x[sample].float(), w.float(), bias, padding=1)
+    ref = F.relu(ref + res[sample].float()) if a.res else F.relu(ref)
+    out = {"boards": B, "res": a.res, "err_vs_fp32": (ys[0][sample].float() - ref).abs().max().item(),
+           "max_diff_vs_first": [(y.float() - ys[0].float()).abs().max().item() for y in ys]}
+    times = {n: [] for n, _ in libs}
+    for _ in range(a.rounds):
+        for (n, L), y in zip(libs, ys):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            run(L, y)
+            e0.record()
+            for _ in range(a.iters):
+                run(L, y)
+            e1.record()
+            torch.cuda.synchronize()
+            times[n].append(e0.elapsed_time(e1) / a.iters * 1e3)
+    flops = 2.0 * B * 90 * 256 * 256 * 9
+    out["us"] = {n: {"median": statistics.median(t), "min": min(t), "tflops_median": flops / statistics.median(t) / 1e6} for n, t in times.items()}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
