@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md (6.29e12 measured copy peak)
+MFMA_PEAK_F16 = 2.5e15  # FLOP/s dense fp16/bf16, MI355X_MICROARCH.md (never the 2:1-sparsity figure)
 
 
 def parse():
@@ -262,6 +263,32 @@ def main():
     torch.cuda.synchronize()
     event_floor_us = float(np.median([x.elapsed_time(y) for x, y in fl])) * 1e3
 
+    # the evaluator's dominant kernel (2 x blocks launches per step): the fused tower convolution, timed live on this stream
+    # over the whole tower on the activations of a real leaf batch (ReLU-sparse data clocks higher than dense random data)
+    net_roofline = None
+    if a.evaluator == "net" and rank == 0 and a.channels == 256 and B >= 64 and os.environ.get("CCZ_FUSED_CONV", "1") != "0":
+        import torch.nn.functional as F
+        inf = pvn._infer
+        leaf = state["leaf"] if state["leaf"] is not None else e.select_leaves()
+        with torch.no_grad():
+            x = leaf.view(B, 119, 10, 9)
+            x = torch.cat([x[:, 49:56], x[:, 105:119]], dim=1).to(torch.float16).contiguous(memory_format=torch.channels_last)
+            x0 = inf._epilogue(F.conv2d(x, inf.stem_w, None, padding=1), inf.stem_b)
+            inf._tower_fused(x0.clone(memory_format=torch.preserve_format))
+            xs = [x0.clone(memory_format=torch.preserve_format) for _ in range(3)]
+            c0, c1 = ev(), ev()
+            c0.record()
+            for xi in xs:
+                inf._tower_fused(xi)
+            c1.record()
+        torch.cuda.synchronize()
+        t_conv = c0.elapsed_time(c1) * 1e-3 / (len(xs) * 2 * a.blocks)
+        conv_flops = 2.0 * B * 90 * 256 * 256 * 9
+        net_roofline = {"bound": "mfma", "kernel": "k_conv3x3_c256 (tower conv3x3 256->256 + bias + residual + ReLU, fp16 in / fp32 acc)",
+                        "achieved": conv_flops / t_conv / 1e12, "peak": MFMA_PEAK_F16 / 1e12, "unit": "TFLOP/s",
+                        "frac": conv_flops / t_conv / MFMA_PEAK_F16, "traffic": None, "avg_launch_us": t_conv * 1e6,
+                        "algorithmic_flops_per_launch": conv_flops, "launches_per_step": 2 * a.blocks}
+
     sims = s1["sims"] - s0["sims"]
     exp = max(1, s1["expansions"] - s0["expansions"])
     kbar = (s1["sum_children"] - s0["sum_children"]) / exp
@@ -287,7 +314,10 @@ def main():
         if os.path.exists(pmc):
             try:
                 with open(pmc) as f:
-                    traffic = json.load(f).get("k_step", {}).get("hbm_bytes_per_launch")
+                    pm = json.load(f)
+                traffic = pm.get("k_step", {}).get("hbm_bytes_per_launch")
+                if net_roofline is not None:  # HBM bytes of one convolution launch (PMC passes of profiles/run_profile.sh)
+                    net_roofline["traffic"] = pm.get("k_conv3x3", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         flops = 8.551e9 * (a.blocks / 40.0) * (a.channels / 256.0) ** 2
@@ -308,6 +338,7 @@ def main():
             "survey_a_sim_bytes": a_sim_survey,
             "step_split_us": {"k_step": t_step * 1e6, "evaluator": t_net * 1e6},
             "trainer_updates": (train_steps[0] if trainer is not None else 0),
+            "net_roofline": net_roofline,
             "net_tflops": (flops * B / t_net / 1e12) if (a.evaluator == "net" and t_net == t_net) else None,
             "engine_hbm_gb": s1["hbm_bytes"] / 1e9, "nodes_peak": s1["nodes_peak"], "depth_peak": s1["depth_peak"],
         }

@@ -1,7 +1,6 @@
 """Cycle stamps of the tower-convolution kernel (diagnostic build libcczero_stamps.so, never the shipped library).
 
-Per workgroup, waves 0 and 4 (one wave of each group): cycles of prologue / K loop / epilogue, in-kernel clock, and
--- with CONV_SEG=1 -- the K loop split into its five segments (stamps fence overlaps: read shares, not lengths).
+Per workgroup, waves 0 and 4: cycles of prologue / K loop / epilogue and the in-kernel clock (s_memtime / s_memrealtime).
 usage: python profiles/conv_stamps.py [boards]
 """
 import ctypes as C
@@ -32,7 +31,7 @@ def main():
     L.ccz_debug_conv_stamps.restype = C.c_int
     L.ccz_debug_conv_stamps.argtypes = [C.c_void_p]
     out = {}
-    for name, dbg in (("plain", 0), ("segments", 16)):
+    for name, dbg in (("plain", 0),):
         relu = 1 | (dbg << 8)
         for _ in range(200):  # keep the chip loaded so that the clock is the loaded clock
             _lib.check(L.ccz_conv3x3_c256_f16(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()),
@@ -47,11 +46,6 @@ def main():
         rec = {"tiles_sampled": int(tiles), "loop_cycles_median": float(np.median(loop)), "loop_cycles_per_halfstep": float(np.median(loop)) / 72,
                "prologue_cycles_median": float(np.median(st[:, :, 0] - st[:, :, 10])), "epilogue_cycles_median": float(np.median(st[:, :, 2] - st[:, :, 1])),
                "clock_ghz_median": float(np.median(loop / np.maximum(real, 1)) * 0.1)}
-        if dbg:
-            names = ["dma+read_k1(+drain)", "mfma_k0", "vmcnt_wait", "barrier", "read_next_k0+mfma_k1"]
-            for grp in (0, 1):
-                seg = st[:, grp, 5:10]
-                rec["group%d_segment_cycles_per_halfstep" % grp] = {n: float(np.median(seg[:, k])) / 72 for k, n in enumerate(names)}
         out[name] = rec
     print(json.dumps(out, indent=1))
 

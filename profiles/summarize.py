@@ -33,7 +33,7 @@ def main():
             w.writerows(keep)
         for r in rows:
             name = r.get("Name", "")
-            for k in ("k_step", "k_softmax_gather", "k_select", "k_expand_backup", "k_finish_move", "k_harvest", "k_bias_act"):
+            for k in ("k_step", "k_softmax_gather", "k_select", "k_expand_backup", "k_finish_move", "k_harvest", "k_bias_act", "k_conv3x3"):
                 if k in name:
                     summary.setdefault(k, {})["avg_ns"] = float(r.get("AverageNs", 0) or 0)
                     summary[k]["calls"] = int(float(r.get("Calls", 0) or 0))
@@ -47,7 +47,7 @@ def main():
             if r.get("Counter_Name") != counter:
                 continue
             name = r.get("Kernel_Name", "")
-            for k in ("k_step", "k_softmax_gather", "k_select", "k_expand_backup", "k_finish_move"):
+            for k in ("k_step", "k_softmax_gather", "k_select", "k_expand_backup", "k_finish_move", "k_conv3x3"):
                 if k in name:
                     acc[k][0] += float(r.get("Counter_Value", 0) or 0)
                     acc[k][1] += 1
