@@ -149,21 +149,56 @@ class InferenceNet(nn.Module):
         return bool(x.is_cuda and x.dtype == torch.float16 and x.shape[1] == 256 and x.shape[0] >= self.FUSED_MIN_BOARDS
                     and x.is_contiguous(memory_format=torch.channels_last))
 
+    TOWER_CHAINS = 2  # independent board ranges run as concurrent launch chains (one HIP stream each); env CCZ_TOWER_CHAINS (<= 8)
+
     def _tower_fused(self, x):
-        """40 residual blocks = 80 launches of one kernel: conv3x3 + bias [+ x] + ReLU each (reference net.py:20-43)."""
+        """40 residual blocks = 80 launches of one kernel: conv3x3 + bias [+ x] + ReLU each (reference net.py:20-43).
+
+        Boards are independent, so the batch is cut into ``TOWER_CHAINS`` contiguous board ranges whose 80-launch
+        chains run on separate HIP streams: the tile tail of one chain's layer (1440 tiles on 256 CUs = 5.6 rounds,
+        paid as 6 when every layer waits for the previous one) is filled by the other chain's tiles. In the bench
+        (4096 boards, 80 different weight sets): 1 chain 29.2 ms/step, 2 chains 27.9, 3: 28.0, 4: 28.5, 8: 28.6
+        (same-weights microbench profiles/conv_streams.py: 352 -> 319 -> 311 us per layer for 1 / 2 / 8 chains).
+        Inside a stream capture (hipGraph) one chain is used."""
         import ctypes as C
         from . import _lib
         L = _lib.lib()
-        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        n_pixels = x.shape[0] * 90
+        B = x.shape[0]
         y = torch.empty_like(x)
-        xp, yp = C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr())
+        cur = torch.cuda.current_stream(x.device)
+        want = int(os.environ.get("CCZ_TOWER_CHAINS", self.TOWER_CHAINS))
+        parts = 1 if torch.cuda.is_current_stream_capturing() else max(1, min(want, 8, B // 256))
+        step = -(-B // parts)
+        if parts > 1:
+            step = -(-step // 128) * 128  # 128 boards = 45 whole tiles: no partial tile inside the batch
+        bounds = [(b0, min(B, b0 + step)) for b0 in range(0, B, step)]
+        if len(bounds) > 1:
+            pool = getattr(self, "_chain_streams", None)
+            if pool is None or pool[0] != x.device or len(pool[1]) < len(bounds) - 1:
+                pool = (x.device, [torch.cuda.Stream(device=x.device) for _ in range(7)])
+                self._chain_streams = pool
+            fork = torch.cuda.Event()
+            fork.record(cur)
+        row = 90 * 256 * x.element_size()
+        chains = []
+        for k, (b0, b1) in enumerate(bounds):
+            st = cur if k == 0 else self._chain_streams[1][k - 1]
+            if k:
+                st.wait_event(fork)
+            chains.append((st, C.c_void_p(st.cuda_stream), C.c_void_p(x.data_ptr() + b0 * row), C.c_void_p(y.data_ptr() + b0 * row), (b1 - b0) * 90))
+        # launches are enqueued layer by layer across the chains, so that the chains advance together (the same layer's
+        # weights stay hot in L2) and no chain waits for the host to finish enqueuing another one
         for i in range(0, len(self.ws), 2):
-            _lib.check(L.ccz_conv3x3_c256_f16(stream, xp, C.c_void_p(self.ws[i].data_ptr()), C.c_void_p(self.bs32[i].data_ptr()),
-                                              None, yp, n_pixels, 1))
-            _lib.check(L.ccz_conv3x3_c256_f16(stream, yp, C.c_void_p(self.ws[i + 1].data_ptr()), C.c_void_p(self.bs32[i + 1].data_ptr()),
-                                              xp, xp, n_pixels, 1))  # output written over the residual input
-        return x
+            w1, b1_, w2, b2_ = (C.c_void_p(t.data_ptr()) for t in (self.ws[i], self.bs32[i], self.ws[i + 1], self.bs32[i + 1]))
+            for _, s, xp, yp, n_pixels in chains:
+                _lib.check(L.ccz_conv3x3_c256_f16(s, xp, w1, b1_, None, yp, n_pixels, 1))
+            for _, s, xp, yp, n_pixels in chains:
+                _lib.check(L.ccz_conv3x3_c256_f16(s, yp, w2, b2_, xp, xp, n_pixels, 1))  # output written over the residual input
+        for st, *_ in chains[1:]:
+            join = torch.cuda.Event()
+            join.record(st)
+            cur.wait_event(join)
+        return x  # every side stream has been joined into the current stream
 
     @torch.no_grad()
     def forward(self, leaf_input: torch.Tensor, return_logits: bool = False):

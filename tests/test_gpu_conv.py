@@ -110,3 +110,23 @@ def test_fused_tower_matches_reference_architecture_and_miopen_path(monkeypatch)
     assert lg_f.shape == (B, 2086)
     # small batches stay on the MIOpen path
     assert not inf._use_fused_tower(torch.empty(8, 256, 10, 9, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last))
+
+
+def test_fused_tower_board_ranges_on_several_streams_equal_one_chain():
+    """The tower cuts the batch into independent board ranges on separate HIP streams (net.py _tower_fused): same bits as
+    one chain, whatever the cut (a board's arithmetic does not depend on which tile it falls in)."""
+    from chinesechesszero_amd.net import InferenceNet, Net
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(6)
+    net = Net(256, 2).to(dev).eval()
+    inf = InferenceNet(net).to(dev).eval()
+    B = 600
+    x0 = torch.relu(torch.randn(B, 256, 10, 9, device=dev)).half().contiguous(memory_format=torch.channels_last)
+    outs = []
+    for chains in (1, 8, 3):
+        inf.TOWER_CHAINS = chains
+        inf._chain_streams = None
+        outs.append(inf._tower_fused(x0.clone(memory_format=torch.preserve_format)).clone())
+        torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.isfinite(outs[0].float()).all() and outs[0].abs().max().item() > 0
