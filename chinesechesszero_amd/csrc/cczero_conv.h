@@ -8,27 +8,32 @@
 //
 //   * D[co, pixel] = W[co, k] . X[k, pixel], k = (tap, ci): weights are the MFMA A operand (rows ->
 //     accumulator registers), pixels the B operand (columns -> lanes), so each lane ends up holding 4
-//     consecutive output channels of ONE pixel per register group.
+//     consecutive output channels of ONE pixel per accumulator tile.
 //   * one workgroup = 256 consecutive pixels x all 256 output channels; 8 waves as 2 (co) x 4 (pixels),
-//     a 128 x 64 accumulator block (4 x 2 tiles of v_mfma_f32_32x32x16_f16) per wave.
-//   * K order = 4 input-channel chunks of 64 (outer) x 9 taps x 2 halves of 32 (inner) = 72 half-steps.
+//     a 128 x 64 accumulator block per wave = 8 x 4 tiles of v_mfma_f32_16x16x32_f16 (128 VGPRs). The 16x16x32
+//     shape, not 32x32x16: this loop is power-limited and the chip holds a higher clock on it at equal cycles per
+//     FLOP (MI355X_MICROARCH.md, DVFS give-back item 7); measured -6.6 % time for the same tile and pipeline.
+//   * K order = 4 input-channel chunks of 64 (outer) x 9 taps x 2 halves of 32 (inner) = 72 half-steps; one
+//     half-step is ONE k-step of the MFMA: 8 weight fragments (lane l: row l & 15, k-chunk l >> 4 of a 64-byte
+//     weight row), 4 pixel fragments (pixel l & 15, k-chunk 4*KH + (l >> 4) of the 128-byte slab row), 32 MFMAs.
 //     The activation slab of a chunk (the tile's 256 pixels + a 10-pixel halo either side, 64 channels) is
 //     staged ONCE into LDS and read nine times at row offsets 9*dy + dx; a tap that leaves the board reads a
 //     zero row instead (per-lane 9-bit validity mask, no arithmetic on the data). Only the weights are
 //     staged per half-step, into a ring of five 16 KB half-tiles, three half-steps ahead.
 //   * both operands arrive by global_load_lds (16 B per lane, no VGPR round trip) into XOR-swizzled rows
-//     (swizzle applied to the SOURCE address and to the read address): conflict-free ds_read_b128.
-//   * software pipeline, one barrier per half-step: the fragments of the next 8-MFMA group are read while the
-//     current group issues; DMA loads stay in flight across barriers (raw s_barrier + counted s_waitcnt vmcnt,
-//     never 0 inside the loop).
+//     (swizzle applied to the SOURCE address and to the read address): conflict-free ds_read_b128 for the
+//     weights, at most 2-way on a few lanes for the pixels.
+//   * software pipeline, one barrier per half-step: [DMA issue | read weight tiles 4-7 | 16 MFMA on tiles 0-3]
+//     barrier [read the next half-step's weight tiles 0-3 and pixels | 16 MFMA on tiles 4-7]; DMA loads stay in
+//     flight across barriers (raw s_barrier + counted s_waitcnt vmcnt, never 0 inside the loop).
 //   * epilogue: each wave transposes its 64 pixel x 128 channel block through its own LDS region, so that the
 //     residual is read and the output written as whole 256-byte pixel-row segments.
 //
-// Measured alternatives that did NOT pay (profiles/conv_ab.py, one device, interleaved): staggering the DMA issue of
-// the two wave groups (-4.5 %), running the groups half a half-step apart (-2 %), s_setprio around the MFMA groups
-// (-11 %), sched_group_barrier-pinned interleave (-1.5 %), fragments read a whole half-step ahead into three
-// register sets (0 %), 16 zero rows (one per bank slot) for the masked lanes (-1 %), a ping-pong form with two barriers
-// per 8-MFMA group and the wave groups one barrier apart (-15 %).
+// Measured alternatives that did NOT pay (profiles/conv_ab.py, one device, interleaved; on the 32x32x16 form):
+// staggering the DMA issue of the two wave groups (-4.5 %), running the groups half a half-step apart (-2 %),
+// s_setprio around the MFMA groups (-11 %), sched_group_barrier-pinned interleave (-1.5 %), fragments read a
+// whole half-step ahead into three register sets (0 %), 16 zero rows (one per bank slot) for the masked lanes
+// (-1 %), a ping-pong form with two barriers per 8-MFMA group and the wave groups one barrier apart (-15 %).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -37,7 +42,6 @@ namespace ccz {
 
 typedef _Float16 cv_half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 cv_half4 __attribute__((ext_vector_type(4)));
-typedef float cv_f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kCvC = 256;             // channels in = channels out
 constexpr int kCvBM = 256;            // pixels per workgroup
@@ -50,9 +54,8 @@ constexpr int kCvAhead = 3;           // weight half-tiles in flight ahead of th
 constexpr int kCvAOff = kCvRing * kCvWBytes; // LDS: [weight ring | slab 0 | slab 1 | zero row]; the ring first, so that
                                              // the four weight reads of a k-sub share one address register (+ immediates)
 constexpr int kCvZeroOff = kCvAOff + 2 * kCvABytes;
-constexpr int kCvLds = kCvZeroOff + 128;
 constexpr int kCvERow = 272;          // epilogue transpose: bytes per pixel row of a wave's 64 x 128 block (256 + pad)
-static_assert(8 * 64 * kCvERow <= kCvLds, "epilogue transpose must fit the operand buffers");
+static_assert(8 * 64 * kCvERow <= kCvZeroOff, "epilogue transpose must fit the operand buffers");
 
 typedef __attribute__((address_space(3))) void *cv_lds_ptr;
 typedef const __attribute__((address_space(1))) void *cv_glb_ptr;
@@ -69,22 +72,10 @@ __host__ __device__ constexpr int cv_act_pass(int u) { return (u >= 2 && u <= 10
 __host__ __device__ constexpr int cv_vmcnt(int u) { return 4 + (cv_act_pass(u) >= 0 ? 1 : 0) + (cv_act_pass((u + 17) % 18) >= 0 ? 1 : 0); }
 template <int N> __device__ __forceinline__ void cv_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-struct CvCtx {
-    unsigned char *lds;
-    const _Float16 *X;
-    int xsrc[5];             // per staging pass: element offset of this thread's 16-byte source in X (chunk 0)
-    const _Float16 *wsrc;    // this thread's 16-byte source in W (row pass 0, tap 0, chunk 0, half 0)
-    int wave_dst;            // w * 1024
-    int h;                   // lane >> 5
-    int a_off[2];            // weight fragment offsets inside a ring slot (k-sub 0 / 1)
-    int brow;                // slab row of this lane's pixel of tile j = 0 at tap offset 0 (tile 1: + 32)
-    unsigned vmask[2];
-    int dbg;                 // diagnostic build (-DCCZ_STAMPS) only: ablation switches from bits 8.. of the relu argument
-};
 // slab addressing of one tap, shared by both pixel tiles and all four k-subs of the tap
 struct CvTap {
     int base; // LDS offset of the row of tile 0 at this tap
-    int sw16; // (((row >> 1) & 7) ^ h) << 4: swizzled position of chunk h
+    int sw16; // (((row >> 1) & 7) ^ q4) << 4: swizzled position of k-chunk q4
 };
 
 #ifdef CCZ_STAMPS
@@ -103,6 +94,22 @@ __device__ __forceinline__ unsigned long long cv_stamp()
 #define CV_DBG(c, bit) 0
 #endif
 
+typedef float cv_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kCvLds = kCvZeroOff + 3 * 2048 + 128; // zero rows at kCvZeroOff + n * 2048: the pixel-tile offset stays an immediate
+
+struct CvCtx {
+    unsigned char *lds;
+    const _Float16 *X;
+    int xsrc[5];       // per staging pass: element offset of this thread's 16-byte source in X (chunk 0)
+    const _Float16 *wsrc; // this thread's 16-byte source in W (row pass 0, tap 0, chunk 0, half 0)
+    int wave_dst;      // w * 1024
+    int q4;            // lane >> 4: this lane's k-chunk inside a 32-k step
+    int a_off;         // weight fragment offset inside a ring slot (tile 0; tile m: + 1024 m)
+    int brow;          // slab row of this lane's pixel of tile 0 at tap offset 0 (tile n: + 16 n)
+    unsigned vmask[4]; // per pixel tile: bit t set = tap t stays on the board
+    int dbg;           // diagnostic build (-DCCZ_STAMPS) only: ablation switches from bits 8.. of the relu argument
+};
+
 template <int TAP> __device__ __forceinline__ CvTap cv_tap(const CvCtx &c, int abase)
 {
     constexpr int delta = 9 * (TAP / 3 - 1) + (TAP % 3 - 1);
@@ -111,63 +118,59 @@ template <int TAP> __device__ __forceinline__ CvTap cv_tap(const CvCtx &c, int a
     const int row = br + delta;
     CvTap t;
     t.base = abase + row * 128;
-    t.sw16 = (((row >> 1) & 7) ^ c.h) << 4;
+    t.sw16 = (((row >> 1) & 7) ^ c.q4) << 4;
     return t;
 }
 
-// fragments of k-sub Q (16 k) of half-step (TAP, KH): 4 weight tiles (A operand) + 2 pixel tiles (B operand)
-template <int TAP, int KH, int Q>
-__device__ __forceinline__ void cv_read_frags(const CvCtx &c, const CvTap &t, int ring_slot, cv_half8 (&a)[4], cv_half8 (&b)[2])
+template <int HI> __device__ __forceinline__ void cv_read_w(const CvCtx &c, int ring_slot, cv_half8 (&a)[4])
 {
-    const unsigned char *const lds = c.lds;
-    if (CV_DBG(c, 64)) return; // ablation: keep the stale fragments
-    if (!CV_DBG(c, 256)) {
-        const unsigned char *wa = lds + (ring_slot * kCvWBytes + c.a_off[Q]);
+    if (CV_DBG(c, 64)) return;
+    const unsigned char *wa = c.lds + (ring_slot * kCvWBytes + c.a_off);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = *(const cv_half8 *)(wa + i * 2048);
-    }
-    if (CV_DBG(c, 512)) return;
-    const int off0 = t.base + (t.sw16 ^ ((4 * KH + 2 * Q) << 4));
+    for (int i = 0; i < 4; ++i) a[i] = *(const cv_half8 *)(wa + (HI * 4 + i) * 1024);
+}
+
+template <int TAP, int KH> __device__ __forceinline__ void cv_read_x(const CvCtx &c, const CvTap &t, cv_half8 (&b)[4])
+{
+    if (CV_DBG(c, 64)) return;
+    const int off0 = t.base + (t.sw16 ^ (KH << 6));
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const bool ok = (c.vmask[j] >> TAP) & 1u; // a tap that leaves the board reads the zero row
-        const int off = ok ? off0 + j * 4096 : kCvZeroOff;
-        b[j] = *(const cv_half8 *)(lds + off);
+    for (int n = 0; n < 4; ++n) {
+        const bool ok = (c.vmask[n] >> TAP) & 1u; // a tap that leaves the board reads a zero row
+        const int off = ok ? off0 : kCvZeroOff;
+        b[n] = *(const cv_half8 *)(c.lds + off + n * 2048);
     }
 }
 
-__device__ __forceinline__ void cv_mfma8(const CvCtx &c, cv_f32x16 (&acc)[4][2], const cv_half8 (&a)[4], const cv_half8 (&b)[2])
+template <int HI>
+__device__ __forceinline__ void cv_mfma16(const CvCtx &c, cv_f32x4 (&acc)[8][4], const cv_half8 (&a)[4], const cv_half8 (&b)[4])
 {
     if (!CV_DBG(c, 8)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int n = 0; n < 4; ++n) acc[HI * 4 + i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[n], acc[HI * 4 + i][n], 0, 0, 0);
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(a[i]));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(b[j]));
+        for (int n = 0; n < 4; ++n) asm volatile("" ::"v"(b[n]));
     }
 }
 
-// One half-step (32 k of one tap): on entry (a0, b0) hold its k-sub 0 fragments and `tap` its slab addressing.
-//   DMA issue (slab piece of the next chunk, weights 3 half-steps ahead) | read k-sub 1 -> (a1, b1) | 8 MFMA on (a0, b0)
-//   | counted vmcnt + barrier: the NEXT half-step's weights are now visible | read next k-sub 0 -> (a0, b0) | 8 MFMA on (a1, b1)
 template <int U>
-__device__ __forceinline__ void cv_halfstep(const CvCtx &c, cv_f32x16 (&acc)[4][2], int chunk, int &ring_rd, int &ring_wr, CvTap &tap,
-                                            cv_half8 (&a0)[4], cv_half8 (&b0)[2], cv_half8 (&a1)[4], cv_half8 (&b1)[2])
+__device__ __forceinline__ void cv_halfstep(const CvCtx &c, cv_f32x4 (&acc)[8][4], int chunk, int &ring_rd, int &ring_wr, CvTap &tap,
+                                              cv_half8 (&alo)[4], cv_half8 (&ahi)[4], cv_half8 (&bcur)[4], cv_half8 (&bnxt)[4])
 {
-    constexpr int TAP = U >> 1, KH = U & 1;
+    constexpr int KH = U & 1;
     unsigned char *const lds = c.lds;
 
     constexpr int pass = cv_act_pass(U);
     if constexpr (pass >= 0) if (!CV_DBG(c, 2)) {
-        const int nxt = (chunk + 1) & 3; // the last chunk re-stages chunk 0 into the free buffer (keeps every count static)
+        const int nxt = (chunk + 1) & 3;
         cv_glds16(c.X + (c.xsrc[pass] + nxt * 64), lds + kCvAOff + ((chunk + 1) & 1) * kCvABytes + (pass < 4 ? pass * 64 : 224) * 128 + c.wave_dst);
     }
     if (!CV_DBG(c, 1)) {
-        // weights of half-step (this + kCvAhead); past the end of the tile the loads wrap to the start (unused)
         constexpr int U2 = (U + kCvAhead) % 18;
         const int chunk2 = (chunk + (U + kCvAhead >= 18 ? 1 : 0)) & 3;
         const _Float16 *s = c.wsrc + (U2 >> 1) * kCvC + chunk2 * 64 + (U2 & 1) * 32;
@@ -175,8 +178,8 @@ __device__ __forceinline__ void cv_halfstep(const CvCtx &c, cv_f32x16 (&acc)[4][
         cv_glds16(s, d);
         cv_glds16(s + 128l * (9 * kCvC), d + 8192);
     }
-    cv_read_frags<TAP, KH, 1>(c, tap, ring_rd, a1, b1);
-    cv_mfma8(c, acc, a0, b0);
+    cv_read_w<1>(c, ring_rd, ahi);
+    cv_mfma16<0>(c, acc, alo, bcur);
 
     ring_rd = ring_rd + 1 == kCvRing ? 0 : ring_rd + 1;
     ring_wr = ring_wr + 1 == kCvRing ? 0 : ring_wr + 1;
@@ -187,19 +190,20 @@ __device__ __forceinline__ void cv_halfstep(const CvCtx &c, cv_f32x16 (&acc)[4][
 
     constexpr int Un = (U + 1) % 18;
     if constexpr (KH == 1) tap = cv_tap<(Un >> 1)>(c, kCvAOff + ((chunk + (U == 17 ? 1 : 0)) & 1) * kCvABytes);
-    cv_read_frags<(Un >> 1), (Un & 1), 0>(c, tap, ring_rd, a0, b0);
-    cv_mfma8(c, acc, a1, b1);
+    cv_read_w<0>(c, ring_rd, alo);
+    cv_read_x<(Un >> 1), (Un & 1)>(c, tap, bnxt);
+    cv_mfma16<1>(c, acc, ahi, bcur);
 }
 
 template <bool RES>
 __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict__ X, const _Float16 *__restrict__ W,
-                                                      const float *__restrict__ bias, const _Float16 *R,
-                                                      _Float16 *Y, int M, int relu)
+                                                          const float *__restrict__ bias, const _Float16 *R,
+                                                          _Float16 *Y, int M, int relu)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kCvLds];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
+    const int r = lane & 15, q4 = lane >> 4;
     const int wm = w >> 2, wn = w & 3;
     const long p0 = (long)blockIdx.x * kCvBM;
 
@@ -207,51 +211,50 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict
     c.lds = lds;
     c.X = X;
     c.wave_dst = w * 1024;
-    c.h = h;
+    c.q4 = q4;
     c.dbg = relu >> 8;
     relu &= 1;
     {
-        // activation slab: 128-byte rows, 8 lanes per row, 64 rows per pass; chunk position cpos holds source chunk cpos ^ ((row >> 1) & 7)
         const int srow = tid >> 3, cpos = tid & 7;
         const int schunk = cpos ^ ((srow >> 1) & 7);
 #pragma unroll
         for (int it = 0; it < 5; ++it) {
             long p = p0 - kCvHalo + (it < 4 ? it * 64 : 224) + srow;
-            p = p < 0 ? 0 : (p > (long)M - 1 ? (long)M - 1 : p); // clamped rows are only ever read by masked taps / unstored pixels
+            p = p < 0 ? 0 : (p > (long)M - 1 ? (long)M - 1 : p);
             c.xsrc[it] = (int)(p * kCvC + schunk * 8);
         }
-        // weight half-tile: 64-byte rows, 4 lanes per row, 128 rows per pass; position cpos holds source chunk cpos ^ ((row >> 2) & 3)
+        // weight half-tile: 64-byte rows; position wpos of row holds source chunk wpos ^ f(row), f = (-(row >> 2)) & 3:
+        // conflict-free for the 16 rows x 4 chunks block one ds_read_b128 of this MFMA shape covers
         const int wrow = tid >> 2, wpos = tid & 3;
-        c.wsrc = W + (long)wrow * (9 * kCvC) + ((wpos ^ ((wrow >> 2) & 3)) * 8);
+        c.wsrc = W + (long)wrow * (9 * kCvC) + ((wpos ^ ((0 - (wrow >> 2)) & 3)) * 8);
     }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) c.a_off[q] = (wm * 128 + r) * 64 + (((2 * q + h) ^ ((r >> 2) & 3)) << 4);
+    c.a_off = (wm * 128 + r) * 64 + ((q4 ^ ((0 - (r >> 2)) & 3)) << 4);
     c.brow = kCvHalo + wn * 64 + r;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int pos = (int)((p0 + wn * 64 + j * 32 + r) % 90), rank = pos / 9, file = pos - rank * 9;
+    for (int n = 0; n < 4; ++n) {
+        const int pos = (int)((p0 + wn * 64 + n * 16 + r) % 90), rank = pos / 9, file = pos - rank * 9;
         unsigned m = 0;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int dy = t / 3 - 1, dx = t % 3 - 1;
             if (rank + dy >= 0 && rank + dy <= 9 && file + dx >= 0 && file + dx <= 8) m |= 1u << t;
         }
-        c.vmask[j] = m;
+        c.vmask[n] = m;
     }
 
-    cv_f32x16 acc[4][2];
+    cv_f32x4 acc[8][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int n = 0; n < 4; ++n)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 4; ++e) acc[i][n][e] = 0.f;
 
 #ifdef CCZ_STAMPS
     const unsigned long long st_prolog = cv_stamp();
 #endif
-    // ---- prologue: slab of chunk 0, weight half-tiles 0..2
-    if (tid < 32) *(uint32_t *)(lds + kCvZeroOff + tid * 4) = 0u;
+    // ---- prologue: slab of chunk 0, weight half-tiles 0..2, the four zero rows
+    if (tid < 128) *(uint32_t *)(lds + kCvZeroOff + (tid >> 5) * 2048 + (tid & 31) * 4) = 0u;
 #pragma unroll
     for (int it = 0; it < 5; ++it) cv_glds16(X + c.xsrc[it], lds + kCvAOff + (it < 4 ? it * 64 : 224) * 128 + c.wave_dst);
 #pragma unroll
@@ -268,54 +271,53 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict
     __builtin_amdgcn_sched_barrier(0);
 
     int ring_rd = 0, ring_wr = kCvAhead;
-    cv_half8 a0[4], b0[2], a1[4], b1[2];
+    cv_half8 alo[4], ahi[4], b0[4], b1[4];
     CvTap tap = cv_tap<0>(c, kCvAOff);
-    cv_read_frags<0, 0, 0>(c, tap, 0, a0, b0);
+    cv_read_w<0>(c, 0, alo);
+    cv_read_x<0, 0>(c, tap, b0);
 #ifdef CCZ_STAMPS
     const unsigned long long st_loop0 = cv_stamp(), st_real0 = __builtin_amdgcn_s_memrealtime();
 #endif
     for (int chunk = 0; chunk < 4; ++chunk) {
-#define CV_HS(u) cv_halfstep<u>(c, acc, chunk, ring_rd, ring_wr, tap, a0, b0, a1, b1)
-        CV_HS(0); CV_HS(1); CV_HS(2); CV_HS(3); CV_HS(4); CV_HS(5); CV_HS(6); CV_HS(7); CV_HS(8);
-        CV_HS(9); CV_HS(10); CV_HS(11); CV_HS(12); CV_HS(13); CV_HS(14); CV_HS(15); CV_HS(16); CV_HS(17);
-#undef CV_HS
+#define CV_HE(u) cv_halfstep<u>(c, acc, chunk, ring_rd, ring_wr, tap, alo, ahi, b0, b1)
+#define CV_HO(u) cv_halfstep<u>(c, acc, chunk, ring_rd, ring_wr, tap, alo, ahi, b1, b0)
+        CV_HE(0); CV_HO(1); CV_HE(2); CV_HO(3); CV_HE(4); CV_HO(5); CV_HE(6); CV_HO(7); CV_HE(8);
+        CV_HO(9); CV_HE(10); CV_HO(11); CV_HE(12); CV_HO(13); CV_HE(14); CV_HO(15); CV_HE(16); CV_HO(17);
+#undef CV_HE
+#undef CV_HO
     }
     cv_wait_vm<0>(); // the wrapped-around DMA loads must land before the LDS is reused / released
 #ifdef CCZ_STAMPS
     const unsigned long long st_loop1 = cv_stamp(), st_real1 = __builtin_amdgcn_s_memrealtime();
 #endif
 
-    // ---- epilogue. Accumulator layout: lane = pixel (column r of tile j), register group g = output channels
-    // 8g + 4h .. + 3 of 32-row tile i. Wave-private 272-byte-row LDS image of the 64 x 128 block, then whole rows out.
+    // ---- epilogue: lane = pixel l & 15 of tile n, registers e = output channels 16 m + 4 (l >> 4) + e
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier(); // every wave is done with the operand buffers
+    __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     unsigned char *const eb = lds + w * (64 * kCvERow);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int m = 0; m < 8; ++m) {
+        const int col = m * 16 + 4 * q4;
+        const float4 bv = *(const float4 *)(bias + wm * 128 + col);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int col = i * 32 + 8 * g + 4 * h;
-            const float4 bv = *(const float4 *)(bias + wm * 128 + col);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                cv_half4 o;
-                o[0] = (_Float16)(acc[i][j][4 * g + 0] + bv.x);
-                o[1] = (_Float16)(acc[i][j][4 * g + 1] + bv.y);
-                o[2] = (_Float16)(acc[i][j][4 * g + 2] + bv.z);
-                o[3] = (_Float16)(acc[i][j][4 * g + 3] + bv.w);
-                *(cv_half4 *)(eb + (j * 32 + r) * kCvERow + col * 2) = o;
-            }
+        for (int n = 0; n < 4; ++n) {
+            cv_half4 o;
+            o[0] = (_Float16)(acc[m][n][0] + bv.x);
+            o[1] = (_Float16)(acc[m][n][1] + bv.y);
+            o[2] = (_Float16)(acc[m][n][2] + bv.z);
+            o[3] = (_Float16)(acc[m][n][3] + bv.w);
+            *(cv_half4 *)(eb + (n * 16 + r) * kCvERow + col * 2) = o;
         }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // wave-private region: no barrier needed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     {
         const int prow = lane >> 4, piece = lane & 15;
         const long pbase = p0 + wn * 64 + prow;
         const long gcol = wm * 128 + piece * 8;
         const cv_half8 zero = (cv_half8)(_Float16)0;
-        if (p0 + kCvBM <= M) { // whole tile inside the tensor (always, when boards * 90 is a multiple of 256)
+        if (p0 + kCvBM <= M) {
             cv_half8 rv[16];
             if (RES) {
 #pragma unroll

@@ -31,7 +31,7 @@ def main():
     L.ccz_debug_conv_stamps.restype = C.c_int
     L.ccz_debug_conv_stamps.argtypes = [C.c_void_p]
     out = {}
-    for name, dbg in (("plain", 0),):
+    for name, dbg in [("plain", 0)] + [("dbg%d" % int(v), int(v)) for v in os.environ.get("CONV_DBG", "").split(",") if v]:
         relu = 1 | (dbg << 8)
         for _ in range(200):  # keep the chip loaded so that the clock is the loaded clock
             _lib.check(L.ccz_conv3x3_c256_f16(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()),
