@@ -33,7 +33,8 @@
 // staggering the DMA issue of the two wave groups (-4.5 %), running the groups half a half-step apart (-2 %),
 // s_setprio around the MFMA groups (-11 %), sched_group_barrier-pinned interleave (-1.5 %), fragments read a
 // whole half-step ahead into three register sets (0 %), 16 zero rows (one per bank slot) for the masked lanes
-// (-1 %), a ping-pong form with two barriers per 8-MFMA group and the wave groups one barrier apart (-15 %).
+// (-1 %), a ping-pong form with two barriers per 8-MFMA group and the wave groups one barrier apart (-15 %); on this
+// form: one barrier per TWO half-steps (the ring of 5 allows it) (-1.6 %).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
