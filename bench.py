@@ -287,7 +287,9 @@ def main():
         net_roofline = {"bound": "mfma", "kernel": "k_conv3x3_c256 (tower conv3x3 256->256 + bias + residual + ReLU, fp16 in / fp32 acc)",
                         "achieved": conv_flops / t_conv / 1e12, "peak": MFMA_PEAK_F16 / 1e12, "unit": "TFLOP/s",
                         "frac": conv_flops / t_conv / MFMA_PEAK_F16, "traffic": None, "avg_launch_us": t_conv * 1e6,
-                        "algorithmic_flops_per_launch": conv_flops, "launches_per_step": 2 * a.blocks}
+                        "algorithmic_flops_per_launch": conv_flops, "launches_per_step": 2 * a.blocks,
+                        "chains": max(1, min(int(os.environ.get("CCZ_TOWER_CHAINS", inf.TOWER_CHAINS)), 8, B // 256)),
+                        "note": "a 'launch' is one layer over the whole batch, issued as `chains` concurrent kernel launches over board ranges"}
 
     sims = s1["sims"] - s0["sims"]
     exp = max(1, s1["expansions"] - s0["expansions"])
@@ -317,7 +319,8 @@ def main():
                     pm = json.load(f)
                 traffic = pm.get("k_step", {}).get("hbm_bytes_per_launch")
                 if net_roofline is not None:  # HBM bytes of one convolution launch (PMC passes of profiles/run_profile.sh)
-                    net_roofline["traffic"] = pm.get("k_conv3x3", {}).get("hbm_bytes_per_launch")
+                    per_kernel = pm.get("k_conv3x3", {}).get("hbm_bytes_per_launch")
+                    net_roofline["traffic"] = per_kernel * net_roofline["chains"] if per_kernel else None
             except Exception:
                 traffic = None
         flops = 8.551e9 * (a.blocks / 40.0) * (a.channels / 256.0) ** 2
