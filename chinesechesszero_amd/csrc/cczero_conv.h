@@ -208,6 +208,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict
     const int wm = w >> 2, wn = w & 3;
     const long p0 = (long)blockIdx.x * kCvBM;
 
+#ifdef CCZ_STAMPS
+    const unsigned long long st_prolog = cv_stamp();
+#endif
     CvCtx c;
     c.lds = lds;
     c.X = X;
@@ -228,6 +231,18 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict
         // conflict-free for the 16 rows x 4 chunks block one ds_read_b128 of this MFMA shape covers
         const int wrow = tid >> 2, wpos = tid & 3;
         c.wsrc = W + (long)wrow * (9 * kCvC) + ((wpos ^ ((0 - (wrow >> 2)) & 3)) * 8);
+    }
+    // ---- prologue: slab of chunk 0, weight half-tiles 0..2, the four zero rows; the DMA is issued first, the
+    // per-lane setup below runs while it is in flight
+    if (tid < 128) *(uint32_t *)(lds + kCvZeroOff + (tid >> 5) * 2048 + (tid & 31) * 4) = 0u;
+#pragma unroll
+    for (int it = 0; it < 5; ++it) cv_glds16(X + c.xsrc[it], lds + kCvAOff + (it < 4 ? it * 64 : 224) * 128 + c.wave_dst);
+#pragma unroll
+    for (int u = 0; u < kCvAhead; ++u) {
+        const _Float16 *s = c.wsrc + (u >> 1) * kCvC + (u & 1) * 32;
+        unsigned char *d = lds + u * kCvWBytes + c.wave_dst;
+        cv_glds16(s, d);
+        cv_glds16(s + 128l * (9 * kCvC), d + 8192);
     }
     c.a_off = (wm * 128 + r) * 64 + ((q4 ^ ((0 - (r >> 2)) & 3)) << 4);
     c.brow = kCvHalo + wn * 64 + r;
@@ -251,20 +266,6 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][n][e] = 0.f;
 
-#ifdef CCZ_STAMPS
-    const unsigned long long st_prolog = cv_stamp();
-#endif
-    // ---- prologue: slab of chunk 0, weight half-tiles 0..2, the four zero rows
-    if (tid < 128) *(uint32_t *)(lds + kCvZeroOff + (tid >> 5) * 2048 + (tid & 31) * 4) = 0u;
-#pragma unroll
-    for (int it = 0; it < 5; ++it) cv_glds16(X + c.xsrc[it], lds + kCvAOff + (it < 4 ? it * 64 : 224) * 128 + c.wave_dst);
-#pragma unroll
-    for (int u = 0; u < kCvAhead; ++u) {
-        const _Float16 *s = c.wsrc + (u >> 1) * kCvC + (u & 1) * 32;
-        unsigned char *d = lds + u * kCvWBytes + c.wave_dst;
-        cv_glds16(s, d);
-        cv_glds16(s + 128l * (9 * kCvC), d + 8192);
-    }
     cv_wait_vm<4>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -293,6 +294,15 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict
 #endif
 
     // ---- epilogue: lane = pixel l & 15 of tile n, registers e = output channels 16 m + 4 (l >> 4) + e
+    const int prow = lane >> 4, piece = lane & 15;
+    const long pbase = p0 + wn * 64 + prow;
+    const long gcol = wm * 128 + piece * 8;
+    const bool full = p0 + kCvBM <= M; // whole tile inside the tensor (always, when boards * 90 is a multiple of 256)
+    cv_half8 rv[16];
+    if (RES && full) { // the residual rows are requested before the transposition, which hides their latency
+#pragma unroll
+        for (int it = 0; it < 16; ++it) rv[it] = *(const cv_half8 *)(R + (pbase + it * 4) * kCvC + gcol);
+    }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -314,16 +324,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     {
-        const int prow = lane >> 4, piece = lane & 15;
-        const long pbase = p0 + wn * 64 + prow;
-        const long gcol = wm * 128 + piece * 8;
         const cv_half8 zero = (cv_half8)(_Float16)0;
-        if (p0 + kCvBM <= M) {
-            cv_half8 rv[16];
-            if (RES) {
-#pragma unroll
-                for (int it = 0; it < 16; ++it) rv[it] = *(const cv_half8 *)(R + (pbase + it * 4) * kCvC + gcol);
-            }
+        if (full) {
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
                 cv_half8 v = *(const cv_half8 *)(eb + (it * 4 + prow) * kCvERow + piece * 16);
