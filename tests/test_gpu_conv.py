@@ -130,3 +130,26 @@ def test_fused_tower_board_ranges_on_several_streams_equal_one_chain():
         torch.cuda.synchronize()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     assert torch.isfinite(outs[0].float()).all() and outs[0].abs().max().item() > 0
+
+
+def test_conv_kernel_full_size_board_permutation_and_sample():
+    """BASELINE size (4096 boards = 1440 tiles): (1) boards are independent, so permuting the boards of the input permutes
+    the output bit for bit, whatever tile / wave / lane a board lands in; (2) a sample of boards against float32."""
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(11)
+    cl = torch.channels_last
+    B = 4096
+    x = torch.relu(torch.randn(B, 256, 10, 9, generator=g) * 0.7).to(dev).half().contiguous(memory_format=cl)
+    r = (torch.randn(B, 256, 10, 9, generator=g) * 0.7).to(dev).half().contiguous(memory_format=cl)
+    w = (torch.randn(256, 256, 3, 3, generator=g) * 0.03).to(dev).half().contiguous(memory_format=cl)
+    b = (torch.randn(256, generator=g) * 0.2).to(dev)
+    y = _conv(x, w, b, r, torch.empty_like(x), 1)
+    perm = torch.randperm(B, generator=g).to(dev)
+    xp = x[perm].contiguous(memory_format=cl)
+    rp = r[perm].contiguous(memory_format=cl)
+    yp = _conv(xp, w, b, rp, torch.empty_like(x), 1)
+    assert torch.equal(yp, y[perm])
+    sample = [0, 1, 2, 1023, 2047, 2048, 4094, 4095]
+    want = F.relu(F.conv2d(x[sample].float(), w.float(), b, padding=1) + r[sample].float())
+    assert (y[sample].float() - want).abs().max().item() < 4e-3 * max(1.0, want.abs().max().item())
+    assert torch.isfinite(y.float()).all()
