@@ -21,8 +21,8 @@
 //     zero row instead (per-lane 9-bit validity mask, no arithmetic on the data). Only the weights are
 //     staged per half-step, into a ring of five 16 KB half-tiles, three half-steps ahead.
 //   * both operands arrive by global_load_lds (16 B per lane, no VGPR round trip) into XOR-swizzled rows
-//     (swizzle applied to the SOURCE address and to the read address): conflict-free ds_read_b128 for the
-//     weights, at most 2-way on a few lanes for the pixels.
+//     (swizzle applied to the SOURCE address and to the read address): conflict-free ds_read_b128 for both
+//     operands at any tap offset (weights: chunk c of row r at c ^ (-(r >> 2) & 3); slab: c ^ (r & 7)).
 //   * software pipeline, one barrier per half-step: [DMA issue | read weight tiles 4-7 | 16 MFMA on tiles 0-3]
 //     barrier [read the next half-step's weight tiles 0-3 and pixels | 16 MFMA on tiles 4-7]; DMA loads stay in
 //     flight across barriers (raw s_barrier + counted s_waitcnt vmcnt, never 0 inside the loop).
@@ -76,7 +76,7 @@ template <int N> __device__ __forceinline__ void cv_wait_vm() { asm volatile("s_
 // slab addressing of one tap, shared by both pixel tiles and all four k-subs of the tap
 struct CvTap {
     int base; // LDS offset of the row of tile 0 at this tap
-    int sw16; // (((row >> 1) & 7) ^ q4) << 4: swizzled position of k-chunk q4
+    int sw16; // ((row & 7) ^ q4) << 4: swizzled position of k-chunk q4
 };
 
 #ifdef CCZ_STAMPS
@@ -119,7 +119,7 @@ template <int TAP> __device__ __forceinline__ CvTap cv_tap(const CvCtx &c, int a
     const int row = br + delta;
     CvTap t;
     t.base = abase + row * 128;
-    t.sw16 = (((row >> 1) & 7) ^ c.q4) << 4;
+    t.sw16 = ((row & 7) ^ c.q4) << 4;
     return t;
 }
 
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict
     relu &= 1;
     {
         const int srow = tid >> 3, cpos = tid & 7;
-        const int schunk = cpos ^ ((srow >> 1) & 7);
+        const int schunk = cpos ^ (srow & 7); // slab row r holds source chunk c at position c ^ (r & 7)
 #pragma unroll
         for (int it = 0; it < 5; ++it) {
             long p = p0 - kCvHalo + (it < 4 ? it * 64 : 224) + srow;
