@@ -531,8 +531,8 @@ int ccz_bias_act_f16(void *stream, void *y_dev, const void *bias_dev, const void
 int ccz_conv3x3_c256_f16(void *stream, const void *x_dev, const void *w_dev, const void *bias_f32_dev, const void *residual_dev, void *y_dev,
                          int64_t n_pixels, int32_t relu)
 {
-    if (!x_dev || !w_dev || !bias_f32_dev || !y_dev || n_pixels < 0 || n_pixels % 90 || n_pixels > (int64_t)INT32_MAX / 2)
-        return fail(-1, "ccz_conv3x3_c256_f16: bad arguments (n_pixels must be boards * 90)");
+    if (!x_dev || !w_dev || !bias_f32_dev || !y_dev || n_pixels < 0 || n_pixels % 90 || n_pixels > (int64_t)INT32_MAX / kCvC) /* 32-bit element offsets in the kernel */
+        return fail(-1, "ccz_conv3x3_c256_f16: bad arguments (n_pixels must be boards * 90, at most 93206 boards per call)");
     if ((((uintptr_t)x_dev) | ((uintptr_t)w_dev) | ((uintptr_t)bias_f32_dev) | ((uintptr_t)residual_dev) | ((uintptr_t)y_dev)) & 15)
         return fail(-1, "ccz_conv3x3_c256_f16: pointers must be 16-byte aligned");
     if (x_dev == y_dev) return fail(-1, "ccz_conv3x3_c256_f16: the output may alias the residual but not the input");

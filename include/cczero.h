@@ -235,7 +235,8 @@ int ccz_bias_act_f16(void *stream, void *y_dev, const void *bias_dev, const void
  * with taps that leave the board contributing zero; act = ReLU when relu != 0 (reference net.py:20-43,
  * ResBlock conv -> BN(folded) -> [+x] -> ReLU; replaces F.conv2d + ccz_bias_act_f16 for these layers).
  * x, y, residual: [n_pixels, 256] fp16 (n_pixels = boards * 90); w: [256, 3, 3, 256] fp16 (the memory of a
- * channels-last [co, ci, 3, 3] tensor); bias: float32 [256]. y may alias residual, not x. */
+ * channels-last [co, ci, 3, 3] tensor); bias: float32 [256]. y may alias residual, not x. At most 93,206 boards
+ * per call (32-bit element offsets). */
 int ccz_conv3x3_c256_f16(void *stream, const void *x_dev, const void *w_dev, const void *bias_f32_dev,
                          const void *residual_dev, void *y_dev, int64_t n_pixels, int32_t relu);
 
