@@ -34,7 +34,8 @@
 // s_setprio around the MFMA groups (-11 %), sched_group_barrier-pinned interleave (-1.5 %), fragments read a
 // whole half-step ahead into three register sets (0 %), 16 zero rows (one per bank slot) for the masked lanes
 // (-1 %), a ping-pong form with two barriers per 8-MFMA group and the wave groups one barrier apart (-15 %); on this
-// form: one barrier per TWO half-steps (the ring of 5 allows it) (-1.6 %).
+// form: one barrier per TWO half-steps (the ring of 5 allows it) (-1.6 %), a split barrier on an LDS arrival counter
+// (arrive after the DMA wait, 8 MFMAs, then poll) instead of s_barrier (-23 %).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -185,11 +186,11 @@ __device__ __forceinline__ void cv_halfstep(const CvCtx &c, cv_f32x4 (&acc)[8][4
     ring_rd = ring_rd + 1 == kCvRing ? 0 : ring_rd + 1;
     ring_wr = ring_wr + 1 == kCvRing ? 0 : ring_wr + 1;
     cv_wait_vm<cv_vmcnt(U)>();
+    constexpr int Un = (U + 1) % 18;
     __builtin_amdgcn_sched_barrier(0);
     if (!CV_DBG(c, 32)) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
-    constexpr int Un = (U + 1) % 18;
     if constexpr (KH == 1) tap = cv_tap<(Un >> 1)>(c, kCvAOff + ((chunk + (U == 17 ? 1 : 0)) & 1) * kCvABytes);
     cv_read_w<0>(c, ring_rd, alo);
     cv_read_x<(Un >> 1), (Un & 1)>(c, tap, bnxt);
