@@ -528,14 +528,14 @@ int ccz_bias_act_f16(void *stream, void *y_dev, const void *bias_dev, const void
     return 0;
 }
 
-int ccz_conv3x3_c256_f16(void *stream, const void *x_dev, const void *w_dev, const void *bias_f32_dev, const void *residual_dev, void *y_dev,
-                         int64_t n_pixels, int32_t relu)
+static int conv3x3_launch(const char *who, void *stream, const void *x_dev, const void *w_dev, const void *bias_f32_dev, const void *residual_dev, void *y_dev,
+                          int64_t n_pixels, int32_t relu, int cin)
 {
     if (!x_dev || !w_dev || !bias_f32_dev || !y_dev || n_pixels < 0 || n_pixels % 90 || n_pixels > (int64_t)INT32_MAX / kCvC) /* 32-bit element offsets in the kernel */
-        return fail(-1, "ccz_conv3x3_c256_f16: bad arguments (n_pixels must be boards * 90, at most 93206 boards per call)");
+        return fail(-1, "%s: bad arguments (n_pixels must be boards * 90, at most 93206 boards per call)", who);
     if ((((uintptr_t)x_dev) | ((uintptr_t)w_dev) | ((uintptr_t)bias_f32_dev) | ((uintptr_t)residual_dev) | ((uintptr_t)y_dev)) & 15)
-        return fail(-1, "ccz_conv3x3_c256_f16: pointers must be 16-byte aligned");
-    if (x_dev == y_dev) return fail(-1, "ccz_conv3x3_c256_f16: the output may alias the residual but not the input");
+        return fail(-1, "%s: pointers must be 16-byte aligned", who);
+    if (x_dev == y_dev) return fail(-1, "%s: the output may alias the residual but not the input", who);
     if (n_pixels == 0) return 0;
     const unsigned tiles = (unsigned)((n_pixels + kCvBM - 1) / kCvBM);
 #ifndef CCZ_STAMPS
@@ -543,10 +543,31 @@ int ccz_conv3x3_c256_f16(void *stream, const void *x_dev, const void *w_dev, con
 #endif
     if (residual_dev)
         hipLaunchKernelGGL(k_conv3x3_c256<true>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev,
-                           (const float *)bias_f32_dev, (const _Float16 *)residual_dev, (_Float16 *)y_dev, (int)n_pixels, (int)relu);
+                           (const float *)bias_f32_dev, (const _Float16 *)residual_dev, (_Float16 *)y_dev, (int)n_pixels, (int)relu, cin);
     else
         hipLaunchKernelGGL(k_conv3x3_c256<false>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev,
-                           (const float *)bias_f32_dev, (const _Float16 *)nullptr, (_Float16 *)y_dev, (int)n_pixels, (int)relu);
+                           (const float *)bias_f32_dev, (const _Float16 *)nullptr, (_Float16 *)y_dev, (int)n_pixels, (int)relu, cin);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ccz_conv3x3_c256_f16(void *stream, const void *x_dev, const void *w_dev, const void *bias_f32_dev, const void *residual_dev, void *y_dev,
+                         int64_t n_pixels, int32_t relu)
+{
+    return conv3x3_launch("ccz_conv3x3_c256_f16", stream, x_dev, w_dev, bias_f32_dev, residual_dev, y_dev, n_pixels, relu, 256);
+}
+
+int ccz_conv3x3_stem_f16(void *stream, const void *x64_dev, const void *w_dev, const void *bias_f32_dev, void *y_dev, int64_t n_pixels, int32_t relu)
+{
+    return conv3x3_launch("ccz_conv3x3_stem_f16", stream, x64_dev, w_dev, bias_f32_dev, nullptr, y_dev, n_pixels, relu, 64);
+}
+
+int ccz_pack_live_planes_f16(void *stream, const void *leaf_dev, void *x64_dev, int32_t n_boards)
+{
+    if (!leaf_dev || !x64_dev || n_boards < 0) return fail(-1, "ccz_pack_live_planes_f16: bad arguments");
+    if ((uintptr_t)x64_dev & 15) return fail(-1, "ccz_pack_live_planes_f16: output must be 16-byte aligned");
+    if (n_boards == 0) return 0;
+    hipLaunchKernelGGL(k_pack_live_planes, dim3((unsigned)n_boards), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)leaf_dev, (half8_t *)x64_dev, (int)n_boards);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -109,6 +109,8 @@ struct CvCtx {
     int a_off;         // weight fragment offset inside a ring slot (tile 0; tile m: + 1024 m)
     int brow;          // slab row of this lane's pixel of tile 0 at tap offset 0 (tile n: + 16 n)
     unsigned vmask[4]; // per pixel tile: bit t set = tap t stays on the board
+    int cin;           // input channels per pixel of X and per (co, tap) row of W: 256 (tower) or 64 (stem, one chunk)
+    int cmask;         // number of 64-channel chunks - 1
     int dbg;           // diagnostic build (-DCCZ_STAMPS) only: ablation switches from bits 8.. of the relu argument
 };
 
@@ -169,16 +171,16 @@ __device__ __forceinline__ void cv_halfstep(const CvCtx &c, cv_f32x4 (&acc)[8][4
 
     constexpr int pass = cv_act_pass(U);
     if constexpr (pass >= 0) if (!CV_DBG(c, 2)) {
-        const int nxt = (chunk + 1) & 3;
+        const int nxt = (chunk + 1) & c.cmask; // past the last chunk: re-stage chunk 0 into the free buffer (keeps every count static)
         cv_glds16(c.X + (c.xsrc[pass] + nxt * 64), lds + kCvAOff + ((chunk + 1) & 1) * kCvABytes + (pass < 4 ? pass * 64 : 224) * 128 + c.wave_dst);
     }
     if (!CV_DBG(c, 1)) {
         constexpr int U2 = (U + kCvAhead) % 18;
-        const int chunk2 = (chunk + (U + kCvAhead >= 18 ? 1 : 0)) & 3;
-        const _Float16 *s = c.wsrc + (U2 >> 1) * kCvC + chunk2 * 64 + (U2 & 1) * 32;
+        const int chunk2 = (chunk + (U + kCvAhead >= 18 ? 1 : 0)) & c.cmask;
+        const _Float16 *s = c.wsrc + (U2 >> 1) * c.cin + chunk2 * 64 + (U2 & 1) * 32;
         unsigned char *d = lds + ring_wr * kCvWBytes + c.wave_dst;
         cv_glds16(s, d);
-        cv_glds16(s + 128l * (9 * kCvC), d + 8192);
+        cv_glds16(s + 128l * (9 * c.cin), d + 8192);
     }
     cv_read_w<1>(c, ring_rd, ahi);
     cv_mfma16<0>(c, acc, alo, bcur);
@@ -200,7 +202,7 @@ __device__ __forceinline__ void cv_halfstep(const CvCtx &c, cv_f32x4 (&acc)[8][4
 template <bool RES>
 __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict__ X, const _Float16 *__restrict__ W,
                                                           const float *__restrict__ bias, const _Float16 *R,
-                                                          _Float16 *Y, int M, int relu)
+                                                          _Float16 *Y, int M, int relu, int cin)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kCvLds];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -217,6 +219,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict
     c.X = X;
     c.wave_dst = w * 1024;
     c.q4 = q4;
+    c.cin = cin;
+    c.cmask = (cin >> 6) - 1;
     c.dbg = relu >> 8;
     relu &= 1;
     {
@@ -226,12 +230,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict
         for (int it = 0; it < 5; ++it) {
             long p = p0 - kCvHalo + (it < 4 ? it * 64 : 224) + srow;
             p = p < 0 ? 0 : (p > (long)M - 1 ? (long)M - 1 : p);
-            c.xsrc[it] = (int)(p * kCvC + schunk * 8);
+            c.xsrc[it] = (int)(p * cin + schunk * 8);
         }
         // weight half-tile: 64-byte rows; position wpos of row holds source chunk wpos ^ f(row), f = (-(row >> 2)) & 3:
         // conflict-free for the 16 rows x 4 chunks block one ds_read_b128 of this MFMA shape covers
         const int wrow = tid >> 2, wpos = tid & 3;
-        c.wsrc = W + (long)wrow * (9 * kCvC) + ((wpos ^ ((0 - (wrow >> 2)) & 3)) * 8);
+        c.wsrc = W + (long)wrow * (9 * cin) + ((wpos ^ ((0 - (wrow >> 2)) & 3)) * 8);
     }
     // ---- prologue: slab of chunk 0, weight half-tiles 0..2, the four zero rows; the DMA is issued first, the
     // per-lane setup below runs while it is in flight
@@ -240,10 +244,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict
     for (int it = 0; it < 5; ++it) cv_glds16(X + c.xsrc[it], lds + kCvAOff + (it < 4 ? it * 64 : 224) * 128 + c.wave_dst);
 #pragma unroll
     for (int u = 0; u < kCvAhead; ++u) {
-        const _Float16 *s = c.wsrc + (u >> 1) * kCvC + (u & 1) * 32;
+        const _Float16 *s = c.wsrc + (u >> 1) * cin + (u & 1) * 32;
         unsigned char *d = lds + u * kCvWBytes + c.wave_dst;
         cv_glds16(s, d);
-        cv_glds16(s + 128l * (9 * kCvC), d + 8192);
+        cv_glds16(s + 128l * (9 * cin), d + 8192);
     }
     c.a_off = (wm * 128 + r) * 64 + ((q4 ^ ((0 - (r >> 2)) & 3)) << 4);
     c.brow = kCvHalo + wn * 64 + r;
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict
 #ifdef CCZ_STAMPS
     const unsigned long long st_loop0 = cv_stamp(), st_real0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    for (int chunk = 0; chunk < 4; ++chunk) {
+    for (int chunk = 0; chunk <= c.cmask; ++chunk) {
 #define CV_HE(u) cv_halfstep<u>(c, acc, chunk, ring_rd, ring_wr, tap, alo, ahi, b0, b1)
 #define CV_HO(u) cv_halfstep<u>(c, acc, chunk, ring_rd, ring_wr, tap, alo, ahi, b1, b0)
         CV_HE(0); CV_HO(1); CV_HE(2); CV_HO(3); CV_HE(4); CV_HO(5); CV_HE(6); CV_HO(7); CV_HE(8);

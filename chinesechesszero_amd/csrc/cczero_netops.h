@@ -27,4 +27,25 @@ __global__ __launch_bounds__(256) void k_bias_act(half8_t *__restrict__ y, const
     }
 }
 
+// The evaluator input [B, 17, 7, 10, 9] fp16 (reference net.py:174-177) has 21 planes that can be non-zero on the
+// search path (groups 7, 15, 16 = planes 49..55 and 105..118, net.py:160-173): pack them as NHWC rows of 64 channels
+// (21 live + 43 zeros), the stem input of the tower convolution kernel. One workgroup per board, 16 B per lane.
+__global__ __launch_bounds__(256) void k_pack_live_planes(const _Float16 *__restrict__ leaf, half8_t *__restrict__ out, int n_boards)
+{
+    const long b = blockIdx.x;
+    const _Float16 *src = leaf + b * (119 * 90);
+    for (int i = threadIdx.x; i < 90 * 8; i += 256) {
+        const int p = i >> 3, cpos = i & 7;
+        half8_t v = (half8_t)(_Float16)0;
+        if (cpos < 3) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ch = cpos * 8 + e;
+                if (ch < 21) v[e] = src[(ch < 7 ? 49 + ch : 98 + ch) * 90 + p];
+            }
+        }
+        out[(b * 90 + p) * 8 + cpos] = v;
+    }
+}
+
 } // namespace ccz

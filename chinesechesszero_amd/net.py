@@ -99,6 +99,12 @@ class InferenceNet(nn.Module):
             w = w[:, self.LIVE]
         self.stem_w = nn.Parameter(w.to(dtype).contiguous(memory_format=cl), requires_grad=False)
         self.stem_b = nn.Parameter(b.to(dtype), requires_grad=False)
+        if live_only and w.shape[0] == 256:
+            # stem weights for the fused kernel: [co, ky, kx, 64] with the 21 live input channels first, zeros above
+            w64 = torch.zeros(256, 3, 3, 64, dtype=w.dtype, device=w.device)
+            w64[..., :len(self.LIVE)] = w.permute(0, 2, 3, 1)
+            self.stem_w64 = nn.Parameter(w64.to(dtype).contiguous(), requires_grad=False)
+            self.stem_b32 = nn.Parameter(b.detach().float().clone(), requires_grad=False)
         ws, bs = [], []
         for blk in net.res_blocks:
             for conv, bn in ((blk.conv1, blk.conv1_bn), (blk.conv2, blk.conv2_bn)):
@@ -200,14 +206,34 @@ class InferenceNet(nn.Module):
             cur.wait_event(join)
         return x  # every side stream has been joined into the current stream
 
+    def _stem_fused(self, leaf_input):
+        """Stem on the same MFMA kernel: pack the 21 live planes as NHWC rows of 64 channels, then one 64-channel chunk of
+        the tower convolution (conv3x3 + bias + ReLU). Replaces cat + layout copy + MIOpen convolution + epilogue pass."""
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        B = leaf_input.shape[0]
+        s = C.c_void_p(torch.cuda.current_stream(leaf_input.device).cuda_stream)
+        x64 = torch.empty((B, 90, 64), dtype=torch.float16, device=leaf_input.device)
+        y = torch.empty((B, 256, 10, 9), dtype=torch.float16, device=leaf_input.device, memory_format=torch.channels_last)
+        _lib.check(L.ccz_pack_live_planes_f16(s, C.c_void_p(leaf_input.data_ptr()), C.c_void_p(x64.data_ptr()), B))
+        _lib.check(L.ccz_conv3x3_stem_f16(s, C.c_void_p(x64.data_ptr()), C.c_void_p(self.stem_w64.data_ptr()), C.c_void_p(self.stem_b32.data_ptr()),
+                                          C.c_void_p(y.data_ptr()), B * 90, 1))
+        return y
+
     @torch.no_grad()
     def forward(self, leaf_input: torch.Tensor, return_logits: bool = False):
         B = leaf_input.shape[0]
-        x = leaf_input.view(B, PLAYS * PIECES, 10, 9)
-        if self.live_only:
-            x = torch.cat([x[:, 49:56], x[:, 105:119]], dim=1)
-        x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
-        x = self._epilogue(F.conv2d(x, self.stem_w, None, padding=1), self.stem_b)
+        if (hasattr(self, "stem_w64") and leaf_input.is_cuda and leaf_input.dtype == torch.float16 and leaf_input.is_contiguous()
+                and B >= self.FUSED_MIN_BOARDS and self.dtype == torch.float16 and os.environ.get("CCZ_FUSED_CONV", "1") != "0"
+                and os.environ.get("CCZ_FUSED_STEM", "1") != "0"):
+            x = self._stem_fused(leaf_input)
+        else:
+            x = leaf_input.view(B, PLAYS * PIECES, 10, 9)
+            if self.live_only:
+                x = torch.cat([x[:, 49:56], x[:, 105:119]], dim=1)
+            x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
+            x = self._epilogue(F.conv2d(x, self.stem_w, None, padding=1), self.stem_b)
         if self._use_fused_tower(x):
             x = self._tower_fused(x)
         else:

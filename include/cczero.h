@@ -240,6 +240,17 @@ int ccz_bias_act_f16(void *stream, void *y_dev, const void *bias_dev, const void
 int ccz_conv3x3_c256_f16(void *stream, const void *x_dev, const void *w_dev, const void *bias_f32_dev,
                          const void *residual_dev, void *y_dev, int64_t n_pixels, int32_t relu);
 
+/* The stem convolution (reference net.py:59-66,86-88: conv3x3(119 -> 256) -> BN(folded) -> ReLU) with the same kernel,
+ * one 64-channel chunk: x64 [n_pixels, 64] fp16 holds the 21 planes that can be non-zero on the search path in
+ * channels 0..20 (ccz_pack_live_planes_f16) and zeros above; w: [256, 3, 3, 64] fp16 (input channels in the same
+ * order, zero-padded); bias float32 [256]; y [n_pixels, 256] fp16. Exact: zero inputs contribute nothing. */
+int ccz_conv3x3_stem_f16(void *stream, const void *x64_dev, const void *w_dev, const void *bias_f32_dev,
+                         void *y_dev, int64_t n_pixels, int32_t relu);
+/* Evaluator input [n_boards, 17, 7, 10, 9] fp16 (the layout ccz_select_leaves / ccz_step write, net.py:174-177)
+ * -> NHWC rows of 64 channels: planes 49..55 (group 7), 105..118 (groups 15, 16), then zeros (net.py:160-173 leaves
+ * every other group zero on the search path). */
+int ccz_pack_live_planes_f16(void *stream, const void *leaf_dev, void *x64_dev, int32_t n_boards);
+
 #ifdef __cplusplus
 }
 #endif

@@ -153,3 +153,32 @@ def test_conv_kernel_full_size_board_permutation_and_sample():
     want = F.relu(F.conv2d(x[sample].float(), w.float(), b, padding=1) + r[sample].float())
     assert (y[sample].float() - want).abs().max().item() < 4e-3 * max(1.0, want.abs().max().item())
     assert torch.isfinite(y.float()).all()
+
+
+@pytest.mark.parametrize("boards", [1, 65, 300])
+def test_stem_pack_and_convolution_match_reference_ops(boards):
+    """ccz_pack_live_planes_f16 (bit-exact gather of planes 49..55, 105..118 into 64-channel NHWC rows) and
+    ccz_conv3x3_stem_f16 (one 64-channel chunk of the tower kernel) against torch ops on the same operands."""
+    from chinesechesszero_amd import _lib
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(100 + boards)
+    leaf = (torch.rand(boards, 17, 7, 10, 9, generator=g) > 0.8).to(dev).half()
+    leaf[:, :7] = 1  # planes outside the live set must not leak in
+    L = _lib.lib()
+    s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    x64 = torch.full((boards, 90, 64), float("nan"), device=dev, dtype=torch.float16)
+    _lib.check(L.ccz_pack_live_planes_f16(s, C.c_void_p(leaf.data_ptr()), C.c_void_p(x64.data_ptr()), boards))
+    planes = leaf.view(boards, 119, 90)
+    want = torch.zeros(boards, 90, 64, device=dev, dtype=torch.float16)
+    want[..., :7] = planes[:, 49:56].permute(0, 2, 1)
+    want[..., 7:21] = planes[:, 105:119].permute(0, 2, 1)
+    assert torch.equal(x64, want)
+    w21 = (torch.randn(256, 21, 3, 3, generator=g) * 0.1).to(dev).half()
+    b = (torch.randn(256, generator=g) * 0.2).to(dev)
+    w64 = torch.zeros(256, 3, 3, 64, device=dev, dtype=torch.float16)
+    w64[..., :21] = w21.permute(0, 2, 3, 1)
+    y = torch.full((boards, 256, 10, 9), float("nan"), device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+    _lib.check(L.ccz_conv3x3_stem_f16(s, C.c_void_p(x64.data_ptr()), C.c_void_p(w64.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(y.data_ptr()), boards * 90, 1))
+    x21 = torch.cat([planes[:, 49:56], planes[:, 105:119]], 1).view(boards, 21, 10, 9).float()
+    ref = F.relu(F.conv2d(x21, w21.float(), b, padding=1))
+    assert (y.float() - ref).abs().max().item() < 4e-3 * max(1.0, ref.abs().max().item())
