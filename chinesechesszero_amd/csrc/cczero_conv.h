@@ -35,7 +35,10 @@
 // whole half-step ahead into three register sets (0 %), 16 zero rows (one per bank slot) for the masked lanes
 // (-1 %), a ping-pong form with two barriers per 8-MFMA group and the wave groups one barrier apart (-15 %); on this
 // form: one barrier per TWO half-steps (the ring of 5 allows it) (-1.6 %), a split barrier on an LDS arrival counter
-// (arrive after the DMA wait, 8 MFMAs, then poll) instead of s_barrier (-23 %).
+// (arrive after the DMA wait, 8 MFMAs, then poll) instead of s_barrier (-23 %), several consecutive tiles per workgroup with
+// the next tile's first slab and weights staged during the last chunk (no prologue for later tiles) and the epilogue
+// transposed through the one free slab buffer, one pixel tile at a time (-12..-16 %: the four serialized epilogue
+// passes and their register pressure cost more than the prologue they save).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
