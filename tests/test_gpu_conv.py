@@ -182,3 +182,37 @@ def test_stem_pack_and_convolution_match_reference_ops(boards):
     x21 = torch.cat([planes[:, 49:56], planes[:, 105:119]], 1).view(boards, 21, 10, 9).float()
     ref = F.relu(F.conv2d(x21, w21.float(), b, padding=1))
     assert (y.float() - ref).abs().max().item() < 4e-3 * max(1.0, ref.abs().max().item())
+
+
+def test_fused_evaluator_inside_hipgraph_capture_equals_eager():
+    """Inside a stream capture the tower uses one chain on the capturing stream (no side streams); the replayed graph
+    must give the same tower output bit for bit as the eager two-chain run (the PyTorch head GEMMs may pick other
+    kernels under capture: the final probabilities / values are compared at fp16-inference tolerance)."""
+    from chinesechesszero_amd.net import InferenceNet, Net
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(8)
+    inf = InferenceNet(Net(256, 2).to(dev).eval()).to(dev).eval()
+    B = 512
+    leaf = (torch.rand(B, 17, 7, 10, 9, device=dev) > 0.9).half()
+
+    def body(x):
+        t = inf._tower_fused(inf._stem_fused(x))
+        p, v = inf(x)
+        return t, p, v
+    with torch.no_grad():
+        t_eager, p_eager, v_eager = body(leaf)
+        t_eager = t_eager.clone()
+        static_in = leaf.clone()
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                body(static_in)
+        torch.cuda.current_stream(dev).wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            t_graph, p_graph, v_graph = body(static_in)
+        g.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(t_graph, t_eager)
+    assert torch.allclose(p_graph, p_eager, atol=2e-3) and torch.allclose(v_graph, v_eager, atol=2e-2)
