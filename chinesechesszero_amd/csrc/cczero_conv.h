@@ -266,13 +266,16 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict
         c.vmask[n] = m;
     }
 
+    // the accumulators start at the bias (loaded in the shadow of the prologue DMA): nothing left to add in the epilogue
     cv_f32x4 acc[8][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 8; ++i) {
+        const float4 bv = *(const float4 *)(bias + wm * 128 + i * 16 + 4 * q4);
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][n][e] = 0.f;
+        for (int n = 0; n < 4; ++n) {
+            acc[i][n][0] = bv.x; acc[i][n][1] = bv.y; acc[i][n][2] = bv.z; acc[i][n][3] = bv.w;
+        }
+    }
 
     cv_wait_vm<4>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -318,14 +321,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         const int col = m * 16 + 4 * q4;
-        const float4 bv = *(const float4 *)(bias + wm * 128 + col);
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             cv_half4 o;
-            o[0] = (_Float16)(acc[m][n][0] + bv.x);
-            o[1] = (_Float16)(acc[m][n][1] + bv.y);
-            o[2] = (_Float16)(acc[m][n][2] + bv.z);
-            o[3] = (_Float16)(acc[m][n][3] + bv.w);
+            o[0] = (_Float16)acc[m][n][0];
+            o[1] = (_Float16)acc[m][n][1];
+            o[2] = (_Float16)acc[m][n][2];
+            o[3] = (_Float16)acc[m][n][3];
             *(cv_half4 *)(eb + (n * 16 + r) * kCvERow + col * 2) = o;
         }
     }
