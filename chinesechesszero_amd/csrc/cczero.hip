@@ -539,7 +539,7 @@ static int conv3x3_launch(const char *who, void *stream, const void *x_dev, cons
     if (n_pixels == 0) return 0;
     const unsigned tiles = (unsigned)((n_pixels + kCvBM - 1) / kCvBM);
 #ifndef CCZ_STAMPS
-    relu = relu ? 1 : 0; // the diagnostic build passes ablation switches in bits 8.. (profiles/conv_microbench.py)
+    relu &= 3; // bit 0: ReLU, bit 1: descending tile order; the diagnostic build passes ablation switches in bits 8.. (profiles/conv_microbench.py)
 #endif
     if (residual_dev)
         hipLaunchKernelGGL(k_conv3x3_c256<true>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev,

@@ -212,7 +212,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q4 = lane >> 4;
     const int wm = w >> 2, wn = w & 3;
-    const long p0 = (long)blockIdx.x * kCvBM;
+    // flags bit 1: tiles in descending order (the tiles written last by the previous layer are then read first)
+    const long p0 = (long)((relu & 2) ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * kCvBM;
 
 #ifdef CCZ_STAMPS
     const unsigned long long st_prolog = cv_stamp();

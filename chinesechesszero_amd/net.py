@@ -194,12 +194,15 @@ class InferenceNet(nn.Module):
             chains.append((st, C.c_void_p(st.cuda_stream), C.c_void_p(x.data_ptr() + b0 * row), C.c_void_p(y.data_ptr() + b0 * row), (b1 - b0) * 90))
         # launches are enqueued layer by layer across the chains, so that the chains advance together (the same layer's
         # weights stay hot in L2) and no chain waits for the host to finish enqueuing another one
+        rev_alt = os.environ.get("CCZ_CONV_ZIGZAG", "1") == "1"  # alternate the tile order from layer to layer: what the previous
+        # layer wrote last (still in the 256 MB Infinity Cache) is read first (-0.7 % on the step)
         for i in range(0, len(self.ws), 2):
+            rev = 2 if rev_alt else 0
             w1, b1_, w2, b2_ = (C.c_void_p(t.data_ptr()) for t in (self.ws[i], self.bs32[i], self.ws[i + 1], self.bs32[i + 1]))
             for _, s, xp, yp, n_pixels in chains:
-                _lib.check(L.ccz_conv3x3_c256_f16(s, xp, w1, b1_, None, yp, n_pixels, 1))
+                _lib.check(L.ccz_conv3x3_c256_f16(s, xp, w1, b1_, None, yp, n_pixels, 1 | rev))
             for _, s, xp, yp, n_pixels in chains:
-                _lib.check(L.ccz_conv3x3_c256_f16(s, yp, w2, b2_, xp, xp, n_pixels, 1))  # output written over the residual input
+                _lib.check(L.ccz_conv3x3_c256_f16(s, yp, w2, b2_, xp, xp, n_pixels, 1 | (rev ^ 2 if rev_alt else 0)))  # output written over the residual input
         for st, *_ in chains[1:]:
             join = torch.cuda.Event()
             join.record(st)

@@ -232,7 +232,9 @@ int ccz_bias_act_f16(void *stream, void *y_dev, const void *bias_dev, const void
 /* A whole tower convolution in one kernel (MFMA implicit GEMM, hand-written for gfx950): 3x3, padding 1,
  * 256 -> 256 channels over boards of 10 x 9, NHWC fp16 in and out, fp32 accumulate:
  *   y[p, co] = act( bias[co] + sum_{ky,kx,ci} w[co, ky, kx, ci] * x[p + 9*(ky-1) + (kx-1), ci] [+ residual[p, co]] )
- * with taps that leave the board contributing zero; act = ReLU when relu != 0 (reference net.py:20-43,
+ * with taps that leave the board contributing zero; relu is a flag word: bit 0 = apply ReLU, bit 1 = process the
+ * pixel tiles in descending order (same results; alternating the order from layer to layer reads first what the
+ * previous layer wrote last) (reference net.py:20-43,
  * ResBlock conv -> BN(folded) -> [+x] -> ReLU; replaces F.conv2d + ccz_bias_act_f16 for these layers).
  * x, y, residual: [n_pixels, 256] fp16 (n_pixels = boards * 90); w: [256, 3, 3, 256] fp16 (the memory of a
  * channels-last [co, ci, 3, 3] tensor); bias: float32 [256]. y may alias residual, not x. At most 93,206 boards
