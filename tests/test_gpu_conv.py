@@ -38,6 +38,9 @@ def test_conv_kernel_matches_fp32_convolution(boards):
             want = F.relu(want)
         err = (y.float() - want).abs().max().item()
         assert err < 4e-3 * max(1.0, want.abs().max().item()), (boards, res is not None, relu, err)
+    # flag bit 1 (descending tile order) changes nothing in the result
+    ya, yb = _conv(x, w, b, r, torch.empty_like(x), 1), _conv(x, w, b, r, torch.empty_like(x), 3)
+    assert torch.equal(ya, yb)
     # the output may be written over the residual input (how the tower uses it)
     y = r.clone(memory_format=torch.preserve_format)
     _conv(x, w, b, y, y, 1)
