@@ -155,6 +155,7 @@ class InferenceNet(nn.Module):
         return bool(x.is_cuda and x.dtype == torch.float16 and x.shape[1] == 256 and x.shape[0] >= self.FUSED_MIN_BOARDS
                     and x.is_contiguous(memory_format=torch.channels_last))
 
+    TOWER_GROUP_BOARDS = 2048  # boards per sequential group (working set of a group fits the Infinity Cache); env CCZ_TOWER_GROUPS
     TOWER_CHAINS = 2  # independent board ranges run as concurrent launch chains (one HIP stream each); env CCZ_TOWER_CHAINS (<= 8)
 
     def _tower_fused(self, x):
@@ -169,15 +170,30 @@ class InferenceNet(nn.Module):
         import ctypes as C
         from . import _lib
         L = _lib.lib()
-        B = x.shape[0]
         y = torch.empty_like(x)
+        # groups of TOWER_GROUP_BOARDS boards go through all 80 layers one after the other: the two activation buffers of a
+        # group (2 x 94 MB at 2048 boards) then stay inside the 256 MB Infinity Cache from layer to layer
+        # (4096 boards: 1 group 27.55 ms/step, 2 groups 27.19, 3: 28.0, 4: 28.4)
+        Bt = x.shape[0]
+        groups = int(os.environ.get("CCZ_TOWER_GROUPS", "0")) or -(-Bt // self.TOWER_GROUP_BOARDS)
+        if torch.cuda.is_current_stream_capturing():
+            groups = 1
+        gstep = -(-(-(-Bt // groups)) // 128) * 128 if groups > 1 else Bt
+        for g0 in range(0, Bt, gstep):
+            self._tower_range(L, C, x, y, g0, min(Bt, g0 + gstep))
+        return x
+
+    def _tower_range(self, L, C, x, y, lo, hi):
+        """Boards [lo, hi) through all 80 layers, as TOWER_CHAINS concurrent launch chains."""
+        from . import _lib
+        B = hi - lo
         cur = torch.cuda.current_stream(x.device)
         want = int(os.environ.get("CCZ_TOWER_CHAINS", self.TOWER_CHAINS))
         parts = 1 if torch.cuda.is_current_stream_capturing() else max(1, min(want, 8, B // 256))
         step = -(-B // parts)
         if parts > 1:
             step = -(-step // 128) * 128  # 128 boards = 45 whole tiles: no partial tile inside the batch
-        bounds = [(b0, min(B, b0 + step)) for b0 in range(0, B, step)]
+        bounds = [(lo + b0, lo + min(B, b0 + step)) for b0 in range(0, B, step)]
         if len(bounds) > 1:
             pool = getattr(self, "_chain_streams", None)
             if pool is None or pool[0] != x.device or len(pool[1]) < len(bounds) - 1:
@@ -193,21 +209,20 @@ class InferenceNet(nn.Module):
                 st.wait_event(fork)
             chains.append((st, C.c_void_p(st.cuda_stream), C.c_void_p(x.data_ptr() + b0 * row), C.c_void_p(y.data_ptr() + b0 * row), (b1 - b0) * 90))
         # launches are enqueued layer by layer across the chains, so that the chains advance together (the same layer's
-        # weights stay hot in L2) and no chain waits for the host to finish enqueuing another one
-        rev_alt = os.environ.get("CCZ_CONV_ZIGZAG", "1") == "1"  # alternate the tile order from layer to layer: what the previous
-        # layer wrote last (still in the 256 MB Infinity Cache) is read first (-0.7 % on the step)
+        # weights stay hot in L2) and no chain waits for the host to finish enqueuing another one. The tile order
+        # alternates from layer to layer: what the previous layer wrote last (still in the Infinity Cache) is read
+        # first (-0.7 % on the step; CCZ_CONV_ZIGZAG=0 switches it off).
+        down = 2 if os.environ.get("CCZ_CONV_ZIGZAG", "1") == "1" else 0
         for i in range(0, len(self.ws), 2):
-            rev = 2 if rev_alt else 0
             w1, b1_, w2, b2_ = (C.c_void_p(t.data_ptr()) for t in (self.ws[i], self.bs32[i], self.ws[i + 1], self.bs32[i + 1]))
             for _, s, xp, yp, n_pixels in chains:
-                _lib.check(L.ccz_conv3x3_c256_f16(s, xp, w1, b1_, None, yp, n_pixels, 1 | rev))
+                _lib.check(L.ccz_conv3x3_c256_f16(s, xp, w1, b1_, None, yp, n_pixels, 1 | down))
             for _, s, xp, yp, n_pixels in chains:
-                _lib.check(L.ccz_conv3x3_c256_f16(s, yp, w2, b2_, xp, xp, n_pixels, 1 | (rev ^ 2 if rev_alt else 0)))  # output written over the residual input
-        for st, *_ in chains[1:]:
+                _lib.check(L.ccz_conv3x3_c256_f16(s, yp, w2, b2_, xp, xp, n_pixels, 1))  # output written over the residual input
+        for st, *_ in chains[1:]:  # every side stream is joined into the current stream
             join = torch.cuda.Event()
             join.record(st)
             cur.wait_event(join)
-        return x  # every side stream has been joined into the current stream
 
     def _stem_fused(self, leaf_input):
         """Stem on the same MFMA kernel: pack the 21 live planes as NHWC rows of 64 channels, then one 64-channel chunk of
