@@ -288,8 +288,11 @@ def main():
                         "achieved": conv_flops / t_conv / 1e12, "peak": MFMA_PEAK_F16 / 1e12, "unit": "TFLOP/s",
                         "frac": conv_flops / t_conv / MFMA_PEAK_F16, "traffic": None, "avg_launch_us": t_conv * 1e6,
                         "algorithmic_flops_per_launch": conv_flops, "launches_per_step": 2 * a.blocks,
-                        "chains": max(1, min(int(os.environ.get("CCZ_TOWER_CHAINS", inf.TOWER_CHAINS)), 8, B // 256)),
-                        "note": "a 'launch' is one layer over the whole batch, issued as `chains` concurrent kernel launches over board ranges"}
+                        "groups": int(os.environ.get("CCZ_TOWER_GROUPS", "0")) or -(-B // inf.TOWER_GROUP_BOARDS),
+                        "note": "a 'launch' is one layer over the whole batch, issued as groups x chains kernel launches over board ranges "
+                                "(groups one after the other, the chains of a group concurrently)"}
+        per_group = -(-B // net_roofline["groups"])
+        net_roofline["chains"] = max(1, min(int(os.environ.get("CCZ_TOWER_CHAINS", inf.TOWER_CHAINS)), 8, per_group // 256))
 
     sims = s1["sims"] - s0["sims"]
     exp = max(1, s1["expansions"] - s0["expansions"])
@@ -320,7 +323,7 @@ def main():
                 traffic = pm.get("k_step", {}).get("hbm_bytes_per_launch")
                 if net_roofline is not None:  # HBM bytes of one convolution launch (PMC passes of profiles/run_profile.sh)
                     per_kernel = pm.get("k_conv3x3", {}).get("hbm_bytes_per_launch")
-                    net_roofline["traffic"] = per_kernel * net_roofline["chains"] if per_kernel else None
+                    net_roofline["traffic"] = per_kernel * net_roofline["chains"] * net_roofline["groups"] if per_kernel else None
             except Exception:
                 traffic = None
         flops = 8.551e9 * (a.blocks / 40.0) * (a.channels / 256.0) ** 2
