@@ -29,7 +29,8 @@
 //   * epilogue: each wave transposes its 64 pixel x 128 channel block through its own LDS region, so that the
 //     residual is read and the output written as whole 256-byte pixel-row segments.
 //
-// Measured alternatives that did NOT pay (profiles/conv_ab.py, one device, interleaved; on the 32x32x16 form):
+// Measured alternatives that did NOT pay (profiles/conv_ab.py, one device, interleaved; figures = change in throughput;
+// on the 32x32x16 form):
 // staggering the DMA issue of the two wave groups (-4.5 %), running the groups half a half-step apart (-2 %),
 // s_setprio around the MFMA groups (-11 %), sched_group_barrier-pinned interleave (-1.5 %), fragments read a
 // whole half-step ahead into three register sets (0 %), 16 zero rows (one per bank slot) for the masked lanes
