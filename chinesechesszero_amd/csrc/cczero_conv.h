@@ -39,7 +39,10 @@
 // (arrive after the DMA wait, 8 MFMAs, then poll) instead of s_barrier (-23 %), several consecutive tiles per workgroup with
 // the next tile's first slab and weights staged during the last chunk (no prologue for later tiles) and the epilogue
 // transposed through the one free slab buffer, one pixel tile at a time (-12..-16 %: the four serialized epilogue
-// passes and their register pressure cost more than the prologue they save).
+// passes and their register pressure cost more than the prologue they save), ONE wave per SIMD with a 128 x 128 block per
+// wave (256 accumulator registers, a third fewer LDS fragment bytes per MFMA) (-14 % as compiled by hipcc, -20 % with the
+// DMA and the reads pinned between the MFMAs by sched_group_barrier: a single instruction stream per SIMD does not hide its
+// own DMA issue and waits without hand scheduling).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
