@@ -266,7 +266,7 @@ def main():
     # the evaluator's dominant kernel (2 x blocks launches per step): the fused tower convolution, timed live on this stream
     # over the whole tower on the activations of a real leaf batch (ReLU-sparse data clocks higher than dense random data)
     net_roofline = None
-    if a.evaluator == "net" and rank == 0 and a.channels == 256 and B >= 64 and os.environ.get("CCZ_FUSED_CONV", "1") != "0":
+    if a.evaluator == "net" and rank == 0 and a.channels == 256 and B >= 192 and os.environ.get("CCZ_FUSED_CONV", "1") != "0":
         import torch.nn.functional as F
         inf = pvn._infer
         leaf = state["leaf"] if state["leaf"] is not None else e.select_leaves()

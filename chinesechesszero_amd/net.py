@@ -145,7 +145,8 @@ class InferenceNet(nn.Module):
             y = y + residual
         return F.relu_(y)
 
-    FUSED_MIN_BOARDS = 64  # below this the 256-pixel tiles of the fused kernel leave most of the chip idle
+    FUSED_MIN_BOARDS = 192  # below this the 256-pixel tiles of the fused kernel leave most of the chip idle (eager evaluator,
+    # profiles/evaluator_crossover.py: 128 boards MIOpen 3.69 ms vs fused 3.96; 256 boards 4.43 vs 3.99; <= 64 both ~3.85, host-bound)
 
     def _use_fused_tower(self, x) -> bool:
         """The hand-written MFMA convolution (libcczero ccz_conv3x3_c256_f16) covers the tower's shape only:

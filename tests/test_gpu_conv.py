@@ -81,7 +81,7 @@ def test_conv_kernel_rejects_bad_arguments():
 
 
 def test_fused_tower_matches_reference_architecture_and_miopen_path(monkeypatch):
-    """256-channel tower (the only width the kernel serves), 3 blocks, 70 boards: fused path vs fp32 reference
+    """256-channel tower (the only width the kernel serves), 3 blocks, 200 boards: fused path vs fp32 reference
     architecture, and vs the MIOpen + epilogue path it replaces."""
     from chinesechesszero_amd.net import InferenceNet, Net
     dev = torch.device("cuda", 0)
@@ -93,7 +93,7 @@ def test_fused_tower_matches_reference_architecture_and_miopen_path(monkeypatch)
             m.running_var.uniform_(0.5, 2)
             m.weight.data.uniform_(0.5, 1.5)
             m.bias.data.normal_(0, 0.1)
-    B = 70
+    B = 200
     x = torch.zeros(B, 17, 7, 10, 9, device=dev)
     x[:, 7] = (torch.rand(B, 7, 10, 9, device=dev) > 0.9).float()
     x[:, 15] = (torch.rand(B, 7, 10, 9, device=dev) > 0.9).float()
