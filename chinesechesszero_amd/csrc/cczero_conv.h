@@ -191,7 +191,9 @@ __device__ __forceinline__ void cv_halfstep(const CvCtx &c, cv_f32x4 (&acc)[8][4
     }
     cv_read_w<1>(c, ring_rd, ahi);
     cv_mfma16<0>(c, acc, alo, bcur);
+#ifndef CCZ_STAMPS // (the diagnostic build's runtime ablation branches make the pass abort in hipcc 7.2)
     __builtin_amdgcn_iglp_opt(1); // LLVM's single-wave MFMA / DS interleave for this scheduling region: -3..-6 % (same bits)
+#endif
 
     ring_rd = ring_rd + 1 == kCvRing ? 0 : ring_rd + 1;
     ring_wr = ring_wr + 1 == kCvRing ? 0 : ring_wr + 1;
