@@ -6,10 +6,16 @@
 
 A "step" is one lockstep simulation of every board: select+make-move+movegen+encode (HIP) ->
 policy-value net (PyTorch-ROCm fp16, same stream) -> expand+backup (HIP); every ``n_playout``-th
-step also plays one move on every board (pi, Dirichlet-mixed choice, re-root, game end; HIP) and
-exchanges finished training rows (RCCL all-gather when N > 1). Workload = BASELINE.json configs[2]:
-4096 concurrent boards per GPU x 400 sims/move, Dirichlet root noise on, random-init 40x256 net,
-all boards from the opening position (synthetic). Prints ONE JSON line on rank 0.
+step also plays one move on every board (pi, Dirichlet-mixed choice, re-root, game end; HIP), harvests
+the training rows of the games that ended and exchanges them (RCCL all-gather when N > 1). Workload =
+BASELINE.json configs[2]: 4096 concurrent boards per GPU x 400 sims/move, Dirichlet root noise on,
+random-init 40x256 net (synthetic).
+
+What the K timed steps see (untimed setup before them): the boards are in the steady state of continuous
+self-play -- spread evenly over plies 1..200 of their games, diverged positions -- and the trees have
+been searched with the real evaluator up to simulation n - K/2 of the current move, so the timed window
+holds the end of one move's search, a REAL move boundary (finish_move + harvest + restart [+ all-gather])
+and the start of the next move on the kept subtrees, whatever K is. Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
@@ -46,6 +52,13 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse "
                     "the N>1 control flow with several ranks sharing one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--preroll-plies", type=int, default=200, help="untimed setup: spread the boards over plies 1..P of their games "
+                    "(stub evaluator, uniformly random moves; 0 = all boards on the opening position, as round 1 timed it)")
+    ap.add_argument("--max-plies", type=int, default=200, help="games are adjudicated as draws at this many plies (the soak's cap); "
+                    "with --preroll-plies equal to it every move ends ~boards/P games, so every move boundary harvests real rows")
+    ap.add_argument("--no-align", dest="align", action="store_false", help="do not advance the search to the point where the timed "
+                    "window straddles a move boundary (the window then starts at the first simulation of a move)")
+    ap.add_argument("--gather-rows", type=int, default=8192, help="N>1: row capacity of the fused all-gather buffer (29,768 B per row)")
     return ap.parse_args()
 
 
@@ -116,6 +129,32 @@ def cpu_baseline(seconds: float, blocks: int, channels: int):
             "moves_per_sec": moves / dt if moves else sims / dt / 200.0}
 
 
+def preroll(e, plies: int, stagger: bool):
+    """Untimed setup: bring the boards to a steady-state spread of game phases.
+
+    Self-play in steady state has its boards at every phase of a game (finished boards restart at once), not all on the
+    opening position. ``plies`` lockstep plies are played with the stub evaluator and ONE simulation per ply (root
+    expansion; a flat pi at temperature 1e3 => a uniformly random legal move, what a random-init net plays up to noise);
+    with ``stagger`` board b is restarted at ply (b mod plies), so that at the end the boards sit at plies 1..plies of
+    their games, evenly. Games that end on the way are harvested (rows discarded) and restarted."""
+    from chinesechesszero_amd.net import uniform_evaluator
+    B = e.B
+    temps = np.full(B, 1e3, np.float64)
+    b_idx = np.arange(B)
+    for t in range(plies):
+        if stagger and t > 0:
+            mask = ((b_idx % plies) == t).astype(np.uint8)
+            if mask.any():
+                e.reset(mask)
+        leaf = e.select_leaves()
+        e.expand_backup(*uniform_evaluator(leaf))
+        e.finish_move(temps=temps, keep_tree=False)
+        if e.game_status()["over"].any():
+            for _ in e.harvest_chunks(1 << 16):
+                pass
+    e.check_healthy()
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -157,37 +196,85 @@ def main():
     else:
         evaluator = uniform_evaluator
     sp = BatchedSelfPlay(evaluator, B, n_playout=n, seed=0, board_id_base=rank * B, device=local_rank,
-                         sampling="device")
+                         sampling="device", max_plies=a.max_plies)
     e = sp.engine
-    gather = TupleGatherer(512, xdev) if world > 1 else None
+    gather = TupleGatherer(a.gather_rows, xdev) if world > 1 else None
 
     trainer = None
     if a.train_every > 0 and rank == 0:
         from chinesechesszero_amd.replay import ReplayBuffer
         from chinesechesszero_amd.trainer import Trainer
         torch.manual_seed(1)
-        trainer = Trainer(PolicyValueNet(device=dev, num_channels=a.channels, resblocks_num=a.blocks))
+        # bf16 autocast, no GradScaler: the fp16 scaler's step() reads found_inf on the host and would stall the self-play
+        # launch loop on every update
+        trainer = Trainer(PolicyValueNet(device=dev, num_channels=a.channels, resblocks_num=a.blocks), amp_dtype="bf16")
         rb = ReplayBuffer(32768, dev)
-        # no game finishes within a short bench window: prefill the buffer with synthetic rows so that the
-        # trainer runs at its steady-state cadence next to self-play ("data": "synthetic")
+        # the buffer is prefilled with synthetic rows so that the trainer runs at its steady-state cadence from the first
+        # step ("data": "synthetic"); harvested rows are appended as games finish
         g = torch.Generator(device=dev).manual_seed(2)
         ps = torch.rand((8192, 2086), device=dev, generator=g)
         rb.append((torch.rand((8192, 17, 7, 10, 9), device=dev, generator=g) > 0.9).half(), ps / ps.sum(1, keepdim=True),
                   torch.randint(-1, 2, (8192,), device=dev, generator=g).float())
         side = torch.cuda.Stream(device=dev)
+        side_done = torch.cuda.Event()
+        side_done.record(torch.cuda.current_stream(dev))
         train_steps = [0]
 
-    def per_move():
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    boundary = {"events": [], "host_s": 0.0, "n": 0, "rows": 0, "rows_local": 0, "games": 0, "gather_s": 0.0, "collectives": 0}
+
+    def per_move(timed):
+        """The move boundary: pi + Dirichlet-mixed choice + re-root + push + game end (k_finish_move, k_flip_half), tuple
+        harvest of the games that ended (k_harvest) with restart, and for N > 1 the all-gather of those rows."""
+        t0 = time.perf_counter()
+        if timed:
+            m0, m1 = ev(), ev()
+            m0.record()
         sp.finish_move()
         st = e.game_status()
-        if st["over"].any() or world > 1:
-            s, p, z = e.harvest(max_rows=1 << 21) if st["over"].any() else (e.leaf_input[:0], torch.empty((0, 2086), device=dev), torch.empty((0,), device=dev))
-            if gather is not None:
-                s, p, z = gather.gather(s.to(xdev), p.to(xdev), z.to(xdev))
-            if trainer is not None and s.shape[0]:
-                rb.append(s.to(dev), p.to(dev), z.to(dev))
+        done = int(st["over"].sum())
+        empty = lambda: (e.leaf_input[:0], torch.empty((0, 2086), device=dev), torch.empty((0,), device=dev))
+        if gather is None:
+            chunks = list(e.harvest_chunks(1 << 19)) if done else []
+            rows = sum(int(c[2].shape[0]) for c in chunks)
+            if trainer is not None and rows:
+                torch.cuda.current_stream(dev).wait_event(side_done)  # the trainer's gather reads must not race the append
+                for c in chunks:
+                    rb.append(*c)
+            loc = rows
+        else:
+            it = iter(e.harvest_chunks(gather.cap)) if done else iter(())
+            chunk = next(it, None)
+            rows = loc = 0
+            first = True
+            while True:
+                nxt = next(it, None) if chunk is not None else None
+                s, p, z = chunk if chunk is not None else empty()
+                loc += int(z.shape[0])
+                g0 = time.perf_counter()
+                s, p, z = gather.gather(s.to(xdev), p.to(xdev), z.to(xdev), more=nxt is not None, user=done if first else 0)
+                if timed:
+                    boundary["gather_s"] += time.perf_counter() - g0
+                    boundary["collectives"] += gather.collectives
+                    boundary["games"] += gather.user_sum
+                first = False
+                rows += int(z.shape[0])
+                if trainer is not None and z.shape[0]:
+                    torch.cuda.current_stream(dev).wait_event(side_done)
+                    rb.append(s.to(dev), p.to(dev), z.to(dev))
+                if not gather.any_more:
+                    break
+                chunk = nxt
+        if timed:
+            m1.record()
+            boundary["events"].append((m0, m1))
+            boundary["host_s"] += time.perf_counter() - t0
+            boundary["n"] += 1
+            boundary["rows"] += rows
+            boundary["rows_local"] += loc
+            if gather is None:
+                boundary["games"] += done
 
-    ev = lambda: torch.cuda.Event(enable_timing=True)
     logits_in = bool(getattr(evaluator, "returns_logits", False))
     import ctypes as _C
     from chinesechesszero_amd._lib import check as check_rc
@@ -225,12 +312,26 @@ def main():
                     pairs.append((e0, e1, e2))
             step_no[0] += 1
             if trainer is not None and step_no[0] % a.train_every == 0:
+                side.wait_stream(torch.cuda.current_stream(dev))  # replay-buffer appends (main stream) happen before the sample
                 with torch.cuda.stream(side):
                     trainer.step(*rb.sample(2048), sync=False)
+                    side_done.record(side)
                 train_steps[0] += 1
             if last_of_move:
-                per_move()
+                per_move(timed)
         return pairs
+
+    # ---- untimed setup: steady-state board states, trees warmed with the REAL evaluator up to the point where the
+    # timed window starts, so that the K timed steps straddle a real move boundary of every board (the end of one
+    # move's search, k_finish_move + harvest + restart [+ all-gather], the start of the next move on the kept subtree)
+    t_setup = time.perf_counter()
+    if a.preroll_plies > 0:
+        preroll(e, a.preroll_plies, stagger=True)
+    st_pre = e.game_status()
+    half = min(a.steps, n) // 2
+    phase = (n - half - a.warmup) % n if a.align else 0
+    run(phase, False)
+    setup_s = time.perf_counter() - t_setup
 
     run(a.warmup, False)
     torch.cuda.synchronize()
@@ -244,13 +345,24 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt_local = dt = time.perf_counter() - t0
+    ranks_seen, per_rank = 1, None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=xdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t = torch.zeros(world + 1, dtype=torch.float64, device=xdev)
+        t[0] = dt
+        mx = t[:1].clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        t[0] = 0.0
+        t[1 + rank] = B * a.steps / dt_local
+        cnt = torch.ones(1, dtype=torch.float64, device=xdev)
+        dist.all_reduce(t)
+        dist.all_reduce(cnt)
+        dt = float(mx.item())
+        ranks_seen = int(cnt.item())
+        per_rank = [float(v) for v in t[1:].tolist()]
     s1 = e.stats()
     e.check_healthy()
+    st_end = e.game_status()
     # what a HIP-event pair reports around a trivial kernel on this stream (the floor included in avg_launch_us)
     tiny = torch.zeros(64, device=dev)
     fl = []
@@ -267,32 +379,7 @@ def main():
     # over the whole tower on the activations of a real leaf batch (ReLU-sparse data clocks higher than dense random data)
     net_roofline = None
     if a.evaluator == "net" and rank == 0 and a.channels == 256 and B >= 192 and os.environ.get("CCZ_FUSED_CONV", "1") != "0":
-        import torch.nn.functional as F
-        inf = pvn._infer
-        leaf = state["leaf"] if state["leaf"] is not None else e.select_leaves()
-        with torch.no_grad():
-            x = leaf.view(B, 119, 10, 9)
-            x = torch.cat([x[:, 49:56], x[:, 105:119]], dim=1).to(torch.float16).contiguous(memory_format=torch.channels_last)
-            x0 = inf._epilogue(F.conv2d(x, inf.stem_w, None, padding=1), inf.stem_b)
-            inf._tower_fused(x0.clone(memory_format=torch.preserve_format))
-            xs = [x0.clone(memory_format=torch.preserve_format) for _ in range(3)]
-            c0, c1 = ev(), ev()
-            c0.record()
-            for xi in xs:
-                inf._tower_fused(xi)
-            c1.record()
-        torch.cuda.synchronize()
-        t_conv = c0.elapsed_time(c1) * 1e-3 / (len(xs) * 2 * a.blocks)
-        conv_flops = 2.0 * B * 90 * 256 * 256 * 9
-        net_roofline = {"bound": "mfma", "kernel": "k_conv3x3_c256 (tower conv3x3 256->256 + bias + residual + ReLU, fp16 in / fp32 acc)",
-                        "achieved": conv_flops / t_conv / 1e12, "peak": MFMA_PEAK_F16 / 1e12, "unit": "TFLOP/s",
-                        "frac": conv_flops / t_conv / MFMA_PEAK_F16, "traffic": None, "avg_launch_us": t_conv * 1e6,
-                        "algorithmic_flops_per_launch": conv_flops, "launches_per_step": 2 * a.blocks,
-                        "groups": int(os.environ.get("CCZ_TOWER_GROUPS", "0")) or -(-B // inf.TOWER_GROUP_BOARDS),
-                        "note": "a 'launch' is one layer over the whole batch, issued as groups x chains kernel launches over board ranges "
-                                "(groups one after the other, the chains of a group concurrently)"}
-        per_group = -(-B // net_roofline["groups"])
-        net_roofline["chains"] = max(1, min(int(os.environ.get("CCZ_TOWER_CHAINS", inf.TOWER_CHAINS)), 8, per_group // 256))
+        net_roofline = tower_roofline(a, pvn, e, state, B, ev)
 
     sims = s1["sims"] - s0["sims"]
     exp = max(1, s1["expansions"] - s0["expansions"])
@@ -314,32 +401,51 @@ def main():
         a_step = a_sel + a_exp
         a_sim_survey = a_step - 3780 + 21420
         ach = a_step * B / t_step if t_step == t_step else None
-        traffic = None
+        traffic = traffic_source = None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
             try:
                 with open(pmc) as f:
                     pm = json.load(f)
                 traffic = pm.get("k_step", {}).get("hbm_bytes_per_launch")
+                # NOT measured in this run: rocprofv3 PMC passes cannot run inside bench.py; these are the committed counters
+                traffic_source = f"profiles/pmc_summary.json ({pm.get('run', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, separate runs')}), replayed, not live"
                 if net_roofline is not None:  # HBM bytes of one convolution launch (PMC passes of profiles/run_profile.sh)
                     per_kernel = pm.get("k_conv3x3", {}).get("hbm_bytes_per_launch")
                     net_roofline["traffic"] = per_kernel * net_roofline["chains"] * net_roofline["groups"] if per_kernel else None
+                    net_roofline["traffic_source"] = traffic_source
             except Exception:
                 traffic = None
+        # the move boundary, measured: HIP events around finish_move + harvest/restart (+ exchange) and the host wall
+        # around the same region (the harvest and the exchange read counts on the host)
+        mb_ev = float(np.mean([x.elapsed_time(y) for x, y in boundary["events"]])) if boundary["events"] else None
+        mb_host = 1e3 * boundary["host_s"] / boundary["n"] if boundary["n"] else None
+        step_ms = 1e3 * (dt - boundary["host_s"]) / a.steps  # one simulation step without the boundary share
+        moves_per_sec = world * B / ((n * step_ms + (mb_host or 0.0)) * 1e-3)
         flops = 8.551e9 * (a.blocks / 40.0) * (a.channels / 256.0) ** 2
+        plies0, plies1 = st_pre["plies"], st_end["plies"]
+        net_desc = f"random-init {a.blocks}x{a.channels} policy-value net fp16" if a.evaluator == "net" else "stub evaluator (uniform priors, v=0)"
+        state_desc = (f"boards in steady state (plies 1..{a.preroll_plies} of their games, evenly; games adjudicated at {a.max_plies} plies)"
+                      if a.preroll_plies > 0 else "all boards from the opening position")
         out = {
             "metric": "self-play MCTS simulations/sec", "value": value, "unit": "sims/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 rules / f32 Q / f64 PUCT (net: fp16)", "data": "synthetic",
-            "config": {"workload": f"{B} concurrent boards/GPU x {n} sims/move, Dirichlet root noise on (device Philox), "
-                                   f"{'random-init %dx%d policy-value net fp16' % (a.blocks, a.channels) if a.evaluator == 'net' else 'stub evaluator (uniform priors, v=0)'}"
-                                   ", all boards from the opening position",
-                       "boards_per_gpu": B, "sims_per_move": n, "evaluator": a.evaluator},
-            "moves_per_sec": value / n,
+            "config": {"workload": f"{B} concurrent boards/GPU x {n} sims/move, Dirichlet root noise on (device Philox), " + net_desc + ", " + state_desc,
+                       "boards_per_gpu": B, "sims_per_move": n, "evaluator": a.evaluator,
+                       "preroll_plies": a.preroll_plies, "max_plies": a.max_plies,
+                       "window": f"{a.steps} steps starting at simulation {phase + a.warmup} of a move: "
+                                 f"{boundary['n']} move boundary(ies) inside the timed window"},
+            "moves_per_sec": moves_per_sec,
+            "move_boundary": {"in_window": boundary["n"], "ms_events": mb_ev, "ms_host": mb_host,
+                              "games_finished": boundary["games"], "rows_harvested_rank0": boundary["rows_local"],
+                              "what": "k_finish_move + k_flip_half + status readback + k_harvest + restart" + (" + all-gather" if world > 1 else ""),
+                              "moves_per_sec_formula": "n_gpus * boards / (sims_per_move * (ms_per_step without the boundary) + ms_host)"},
             "roofline": {"bound": "hbm", "kernel": "k_step (fused expand+backup+select+movegen+encode)",
                          "achieved": (ach or 0) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": (ach or 0) / HBM_PEAK,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": a_step * B, "avg_launch_us": t_step * 1e6,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "algorithmic_bytes_per_launch": a_step * B, "avg_launch_us": t_step * 1e6,
                          "k_bar": kbar, "d_bar": dbar, "event_floor_us": event_floor_us},
             "survey_a_sim_bytes": a_sim_survey,
             "step_split_us": {"k_step": t_step * 1e6, "evaluator": t_net * 1e6},
@@ -347,13 +453,51 @@ def main():
             "net_roofline": net_roofline,
             "net_tflops": (flops * B / t_net / 1e12) if (a.evaluator == "net" and t_net == t_net) else None,
             "engine_hbm_gb": s1["hbm_bytes"] / 1e9, "nodes_peak": s1["nodes_peak"], "depth_peak": s1["depth_peak"],
+            "plies": {"start_mean": float(plies0.mean()), "start_max": int(plies0.max()), "end_mean": float(plies1.mean())},
+            "setup_seconds": setup_s,
         }
+        if world > 1:
+            out["multi_gpu"] = {"world_size": world, "ranks_seen": ranks_seen, "backend": a.backend,
+                                "per_rank_sims_per_sec": per_rank, "exchanges_in_window": boundary["n"],
+                                "collectives_in_window": boundary["collectives"], "rows_gathered": boundary["rows"],
+                                "gather_ms": 1e3 * boundary["gather_s"] / max(1, boundary["n"]),
+                                "bytes_sent_per_rank_per_collective": gather.bytes_per_exchange(), "gather_capacity_rows": gather.cap}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_seconds, a.blocks, a.channels)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def tower_roofline(a, pvn, e, state, B, ev):
+    import torch.nn.functional as F
+    inf = pvn._infer
+    leaf = state["leaf"] if state["leaf"] is not None else e.select_leaves()
+    with torch.no_grad():
+        x = leaf.view(B, 119, 10, 9)
+        x = torch.cat([x[:, 49:56], x[:, 105:119]], dim=1).to(torch.float16).contiguous(memory_format=torch.channels_last)
+        x0 = inf._epilogue(F.conv2d(x, inf.stem_w, None, padding=1), inf.stem_b)
+        inf._tower_fused(x0.clone(memory_format=torch.preserve_format))
+        xs = [x0.clone(memory_format=torch.preserve_format) for _ in range(3)]
+        c0, c1 = ev(), ev()
+        c0.record()
+        for xi in xs:
+            inf._tower_fused(xi)
+        c1.record()
+    torch.cuda.synchronize()
+    t_conv = c0.elapsed_time(c1) * 1e-3 / (len(xs) * 2 * a.blocks)
+    conv_flops = 2.0 * B * 90 * 256 * 256 * 9
+    nr = {"bound": "mfma", "kernel": "k_conv3x3_c256 (tower conv3x3 256->256 + bias + residual + ReLU, fp16 in / fp32 acc)",
+          "achieved": conv_flops / t_conv / 1e12, "peak": MFMA_PEAK_F16 / 1e12, "unit": "TFLOP/s",
+          "frac": conv_flops / t_conv / MFMA_PEAK_F16, "traffic": None, "avg_launch_us": t_conv * 1e6,
+          "algorithmic_flops_per_launch": conv_flops, "launches_per_step": 2 * a.blocks,
+          "groups": int(os.environ.get("CCZ_TOWER_GROUPS", "0")) or -(-B // inf.TOWER_GROUP_BOARDS),
+          "note": "a 'launch' is one layer over the whole batch, issued as groups x chains kernel launches over board ranges "
+                  "(groups one after the other, the chains of a group concurrently)"}
+    per_group = -(-B // nr["groups"])
+    nr["chains"] = max(1, min(int(os.environ.get("CCZ_TOWER_CHAINS", inf.TOWER_CHAINS)), 8, per_group // 256))
+    return nr
 
 
 if __name__ == "__main__":

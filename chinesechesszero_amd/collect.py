@@ -6,9 +6,10 @@ Two modes behind the same class:
   * ``n_boards > 1``: the MI355X-native path -- ``BatchedSelfPlay`` runs all games in lockstep on the
     GPU, ``harvest`` materialises (state, pi, z) rows incl. the mirror images on the device, and (with
     ``torch.distributed`` initialised) rows are all-gathered over RCCL.
-Rows go to a ``TupleSink``: ``states.npy / mcts.npy / winners.npy / meta.json`` exactly as the
-reference's convert.py:84-99 produces and dataset.py:45-89 reads (h5py is not part of this image; the
-per-game HDF5 groups of collect.py:146-167 are written instead when h5py is importable).
+Rows go to a ``TupleSink``: shard files while collecting, merged by ``TupleSink.finalize()`` into ``states.npy /
+mcts.npy / winners.npy / meta.json`` with the array names, dtypes and ``meta.json`` keys of the reference's
+convert.py:84-99 (what dataset.py:45-89 reads). h5py is not part of this image: the per-game HDF5 groups of
+collect.py:146-167 are not written.
 """
 from __future__ import annotations
 
@@ -26,83 +27,127 @@ from .tools import flip_map, log
 
 
 class TupleSink:
-    """Append-only store of training rows in the trainer's on-disk format (convert.py:84-99).
+    """Append-only store of training rows in the trainer's on-disk format.
 
-    ``append`` streams every batch of rows to a shard file (host memory stays bounded by one batch: a 4096-board
-    run produces tens of GB of rows); ``flush`` merges old files + shards into ``states.npy / mcts.npy /
-    winners.npy / meta.json`` through memory maps, the same two-pass shape the reference's HDF5 -> .npy
-    converter has (convert.py:21-107).
+    ``append`` streams every batch of rows to its own shard file (host memory stays bounded by one batch: a
+    4096-board run produces tens of GB of rows) and is all a collector does while it runs -- the reference likewise
+    appends one group per game (collect.py:146-167) and leaves the flattening to its offline converter.
+    ``finalize`` is that converter step (convert.py:21-107): old files + shards are merged through memory maps into
+    ``states.npy / mcts.npy / winners.npy`` and ``meta.json`` is written LAST with the keys of convert.py:89-97
+    (``total_count, states_shape, states_dtype, mcts_shape, mcts_dtype, winners_shape, winners_dtype``; plus
+    ``iters``, the game counter the reference keeps in ``data.h5`` attrs). ``mcts.npy`` is float64 by default, the
+    dtype the reference stores (mcts.py:212 ``np.zeros(2086)`` kept as is by collect.py:157-160); ``pi_dtype=np.float32``
+    halves the file. Crash safety: shards are only deleted after ``meta.json`` is in place; a sink opened on a directory
+    that still holds shards adopts them, and ``finalize`` skips arrays that already have their merged length.
     """
 
-    def __init__(self, out_dir: str = DATA_DIR, pi_dtype=np.float32):
+    ARRAYS = {"states": ("_s.npy", np.float16, (17, 7, 10, 9)), "mcts": ("_p.npy", None, (2086,)), "winners": ("_z.npy", np.float32, ())}
+
+    def __init__(self, out_dir: str = DATA_DIR, pi_dtype=np.float64):
         self.out_dir = out_dir
         self.pi_dtype = np.dtype(pi_dtype)
         self._shards: list[tuple[str, int]] = []
         self._next = 0
         self.games = 0
         os.makedirs(out_dir, exist_ok=True)
+        self._merged_rows = 0
         meta = os.path.join(out_dir, "meta.json")
         if os.path.exists(meta):
-            with open(meta) as f:
-                self.games = int(json.load(f).get("iters", 0))
+            with open(meta, encoding="utf-8") as f:
+                m = json.load(f)
+            self.games = int(m.get("iters", 0))
+            self._merged_rows = int(m.get("total_count", 0))
+        state = os.path.join(out_dir, "collect_state.json")
+        if os.path.exists(state):
+            with open(state, encoding="utf-8") as f:
+                self.games = max(self.games, int(json.load(f).get("iters", 0)))
+        # shards a previous (crashed or still unmerged) collector left behind are part of the data set
+        for name in sorted(os.listdir(out_dir)):
+            if name.startswith(".shard_") and name.endswith("_z.npy"):
+                base = os.path.join(out_dir, name[:-len("_z.npy")])
+                if all(os.path.exists(base + sfx) for sfx, _, _ in self.ARRAYS.values()):
+                    self._shards.append((base, int(np.load(base + "_z.npy", mmap_mode="r").shape[0])))
+
+    def _dtype(self, key):
+        return self.pi_dtype if key == "mcts" else np.dtype(self.ARRAYS[key][1])
 
     def append(self, states, pi, z, games: int = 1):
         to_np = lambda t: t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
         s, p, w = to_np(states), to_np(pi), to_np(z)
         self.games += games
-        if len(w) == 0:
-            return
-        base = os.path.join(self.out_dir, f".shard_{os.getpid()}_{self._next:06d}")
-        self._next += 1
-        np.save(base + "_s.npy", s.astype(np.float16, copy=False).reshape(-1, 17, 7, 10, 9))
-        np.save(base + "_p.npy", p.astype(self.pi_dtype, copy=False).reshape(-1, 2086))
-        np.save(base + "_z.npy", w.astype(np.float32, copy=False).reshape(-1))
-        self._shards.append((base, int(len(w))))
+        if len(w):
+            base = os.path.join(self.out_dir, f".shard_{os.getpid()}_{self._next:06d}")
+            while os.path.exists(base + "_z.npy"):
+                self._next += 1
+                base = os.path.join(self.out_dir, f".shard_{os.getpid()}_{self._next:06d}")
+            self._next += 1
+            np.save(base + "_s.npy", s.astype(np.float16, copy=False).reshape(-1, 17, 7, 10, 9))
+            np.save(base + "_p.npy", p.astype(self.pi_dtype, copy=False).reshape(-1, 2086))
+            np.save(base + "_z.npy", w.astype(np.float32, copy=False).reshape(-1))
+            self._shards.append((base, int(len(w))))
+        if games:
+            tmp = os.path.join(self.out_dir, "collect_state.json.tmp")
+            with open(tmp, "w", encoding="utf-8") as f:
+                json.dump({"iters": self.games}, f)
+            os.replace(tmp, os.path.join(self.out_dir, "collect_state.json"))
 
     def rows(self) -> int:
+        """Rows waiting in shards (not yet merged)."""
         return int(sum(n for _, n in self._shards))
 
-    def flush(self) -> int:
-        """Merge what is on disk with the pending shards; returns the total number of rows stored."""
-        names = {"states": ("_s.npy", np.float16, (17, 7, 10, 9)), "mcts": ("_p.npy", self.pi_dtype, (2086,)),
-                 "winners": ("_z.npy", np.float32, ())}
-        paths = {k: os.path.join(self.out_dir, k + ".npy") for k in names}
-        have_old = all(os.path.exists(p) for p in paths.values())
-        n_old = int(np.load(paths["winners"], mmap_mode="r").shape[0]) if have_old else 0
+    def finalize(self) -> int:
+        """Merge what is on disk with the pending shards (the reference's converter step); returns the total row count."""
+        paths = {k: os.path.join(self.out_dir, k + ".npy") for k in self.ARRAYS}
+        n_old = self._merged_rows
         total = n_old + self.rows()
         if total == 0:
             return 0
-        if self._shards:
-            for k, (suffix, dtype, tail) in names.items():
-                if have_old and np.load(paths[k], mmap_mode="r").dtype != np.dtype(dtype):
-                    raise ValueError(f"{paths[k]} holds another dtype than this sink writes")
-                tmp = paths[k] + ".tmp"
-                out = np.lib.format.open_memmap(tmp, mode="w+", dtype=dtype, shape=(total,) + tail)
-                pos = 0
-                if have_old:
-                    old = np.load(paths[k], mmap_mode="r")
-                    out[:n_old] = old
-                    pos = n_old
-                    del old
-                for base, n in self._shards:
-                    out[pos:pos + n] = np.load(base + suffix, mmap_mode="r")
-                    pos += n
-                out.flush()
-                del out
-                os.replace(tmp, paths[k])
-            for base, _ in self._shards:
-                for suffix, _, _ in names.values():
-                    os.remove(base + suffix)
-            self._shards = []
-        with open(os.path.join(self.out_dir, "meta.json"), "w") as f:
-            json.dump({"iters": self.games, "total_samples": total, "state_shape": [17, 7, 10, 9], "state_dtype": "float16",
-                       "mcts_dtype": str(self.pi_dtype), "winner_dtype": "float32"}, f)
+        for k, (suffix, _, tail) in self.ARRAYS.items():
+            dtype = self._dtype(k)
+            have = os.path.exists(paths[k])
+            cur = np.load(paths[k], mmap_mode="r") if have else None
+            if have and cur.dtype != dtype:
+                raise ValueError(f"{paths[k]} holds {cur.dtype}, this sink writes {dtype}")
+            cur_n = int(cur.shape[0]) if have else 0
+            if cur_n == total:
+                continue  # merged by an interrupted finalize(): nothing to redo for this array
+            if cur_n < n_old:
+                raise ValueError(f"{paths[k]} has {cur_n} rows, meta.json says {n_old}")
+            tmp = paths[k] + ".tmp"
+            out = np.lib.format.open_memmap(tmp, mode="w+", dtype=dtype, shape=(total,) + tail)
+            if n_old:
+                out[:n_old] = cur[:n_old]
+            pos = n_old
+            del cur
+            for base, n in self._shards:
+                out[pos:pos + n] = np.load(base + suffix, mmap_mode="r")
+                pos += n
+            out.flush()
+            del out
+            os.replace(tmp, paths[k])
+        meta = {"total_count": int(total),
+                "states_shape": [int(total), 17, 7, 10, 9], "states_dtype": "float16",
+                "mcts_shape": [int(total), 2086], "mcts_dtype": str(self.pi_dtype),
+                "winners_shape": [int(total)], "winners_dtype": "float32",
+                "iters": int(self.games)}
+        tmp = os.path.join(self.out_dir, "meta.json.tmp")
+        with open(tmp, "w", encoding="utf-8") as f:
+            json.dump(meta, f, ensure_ascii=False, indent=2)  # convert.py:98-99
+        os.replace(tmp, os.path.join(self.out_dir, "meta.json"))  # readers trust meta.json: it changes last
+        for base, _ in self._shards:
+            for suffix, _, _ in self.ARRAYS.values():
+                os.remove(base + suffix)
+        self._shards = []
+        self._merged_rows = total
         return total
+
+    flush = finalize  # round-1 name
 
 
 class CollectPipeline:
     def __init__(self, init_model=None, n_boards: int = 1, n_playout: int = PLAYOUT, device: int = 0, seed: int = 0,
-                 data_dir: str = DATA_DIR, reference_quirks: bool = False, num_channels: int = 256, resblocks_num: int = 40):
+                 data_dir: str = DATA_DIR, reference_quirks: bool = False, num_channels: int = 256, resblocks_num: int = 40,
+                 finalize_every: int = 0, on_playout=None):
         self.board = Board()                       # collect.py:28 (never advanced: source of the turn-plane quirk)
         self.game = Game(self.board, reference_quirks=reference_quirks)
         self.temp = 1.0
@@ -120,6 +165,9 @@ class CollectPipeline:
         self.sink = TupleSink(data_dir)
         self.iters = self.sink.games
         self.episode_len = 0
+        self.finalize_every = finalize_every
+        self._finalized_at = self.sink.games
+        self.on_playout = on_playout  # progress sink of the batched path (reference game.py:162-185 feeds a progress bar)
 
     def load_model(self):
         """collect.py:48-62: load once; on failure fall back to a random-init net."""
@@ -179,9 +227,16 @@ class CollectPipeline:
         play_data = self.flip_data(self.preprocess(play_data))
         self.sink.append(np.array([np.asarray(s, dtype=np.float16) for s, _, _ in play_data]),
                          np.array([p for _, p, _ in play_data]), np.array([w for _, _, w in play_data]))
-        self.sink.flush()
         self.iters = self.sink.games
+        self._maybe_finalize()
         return self.iters
+
+    def _maybe_finalize(self):
+        """Rows stay in shards while collecting (the reference appends one group per game, collect.py:146-167, and converts
+        offline); ``finalize_every`` > 0 merges them into the trainer's .npy files every that many games."""
+        if self.finalize_every > 0 and self.sink.games - self._finalized_at >= self.finalize_every:
+            self.sink.finalize()
+            self._finalized_at = self.sink.games
 
     # ---- MI355X path --------------------------------------------------------------------------------
     def collect_batched(self, n_moves: int, gatherer=None):
@@ -194,39 +249,40 @@ class CollectPipeline:
                                             c_puct=self.c_puct, temp=self.temp, seed=self.seed, board_id_base=rank * self.n_boards,
                                             device=self.device, reference_quirks=self.reference_quirks)
         for _ in range(n_moves):
-            self.selfplay.run_move()
+            self.selfplay.run_move(on_playout=self.on_playout)
             st = self.selfplay.engine.game_status()
             done = int(st["over"].sum())
-            if done or gatherer is not None:
+            if gatherer is None:
+                if done:
+                    first = True
+                    for chunk in self.selfplay.harvest_chunks(1 << 19):
+                        self.sink.append(*chunk, games=done if first else 0)
+                        first = False
+            else:
+                # Every rank calls gather() the same number of times: once per move at least (possibly with zero rows), and
+                # again while ANY rank still holds harvest chunks. The "more" flag and the finished-game count ride in the
+                # header of the same collective (no extra all-reduce). Chunks are sized to the gatherer's capacity, so one
+                # chunk is one collective.
                 e = self.selfplay.engine
-                # with an all-gather every rank ends up holding world x chunk rows: keep chunks at ~1 GB per rank
-                it = iter(self.selfplay.harvest_chunks(1 << 15 if gatherer is not None else 1 << 19)) if done else iter(())
+                it = iter(self.selfplay.harvest_chunks(gatherer.cap)) if done else iter(())
+                chunk = next(it, None)
                 first = True
                 while True:
-                    chunk = next(it, None)
-                    if gatherer is None:
-                        if chunk is None:
-                            break
-                        self.sink.append(*chunk, games=done if first else 0)
+                    nxt = next(it, None) if chunk is not None else None
+                    if chunk is None:
+                        chunk = (e.leaf_input[:0], torch.empty((0, 2086), device=e.device), torch.empty((0,), device=e.device))
+                    s, p, z = gatherer.gather(*(t.to(gatherer.device) for t in chunk), more=nxt is not None, user=done if first else 0)
+                    if gatherer.rank == 0:  # the union of the shards goes to ONE store, as N collectors -> one data file
+                        self.sink.append(s, p, z, games=gatherer.user_sum)
                     else:
-                        # ranks finish different numbers of games: keep exchanging until nobody has rows left
-                        more = torch.tensor([0 if chunk is None else 1], device=gatherer.device)
-                        torch.distributed.all_reduce(more, op=torch.distributed.ReduceOp.MAX)
-                        if int(more.item()) == 0:
-                            break
-                        if chunk is None:
-                            chunk = (e.leaf_input[:0], torch.empty((0, 2086), device=e.device), torch.empty((0,), device=e.device))
-                        s, p, z = gatherer.gather(*(t.to(gatherer.device) for t in chunk))
-                        if gatherer.rank == 0:  # the union of the shards goes to ONE store, as N collectors -> one data file
-                            self.sink.append(s, p, z, games=0)
+                        self.sink.games += gatherer.user_sum
                     first = False
-                if gatherer is not None:
-                    n_done = torch.tensor([done], device=gatherer.device)
-                    torch.distributed.all_reduce(n_done)
-                    self.sink.games += int(n_done.item())
+                    if not gatherer.any_more:
+                        break
+                    chunk = nxt
+            self.iters = self.sink.games
+            self._maybe_finalize()
         self.selfplay.engine.check_healthy()
-        self.sink.flush()
-        self.iters = self.sink.games
         return self.iters
 
     def run(self, is_shown=False):
@@ -237,6 +293,8 @@ class CollectPipeline:
                 log(f"Episode {iters}, steps {self.episode_len}")
         except KeyboardInterrupt:
             log("Exit")
+        finally:
+            self.sink.finalize()
 
 
 if __name__ == "__main__":

@@ -218,9 +218,15 @@ class Board:
 class Game:
     """reference game.py:11-237 (self-play and match loops; the SVG viewer hook is out of scope)."""
 
-    def __init__(self, board=None, reference_quirks: bool = False):
+    def __init__(self, board=None, reference_quirks: bool = False, progress=None, viewer=None):
+        """``progress(game_index, step, advanced, total, avg_step_seconds)``: the sink the reference feeds its rich progress
+        bar from (game.py:162-185), called through ``get_action``'s ``on_playout``. ``viewer``: anything with
+        ``update_board(board_text_or_svg, status_text)`` -- the hook ``graphic`` drives (frontend.py ``ChessWindow``,
+        game.py:47-75); without one ``graphic`` logs the text board."""
         self.board = board if board is not None else Board()
         self.reference_quirks = reference_quirks
+        self.progress = progress
+        self.viewer = viewer
         self.red_states = None
         self.black_states = None
         self.reset_states_history()
@@ -240,7 +246,17 @@ class Game:
         self.black_states.insert(0, black_state)
 
     def graphic(self, board):
-        log(str(board))
+        """game.py:47-75: push the position to the viewer window (status line as the reference formats it); the SVG
+        rendering of ``cchess.svg`` is not part of this build, the viewer receives the text board and the FEN."""
+        current_player = "red" if board.turn == RED else "black"
+        status_text = f"to move: {current_player} - ply: {len(board.move_stack)}"
+        if self.viewer is not None:
+            try:
+                self.viewer.update_board(str(board) + "\n" + board.fen(), status_text)
+                return
+            except Exception as e:  # the reference falls back to terminal display when the window fails
+                log(f"viewer update failed: {e}", "WARNING")
+        log(status_text + "\n" + str(board))
 
     def start_play(self, player1, player0, is_shown=False):
         """game.py:77-130: player1 = RED moves first; returns the winner (True/False) or -1 for a draw."""
@@ -266,12 +282,21 @@ class Game:
         """
         self.board = Board()
         self.reset_states_history()
+        import time
         mcts_probs, current_players, histories = [], [], []
         move_count = 0
+        avg_step_time = 0.0
+        total = getattr(getattr(player, "mcts", None), "n_playout", 0)  # game.py:173 reads player.mcts.n_playout
         while True:
             move_count += 1
             current_temp = temp if move_count <= 30 else max(0.1, temp * 0.5)  # game.py:159
-            move, move_probs = player.get_action(self.board, temp=current_temp, return_prob=True, on_playout=None)
+            step_start_time = time.time()
+            on_playout = None
+            if self.progress is not None:  # game.py:162-185: playout progress and the average time per step
+                on_playout = lambda d, _s=move_count, _a=avg_step_time: self.progress(game_index, _s, d, total, _a)
+            move, move_probs = player.get_action(self.board, temp=current_temp, return_prob=True, on_playout=on_playout)
+            step_time = time.time() - step_start_time
+            avg_step_time = (avg_step_time * (move_count - 1) + step_time) / move_count
             prob_sum = np.sum(move_probs)
             if prob_sum > 0:
                 move_probs = move_probs / prob_sum  # game.py:188-190

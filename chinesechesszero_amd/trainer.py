@@ -13,7 +13,10 @@ import torch.nn.functional as F
 
 
 class Trainer:
-    def __init__(self, policy_value_net, label_smoothing: float = 0.05, clip: float = 5.0, lr: float = 1e-3):
+    def __init__(self, policy_value_net, label_smoothing: float = 0.05, clip: float = 5.0, lr: float = 1e-3, amp_dtype: str = "fp16"):
+        """``amp_dtype``: "fp16" = autocast + GradScaler as train.py:163-187 (the scaler's step() reads ``found_inf`` on the
+        host: one sync per update); "bf16" = bf16 autocast without a scaler, no host sync at all (what bench.py's concurrent
+        config-5 trainer uses, so that ``step(sync=False)`` really never waits)."""
         self.pvn = policy_value_net
         self.net = policy_value_net.policy_value_net
         self.opt = policy_value_net.optimizer
@@ -21,8 +24,11 @@ class Trainer:
         self.clip = clip
         for g in self.opt.param_groups:
             g["lr"] = lr
+        if amp_dtype not in ("fp16", "bf16"):
+            raise ValueError("amp_dtype must be 'fp16' or 'bf16'")
         self.use_amp = next(self.net.parameters()).is_cuda
-        self.scaler = torch.amp.GradScaler("cuda", enabled=self.use_amp)
+        self.amp_dtype = torch.float16 if amp_dtype == "fp16" else torch.bfloat16
+        self.scaler = torch.amp.GradScaler("cuda", enabled=self.use_amp and amp_dtype == "fp16")
         self.steps = 0
 
     def step(self, states: torch.Tensor, pi: torch.Tensor, z: torch.Tensor, sync: bool = True) -> dict:
@@ -34,7 +40,7 @@ class Trainer:
             if not ((sums > 0.99) & (sums < 1.01)).all():  # train.py:134-136
                 raise ValueError("mcts_probs rows must sum to 1 (+-0.01)")
         self.opt.zero_grad(set_to_none=True)
-        with torch.autocast("cuda", enabled=self.use_amp):
+        with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.use_amp):
             log_act_probs, value = self.net(states)
             value_loss = F.mse_loss(value.flatten().float(), z)
             target = (1 - self.eps) * pi + self.eps / pi.size(1) if self.eps > 0 else pi

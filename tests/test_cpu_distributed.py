@@ -41,7 +41,11 @@ def _worker_body(rank, world, port, counts_per_round, cap, q):
     ok = True
     for counts in counts_per_round:
         s, p, z = _rows(rank, counts[rank])
-        S, P, Z = g.gather(s, p, z)
+        S, P, Z = g.gather(s, p, z, more=(rank == 1 and counts[1] == 2), user=rank + 1)
+        # ONE collective per exchange unless some rank holds more rows than the buffer; counts, the "more" flag and the
+        # user counter travel in the header of that same collective
+        ok = ok and g.collectives == max(1, -(-max(counts) // cap)) and g.rows_per_rank == list(counts)
+        ok = ok and g.user_sum == 3 and g.any_more == (counts[1] == 2)
         exp = [_rows(r, counts[r]) for r in range(world)]
         ES = torch.cat([e[0] for e in exp])
         EP = torch.cat([e[1] for e in exp])
@@ -136,7 +140,7 @@ class _FakeSelfPlay:
         self.script = script  # per move: list of chunk sizes this rank harvests
         self.move = -1
 
-    def run_move(self):
+    def run_move(self, on_playout=None):
         self.move += 1
         self.engine.over[:] = 0
         self.engine.over[:len(self.script[self.move])] = 1 if self.script[self.move] else 0
@@ -160,12 +164,18 @@ def _collect_worker(rank, world, port, tmp, q):
         cp.sink = TupleSink(os.path.join(tmp, f"rank{rank}"))
         cp.iters = 0
         cp.n_boards = 4
+        cp.finalize_every = 0
+        cp._finalized_at = 0
+        cp.on_playout = None
         cp.load_model = lambda: None
         # rank 0: move 0 -> two chunks (5, 2 rows); move 1 -> nothing; rank 1: move 0 -> nothing; move 1 -> three chunks
         script = {0: [[5, 2], []], 1: [[], [3, 1, 4]]}[rank]
         cp.selfplay = _FakeSelfPlay(rank, script)
         g = TupleGatherer(4, "cpu")
         cp.collect_batched(2, gatherer=g)
+        collectives = g.collectives  # of the last exchange
+        assert not os.path.exists(os.path.join(tmp, f"rank{rank}", "winners.npy"))  # rows stay in shards while collecting
+        cp.sink.finalize()
         n = int(np.load(os.path.join(tmp, f"rank{rank}", "winners.npy")).shape[0]) if os.path.exists(os.path.join(tmp, f"rank{rank}", "winners.npy")) else 0
         q.put((rank, True, n, cp.iters))
         dist.barrier()

@@ -1,0 +1,87 @@
+"""GPU: bench.py as the driver runs it -- the one-line JSON contract at N = 1, and the N = 2 control flow rehearsed
+with two ranks sharing the one GPU of this box over gloo (RCCL refuses two ranks on one device; the real N > 1 run is
+``--backend nccl``, one rank per GPU, launched by the driver).
+
+This file sorts first on purpose: its tests START OTHER PROGRAMS, which a process that has already initialised the
+GPU must not do on this pool. Nothing here touches HIP in the pytest process itself.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--boards", "256", "--blocks", "2", "--channels", "256", "--preroll-plies", "12", "--max-plies", "12"]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _json_line(out: str) -> dict:
+    lines = [l for l in out.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, out[-3000:]
+    return json.loads(lines[0])
+
+
+def _env():
+    env = dict(os.environ)
+    env["CCZ_MIOPEN_FIND"] = "0"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def test_bench_two_ranks_exchange_inside_the_timed_window():
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2",
+           "--backend", "gloo", "--share-gpu", "--gather-rows", "1024", "--playout", "16"] + SMALL
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 2 and j["steps"] == 12 and j["warmup"] == 2 and j["scaling"] == "weak" and j["unit"] == "sims/s"
+    m = j["multi_gpu"]
+    assert m["world_size"] == 2 and m["ranks_seen"] == 2 and m["backend"] == "gloo"
+    # a 12-step window of a 16-simulation move still holds one real move boundary with its exchange: ONE collective
+    assert m["exchanges_in_window"] == 1 and m["collectives_in_window"] == 1
+    # boards 0, 12, 24, ... of each rank stand at the 12-ply cap: 22 games x 12 plies x 2 (mirror images) per rank at least
+    assert m["rows_gathered"] >= 2 * 22 * 12 * 2 and j["move_boundary"]["games_finished"] >= 44
+    assert m["gather_ms"] > 0 and m["bytes_sent_per_rank_per_collective"] == 64 + 1024 * 29768
+    assert len(m["per_rank_sims_per_sec"]) == 2 and all(v > 0 for v in m["per_rank_sims_per_sec"])
+    # whole-job value = all ranks' simulations over the slowest rank's time: never above the sum of the per-rank rates
+    assert 0 < j["value"] <= sum(m["per_rank_sims_per_sec"]) * 1.001
+    assert j["move_boundary"]["in_window"] == 1 and j["move_boundary"]["ms_host"] > 0
+    assert abs(j["ms_per_step"] * 12 * 1e-3 * j["value"] - 2 * 256 * 12) < 1e-3 * 2 * 256 * 12
+
+
+def test_bench_single_gpu_line_contract():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3", "--cpu-baseline-seconds", "3", "--playout", "64"] + SMALL
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    j = _json_line(r.stdout)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["steps"] == 10 and j["warmup"] == 3 and j["higher_is_better"] is True and j["vs_baseline"] is None
+    assert "workload" in j["config"] and "model" not in j["config"]
+    rf = j["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert rf["traffic"] is None or "replayed" in rf["traffic_source"]      # committed counters are labelled as such
+    assert rf["d_bar"] > 1.0                                                # mid-move trees, not the first simulations of move 1
+    mb = j["move_boundary"]
+    assert mb["in_window"] == 1 and mb["games_finished"] >= 22 and mb["rows_harvested_rank0"] >= 22 * 12 * 2
+    assert mb["ms_events"] > 0 and mb["ms_host"] > 0 and j["moves_per_sec"] > 0
+    cb = j["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    nr = j["net_roofline"]
+    assert nr["bound"] == "mfma" and nr["peak"] == 2500.0 and 0 < nr["frac"] < 1
+    assert j["plies"]["start_mean"] > 3
