@@ -226,6 +226,10 @@ def main():
     def per_move(timed):
         """The move boundary: pi + Dirichlet-mixed choice + re-root + push + game end (k_finish_move, k_flip_half), tuple
         harvest of the games that ended (k_harvest) with restart, and for N > 1 the all-gather of those rows."""
+        if timed:
+            # the launch loop runs ahead of the GPU; the boundary's first host read would wait for the queued steps anyway:
+            # drain them here so that the boundary's own wall time is what gets measured (no extra wait in total)
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         if timed:
             m0, m1 = ev(), ev()
@@ -267,6 +271,7 @@ def main():
                 chunk = nxt
         if timed:
             m1.record()
+            torch.cuda.synchronize()
             boundary["events"].append((m0, m1))
             boundary["host_s"] += time.perf_counter() - t0
             boundary["n"] += 1
@@ -281,6 +286,7 @@ def main():
     ptr_of = lambda t: _C.c_void_p(t.data_ptr())
     step_no = [0]
     state = {"leaf": None}
+    trace = []
 
     def run(steps, timed):
         """steps x [evaluator -> fused k_step (expand+backup of this leaf, select of the next)]; a move boundary
@@ -310,6 +316,7 @@ def main():
                 e2.record()
                 if not last_of_move:
                     pairs.append((e0, e1, e2))
+                trace.append((step_no[0] % n, e0, e2))
             step_no[0] += 1
             if trainer is not None and step_no[0] % a.train_every == 0:
                 side.wait_stream(torch.cuda.current_stream(dev))  # replay-buffer appends (main stream) happen before the sample
@@ -381,6 +388,8 @@ def main():
     if a.evaluator == "net" and rank == 0 and a.channels == 256 and B >= 192 and os.environ.get("CCZ_FUSED_CONV", "1") != "0":
         net_roofline = tower_roofline(a, pvn, e, state, B, ev)
 
+    if os.environ.get("CCZ_BENCH_TRACE") and rank == 0:  # per-step GPU time inside the timed window (diagnostics, stderr)
+        print("trace: (simulation index within its move, ms) " + " ".join(f"{i}:{x.elapsed_time(y):.2f}" for i, x, y in trace[:4000]), file=sys.stderr)
     sims = s1["sims"] - s0["sims"]
     exp = max(1, s1["expansions"] - s0["expansions"])
     kbar = (s1["sum_children"] - s0["sum_children"]) / exp

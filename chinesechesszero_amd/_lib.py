@@ -21,11 +21,13 @@ MAX_LEGAL = 128
 MASK_WORDS = 66
 PLANES = 10710
 
+ABI_VERSION = 2
+RULE_PERPETUAL_CHECK = 1
 FLAG_REFERENCE_QUIRKS = 1
 FLAG_NO_MIRROR = 2
 LEAF_EXPAND, LEAF_DRAW, LEAF_LOSS, LEAF_SKIP = 0, 1, 2, 3
 
-ERR_BITS = {1: "node pool exhausted (raise max_nodes)", 2: "selection depth / history chain overflow",
+ERR_BITS = {1: "node pool exhausted (raise max_nodes)", 2: "selection path deeper than max_depth", 64: "history chain overflow (> 128 positions since the last capture)",
             4: "more than 128 legal moves or pseudo-move overflow", 8: "pi record arena overflow",
             16: "forced move is not a child of the root / root not expanded", 32: "NaN priors"}
 
@@ -40,6 +42,7 @@ class Config(C.Structure):
         ("alpha", C.c_float), ("temp", C.c_float), ("max_nodes", C.c_int32), ("max_depth", C.c_int32),
         ("max_plies", C.c_int32), ("flags", C.c_uint32), ("seed", C.c_uint64), ("board_id_base", C.c_uint64),
         ("device", C.c_int32), ("reserve_nodes", C.c_int32),
+        ("move_rank_host", C.c_void_p), ("plane_of_type", C.c_uint8 * 8), ("rule_flags", C.c_uint32), ("reserved0", C.c_uint32),
     ]
 
 
@@ -64,6 +67,7 @@ PROTOTYPES = {
     "ccz_destroy": (C.c_int, [_P]),
     "ccz_reset": (C.c_int, [_P, _P, _P]),
     "ccz_set_position": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32]),
+    "ccz_reset_tree": (C.c_int, [_P, _P, _P]),
     "ccz_select_leaves": (C.c_int, [_P, _P, _P]),
     "ccz_zero_leaf_input": (C.c_int, [_P, _P, _P]),
     "ccz_expand_backup": (C.c_int, [_P, _P, _P, _P]),
@@ -103,7 +107,7 @@ def lib() -> C.CDLL:
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.ccz_abi_version() != 1:
+        if L.ccz_abi_version() != ABI_VERSION:
             raise CczError("libcczero.so ABI version mismatch")
         _lib = L
     return _lib

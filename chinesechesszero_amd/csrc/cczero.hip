@@ -142,6 +142,37 @@ int ccz_create(const ccz_config *cfg, ccz_engine **out)
     d.flags = cfg->flags;
     d.seed = cfg->seed;
     d.board_id_base = cfg->board_id_base;
+    // ---- run-time rule tables (ABI 2)
+    if (cfg->rule_flags & CCZ_RULE_PERPETUAL_CHECK) { delete e; return fail(-6, "ccz_create: CCZ_RULE_PERPETUAL_CHECK is reserved and not implemented"); }
+    if (cfg->rule_flags & ~CCZ_RULE_PERPETUAL_CHECK) { delete e; return fail(-1, "ccz_create: unknown rule_flags 0x%x", cfg->rule_flags); }
+    {
+        uint8_t pot[8] = {0, 0, 1, 2, 3, 4, 5, 6};
+        bool all_zero = true;
+        for (int t = 0; t < 8; ++t) all_zero = all_zero && cfg->plane_of_type[t] == 0;
+        if (!all_zero) {
+            unsigned seen = 0;
+            for (int t = 1; t <= 7; ++t) {
+                const int c = cfg->plane_of_type[t];
+                if (c > 6 || (seen >> c & 1u)) { delete e; return fail(-1, "ccz_create: plane_of_type[1..7] must be a permutation of 0..6"); }
+                seen |= 1u << c;
+                pot[t] = (uint8_t)c;
+            }
+        }
+        d.chanpack = d.typepack = 0;
+        for (int t = 1; t <= 7; ++t) {
+            d.chanpack |= (uint32_t)pot[t] << (3 * t);
+            d.typepack |= (uint32_t)(t - 1) << (3 * pot[t]);
+        }
+    }
+    std::vector<uint16_t> h_rank, h_unrank;
+    if (cfg->move_rank_host) {
+        h_rank.assign(cfg->move_rank_host, cfg->move_rank_host + kNMoves);
+        h_unrank.assign(kNMoves, 0xffff);
+        for (int i = 0; i < kNMoves; ++i) {
+            if (h_rank[i] >= kNMoves || h_unrank[h_rank[i]] != 0xffff) { delete e; return fail(-1, "ccz_create: move_rank_host must be a permutation of 0..2085 (entry %d)", i); }
+            h_unrank[h_rank[i]] = (uint16_t)i;
+        }
+    }
     const size_t B = (size_t)d.B;
     hipError_t he = hipSuccess;
 #define ALLOC(ptr, n)                                                        \
@@ -178,6 +209,15 @@ int ccz_create(const ccz_config *cfg, ccz_engine **out)
     ALLOC(e->st_rowbase, B);
     ALLOC(e->st_mask, B);
     ALLOC(e->st_sq, 96);
+    uint16_t *d_rank = nullptr, *d_unrank = nullptr;
+    if (!h_rank.empty()) {
+        ALLOC(d_rank, kNMoves);
+        ALLOC(d_unrank, kNMoves);
+        if (he == hipSuccess) he = hipMemcpy(d_rank, h_rank.data(), kNMoves * 2, hipMemcpyHostToDevice);
+        if (he == hipSuccess) he = hipMemcpy(d_unrank, h_unrank.data(), kNMoves * 2, hipMemcpyHostToDevice);
+    }
+    d.rank = d_rank;
+    d.unrank = d_unrank;
 #undef ALLOC
     if (he != hipSuccess) {
         for (void *p : e->owned) (void)hipFree(p);
@@ -237,6 +277,21 @@ int ccz_set_position(ccz_engine *e, void *stream, int32_t board, const uint8_t *
     hipLaunchKernelGGL(k_set_position, dim3(1), dim3(64), 0, s, e->d, board, (const uint8_t *)e->st_sq, turn ? 1 : 0, halfmove);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+int ccz_reset_tree(ccz_engine *e, void *stream, const uint8_t *mask_host)
+{
+    NEED(e);
+    hipStream_t s = (hipStream_t)stream;
+    const uint8_t *mask = nullptr;
+    if (mask_host) {
+        HIP_TRY(hipMemcpyAsync(e->st_mask, mask_host, (size_t)e->d.B, hipMemcpyHostToDevice, s));
+        mask = e->st_mask;
+    }
+    hipLaunchKernelGGL(k_reset_tree, dim3((e->d.B + 255) / 256), dim3(256), 0, s, e->d, mask);
+    HIP_TRY(hipGetLastError());
+    if (mask_host) HIP_TRY(hipStreamSynchronize(s)); // st_mask is reused by the next call
     return 0;
 }
 

@@ -81,7 +81,14 @@ struct Dev {
     int32_t *half;     // [1] pool half holding every live tree: flipped once per move for ALL boards, so that tree
                        // addresses (root = node 0, its children = nodes 1..k) are known before any load returns
     unsigned long long *stamps; // [B][16] s_memtime stamps; only written by the diagnostic build (-DCCZ_STAMPS)
+    // run-time rule tables (ccz_config, ABI 2): the two choices no golden trace can pin against cchess
+    const uint16_t *rank;   // [2086] position of move id in `board.legal_moves` order, or nullptr = ascending id
+    const uint16_t *unrank; // [2086] inverse of rank
+    uint32_t chanpack;      // 3 bits per piece type t (bits 3t..3t+2): plane channel of type t (tools.py:100)
+    uint32_t typepack;      // 3 bits per channel c (bits 3c..3c+2): piece type - 1 encoded in channel c
 };
+__device__ __forceinline__ int plane_of(const Dev &D, int type) { return (int)((D.chanpack >> (3 * type)) & 7u); }
+__device__ __forceinline__ int type_in_plane(const Dev &D, int chan) { return (int)((D.typepack >> (3 * chan)) & 7u) + 1; }
 
 // In-kernel stamps (diagnostic build only: profiles/sim_stamps.py builds libcczero_stamps.so with -DCCZ_STAMPS;
 // the shipped kernels contain no stamp). One asm statement: s_memtime + its wait, fenced against reordering.
@@ -313,12 +320,13 @@ struct GenResult {
     bool overflow;
 };
 
-// Legal moves of the side to move as a bitmask over the 2086 action ids (S.mask) and, if ids_out
-// is non-null, as an ascending id list (the canonical `board.legal_moves` order).
+// Legal moves of the side to move as a bitmask (S.mask) and, if ids_out is non-null, as a list in
+// `board.legal_moves` order: ascending id (the canonical order of this build) when rank is null --
+// then bit i of the mask is move id i --, else ascending rank[id] (bit r of the mask is the move of rank r).
 // Lane 4p+d generates direction d of piece p; lane j then tests pseudo-move j for king safety.
 // Must be called by all 64 lanes of the wave; sq[90..95] must be 0.
 __device__ inline GenResult gen_legal(const uint8_t *sq, int turn, GenScratch &S, uint16_t *ids_out, int lane,
-                                   unsigned long long *sp = nullptr)
+                                   unsigned long long *sp = nullptr, const uint16_t *rank = nullptr, const uint16_t *unrank = nullptr)
 {
     GenResult R;
     (void)sp;
@@ -448,8 +456,11 @@ __device__ inline GenResult gen_legal(const uint8_t *sq, int turn, GenScratch &S
         const int mover = sq[fr];
         const int ksq = (mover & 7) == KING ? to : R.ksq;
         if (ksq >= 0 && !king_attacked(sq, S, ksq, fr, to, mover, turn)) {
-            const uint32_t id = c_tab.inv[fr * 90 + to];
-            if (id < (uint32_t)kNMoves) atomicOr(&S.mask[id >> 5], 1u << (id & 31));
+            uint32_t id = c_tab.inv[fr * 90 + to];
+            if (id < (uint32_t)kNMoves) {
+                if (rank) id = rank[id];
+                atomicOr(&S.mask[id >> 5], 1u << (id & 31));
+            }
         }
     }
     wave_sync();
@@ -470,7 +481,7 @@ __device__ inline GenResult gen_legal(const uint8_t *sq, int turn, GenScratch &S
         while (w) {
             const int bit = __ffs((int)w) - 1;
             w &= w - 1;
-            if (o < kMaxLegal) ids_out[o] = (uint16_t)(lane * 32 + bit);
+            if (o < kMaxLegal) ids_out[o] = unrank ? unrank[lane * 32 + bit] : (uint16_t)(lane * 32 + bit);
             ++o;
         }
         if (lane < 2) {
@@ -479,7 +490,7 @@ __device__ inline GenResult gen_legal(const uint8_t *sq, int turn, GenScratch &S
             while (w) {
                 const int bit = __ffs((int)w) - 1;
                 w &= w - 1;
-                if (o < kMaxLegal) ids_out[o] = (uint16_t)((64 + lane) * 32 + bit);
+                if (o < kMaxLegal) ids_out[o] = unrank ? unrank[(64 + lane) * 32 + bit] : (uint16_t)((64 + lane) * 32 + bit);
                 ++o;
             }
         }

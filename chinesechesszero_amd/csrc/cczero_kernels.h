@@ -73,6 +73,19 @@ __global__ __launch_bounds__(64) void k_reset(Dev D, const uint8_t *mask)
     init_board(D, b, lane, 1, 0, true);
 }
 
+// MCTS.update_with_move(-1) (mcts.py:176-178): a fresh root on the live pool half; position, history and record stay
+__global__ void k_reset_tree(Dev D, const uint8_t *mask)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= D.B || (mask && !mask[b])) return;
+    const size_t base = ((size_t)b * 2 + *D.half) * (size_t)D.cap;
+    D.nodeA[base] = NodeA{0, 0.0f, 1.0f, -1};
+    D.nodeB[base] = 0u;
+    D.meta[b].n_nodes = 1;
+    D.path_len[b] = 0;
+    D.leaf_status[b] = CCZ_LEAF_SKIP;
+}
+
 __global__ __launch_bounds__(64) void k_set_position(Dev D, int b, const uint8_t *sq_in, int turn, int halfmove)
 {
     const int lane = threadIdx.x;
@@ -92,9 +105,10 @@ struct LeafEval {
 // s_chain[0..chain_len) holds the keys since the last capture incl. the current position (last)
 __device__ inline LeafEval eval_position(const uint8_t *s_sq, int turn, int halfmove, uint64_t key,
                                          const uint64_t *s_chain, int chain_len, GenScratch &S,
-                                         uint16_t *ids_out, int lane, bool &overflow, unsigned long long *sp = nullptr)
+                                         uint16_t *ids_out, int lane, bool &overflow, unsigned long long *sp = nullptr,
+                                         const uint16_t *rank = nullptr, const uint16_t *unrank = nullptr)
 {
-    const GenResult g = gen_legal(s_sq, turn, S, ids_out, lane, sp);
+    const GenResult g = gen_legal(s_sq, turn, S, ids_out, lane, sp, rank, unrank);
     overflow = g.overflow;
     int rep = 0;
     for (int i0 = 0; i0 < chain_len; i0 += 64) {
@@ -298,7 +312,7 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
         const int first = lastcap >= 0 ? lastcap : 0;
         const int new_len = (lastcap >= 0 ? 0 : chain_len) + (depth - first);
         if (new_len > kChainCap) {
-            set_err(D, 2);
+            set_err(D, 64);
             if (lane == 0) D.leaf_status[b] = CCZ_LEAF_SKIP;
             return;
         }
@@ -332,7 +346,7 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
     unsigned long long *sp = nullptr;
 #endif
     const LeafEval L = eval_position(s_sq, turn, halfmove, key, s_chain, chain_len, sh.S,
-                                     D.leaf_ids + (size_t)b * kMaxLegal, lane, overflow, sp);
+                                     D.leaf_ids + (size_t)b * kMaxLegal, lane, overflow, sp, D.rank, D.unrank);
     if (overflow) set_err(D, 4);
     CCZ_STAMP(D, b, lane, 6)
     if (lane == 0) {
@@ -360,8 +374,8 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
             uint16_t *eh = (uint16_t *)enc;
             const int q0 = s_sq[lane];
             const int q1 = lane < 26 ? s_sq[64 + lane] : 0;
-            if (q0) eh[(q0 >> 3) * 630 + ((q0 & 7) - 1) * 90 + lane] = kHalfOne;
-            if (q1) eh[(q1 >> 3) * 630 + ((q1 & 7) - 1) * 90 + 64 + lane] = kHalfOne;
+            if (q0) eh[(q0 >> 3) * 630 + plane_of(D, q0 & 7) * 90 + lane] = kHalfOne;
+            if (q1) eh[(q1 >> 3) * 630 + plane_of(D, q1 & 7) * 90 + 64 + lane] = kHalfOne;
         }
         wave_sync();
         uint32_t *row = (uint32_t *)(leaf_in + (size_t)b * 10710);
@@ -764,7 +778,7 @@ __global__ __launch_bounds__(64) void k_finish_move(Dev D, const int32_t *forced
     const int turn = m.turn ^ 1;
     int halfmove = cap ? 0 : m.halfmove + 1;
     int chain_len = cap ? 0 : m.chain_len;
-    if (chain_len >= kChainCap) { chain_len = kChainCap - 1; set_err(D, 2); }
+    if (chain_len >= kChainCap) { chain_len = kChainCap - 1; set_err(D, 64); }
     for (int i = lane; i < chain_len; i += 64) s_chain[i] = D.chain[(size_t)b * kChainCap + i];
     if (lane == 0) { s_chain[chain_len] = key; D.chain[(size_t)b * kChainCap + chain_len] = key; }
     ++chain_len;
@@ -831,7 +845,7 @@ __global__ __launch_bounds__(256) void k_harvest(Dev D, const long long *row_bas
                         const int ss = pass ? (s - s % 9) + (8 - s % 9) : s; // np.flip(axis=2): file mirror
                         int tp = te - (g & 7);
                         if (tp < 0) tp = 0;
-                        on = rsq[(size_t)tp * 96 + ss] == ch + 1 + (g >= 8 ? 8 : 0);
+                        on = rsq[(size_t)tp * 96 + ss] == type_in_plane(D, ch) + (g >= 8 ? 8 : 0);
                     }
                     if (on) v |= (uint32_t)kHalfOne << (16 * h);
                 }

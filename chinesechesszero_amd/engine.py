@@ -30,7 +30,11 @@ class SelfPlayEngine:
     def __init__(self, n_boards: int, n_playout: int = 400, c_puct: float = 5, eps: float = 0.25,
                  alpha: float = 0.2, temp: float = 1.0, seed: int = 0, board_id_base: int = 0,
                  device: int = 0, max_nodes: int = 0, max_depth: int = 0, max_plies: int = 0,
-                 reference_quirks: bool = False, mirror: bool = True, reserve_nodes: int = 0):
+                 reference_quirks: bool = False, mirror: bool = True, reserve_nodes: int = 0,
+                 move_rank="tools", plane_of_type="tools"):
+        """``move_rank`` (uint16[2086] permutation, None = ascending id) and ``plane_of_type`` (8 entries, None = type-1)
+        are the run-time rule tables of ``ccz_config`` (ABI 2); the default "tools" takes the process-wide choice of
+        :func:`chinesechesszero_amd.tools.set_rules`."""
         self.L = _lib.lib()
         if not torch.cuda.is_available():
             raise CczError("no GPU visible to PyTorch-ROCm; the engine has no CPU fallback")
@@ -39,10 +43,23 @@ class SelfPlayEngine:
         self.n_playout = int(n_playout)
         flags = (_lib.FLAG_REFERENCE_QUIRKS if reference_quirks else 0) | (0 if mirror else _lib.FLAG_NO_MIRROR)
         self.mirror = mirror
+        from . import tools
+        if isinstance(move_rank, str):
+            move_rank = tools.MOVE_RANK
+        if isinstance(plane_of_type, str):
+            plane_of_type = tools.PLANE_OF_TYPE
         cfg = Config(n_boards=self.B, n_playout=self.n_playout, c_puct=float(c_puct), eps=float(eps),
                      alpha=float(alpha), temp=float(temp), max_nodes=int(max_nodes), max_depth=int(max_depth),
                      max_plies=int(max_plies), flags=flags, seed=int(seed) & (2**64 - 1),
                      board_id_base=int(board_id_base), device=int(device), reserve_nodes=int(reserve_nodes))
+        self.move_rank = None if move_rank is None else np.ascontiguousarray(move_rank, dtype=np.uint16)
+        if self.move_rank is not None:
+            if self.move_rank.shape != (NMOVES,):
+                raise ValueError("move_rank must have 2086 entries")
+            cfg.move_rank_host = self.move_rank.ctypes.data
+        self.plane_of_type = (0, 0, 1, 2, 3, 4, 5, 6) if plane_of_type is None else tuple(int(x) for x in plane_of_type)
+        if plane_of_type is not None:
+            cfg.plane_of_type = (C.c_uint8 * 8)(*self.plane_of_type)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             check(self.L.ccz_create(C.byref(cfg), C.byref(h)))
@@ -72,6 +89,11 @@ class SelfPlayEngine:
     def reset(self, mask=None):
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
         check(self.L.ccz_reset(self.h, self._stream(), _ptr(m)))
+
+    def reset_tree(self, mask=None):
+        """Fresh root on the masked boards (all if None); position, history and game record stay (mcts.py:176-178)."""
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        check(self.L.ccz_reset_tree(self.h, self._stream(), _ptr(m)))
 
     def set_position(self, board: int, squares, turn: int, halfmove: int = 0):
         sq = np.ascontiguousarray(squares, dtype=np.uint8)

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import numpy as np
 
+from . import tools
 from .tools import MOVE_FROM, MOVE_TO, decode_board, is_tie, log, move_action2move_id, move_id2move_action
 
 RED = True
@@ -170,11 +171,12 @@ class Board:
             from .engine import legal_moves
             mask, cnt, flags = legal_moves(self._sq[None, :], np.array([1 if self.turn else 0], np.uint8),
                                            np.array([self.halfmove_clock], np.int32), device=self._device)
-            self._cache = (np.nonzero(mask[0])[0].astype(np.int64).tolist(), int(flags[0]))
+            self._cache = (tools.order_ids(np.nonzero(mask[0])[0].astype(np.int64).tolist()), int(flags[0]))
         return self._cache
 
     def legal_ids(self) -> list[int]:
-        """Legal move ids, ascending (the canonical ``legal_moves`` order of this build)."""
+        """Legal move ids in ``legal_moves`` order: ascending id (the canonical order of this build) or ascending
+        ``tools.MOVE_RANK`` when :func:`tools.set_rules` installed another order."""
         return list(self._rules()[0])
 
     @property

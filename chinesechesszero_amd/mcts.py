@@ -51,8 +51,12 @@ class LeafView:
 
 
 def _planes_to_squares(planes: np.ndarray):
+    from . import tools
     p = planes.reshape(17, 7, 90)
-    types = np.arange(1, 8).reshape(7, 1)
+    types = np.zeros(7, np.int64)
+    for t in range(1, 8):
+        types[tools.PLANE_OF_TYPE[t]] = t   # channel -> piece type
+    types = types.reshape(7, 1)
     return ((p[7] * types).sum(0) + (p[15] * (types + 8)).sum(0)).astype(np.uint8), bool(p[16, 0, 0] > 0)
 
 
@@ -107,12 +111,8 @@ class MCTS:
         assert np.array_equal(e.root_positions()[0], board.squares()), "engine root out of sync with the board"
 
     def _reset_tree_keep_position(self, board):
-        # Node(None, 1.0) (mcts.py:176-178) without losing the game history: replay from the start position
-        e = self._engine
-        start = self._start
-        e.set_position(0, start[0], 1 if start[1] else 0, start[2])
-        for mid in self._synced:
-            e.finish_move(forced_moves=np.array([mid], np.int32), keep_tree=False)
+        # Node(None, 1.0) (mcts.py:176-178): one launch; position, history chain and clocks stay on the engine
+        self._engine.reset_tree()
         self._discard = False
 
     # ---- reference surface ------------------------------------------------------------------------

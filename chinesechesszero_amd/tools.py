@@ -45,6 +45,41 @@ move_id2move_action = {i: s for i, s in enumerate(_names)}
 move_action2move_id = {s: i for i, s in enumerate(_names)}
 
 
+# ---- rule choices that cannot be checked against the absent `cchess` module, as tables -----------
+# MOVE_RANK[id]: position of move id in the iteration order of ``board.legal_moves`` (None = ascending id, this build's
+# canonical order); PLANE_OF_TYPE[t]: channel of piece type t (1..7) in ``decode_board`` (default t-1, tools.py:100 under
+# this build's PIECE_TYPES numbering PAWN 1 .. KING 7). ``set_rules`` changes them for the process -- the analogue of
+# installing another cchess version; engines created afterwards (MCTS, BatchedSelfPlay, ...) pick them up.
+MOVE_RANK: np.ndarray | None = None
+PLANE_OF_TYPE: tuple = (0, 0, 1, 2, 3, 4, 5, 6)
+
+
+def set_rules(move_rank=None, plane_of_type=None):
+    global MOVE_RANK, PLANE_OF_TYPE
+    if move_rank is not None:
+        r = np.ascontiguousarray(move_rank, dtype=np.uint16)
+        if r.shape != (_lib.NMOVES,) or not np.array_equal(np.sort(r), np.arange(_lib.NMOVES)):
+            raise ValueError("move_rank must be a permutation of 0..2085")
+        MOVE_RANK = r
+    else:
+        MOVE_RANK = None
+    if plane_of_type is not None:
+        pt = tuple(int(x) for x in plane_of_type)
+        if len(pt) != 8 or sorted(pt[1:]) != list(range(7)):
+            raise ValueError("plane_of_type must be 8 entries, [1..7] a permutation of 0..6")
+        PLANE_OF_TYPE = (0,) + pt[1:]
+    else:
+        PLANE_OF_TYPE = (0, 0, 1, 2, 3, 4, 5, 6)
+
+
+def order_ids(ids):
+    """Legal move ids in ``board.legal_moves`` order (ascending id, or ascending MOVE_RANK)."""
+    ids = list(ids)
+    if MOVE_RANK is None:
+        return sorted(ids)
+    return sorted(ids, key=lambda i: int(MOVE_RANK[i]))
+
+
 def flip_map() -> np.ndarray:
     """int32[2086]: id -> id of the file-mirrored move (collect.py:118-123)."""
     return _FLIP.copy()
@@ -79,7 +114,7 @@ def decode_board(board):
         occ = np.nonzero(s)[0]
         for i in occ:
             pc = int(s[i])
-            (black if pc & 8 else red)[(pc & 7) - 1, i] = 1
+            (black if pc & 8 else red)[PLANE_OF_TYPE[pc & 7], i] = 1
         return red.reshape(7, 10, 9), black.reshape(7, 10, 9)
     red_state = np.zeros((7, 10, 9), dtype=np.int8)
     black_state = np.zeros((7, 10, 9), dtype=np.int8)
@@ -87,7 +122,7 @@ def decode_board(board):
         for j in range(9):
             piece = board.piece_at(j + i * 9)
             if piece:
-                (red_state if piece.color else black_state)[piece.piece_type - 1, i, j] = 1
+                (red_state if piece.color else black_state)[PLANE_OF_TYPE[piece.piece_type], i, j] = 1
     return red_state, black_state
 
 

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define CCZ_ABI_VERSION 1
+#define CCZ_ABI_VERSION 2
 #define CCZ_NSQ 90
 #define CCZ_SQ_STRIDE 96            /* mailbox row stride in bytes (90 squares + 6 pad)         */
 #define CCZ_NMOVES 2086             /* action space, reference tools.py:172-272                 */
@@ -44,8 +44,14 @@ extern "C" {
 #define CCZ_PLANES 10710            /* 17*7*10*9 evaluator input elements, net.py:174-177       */
 
 /* piece codes in the mailbox: 0 empty, red = type, black = type + 8;
- * types PAWN=1 CANNON=2 ROOK=3 KNIGHT=4 BISHOP=5 ADVISOR=6 KING=7 (channel = type-1, tools.py:100)
+ * types PAWN=1 CANNON=2 ROOK=3 KNIGHT=4 BISHOP=5 ADVISOR=6 KING=7 (the engine's own numbering; the plane
+ * channel a type is encoded into is ccz_config.plane_of_type, default type-1 as tools.py:100 computes it)
  * colours as in cchess: RED = 1 (True), BLACK = 0 (False). square = file + 9*rank (tools.py:91). */
+
+/* ccz_config.rule_flags: rule variants of the absent `cchess` module that cannot be checked here */
+#define CCZ_RULE_PERPETUAL_CHECK 1u /* reserved: adjudicate perpetual check / chase. NOT implemented -- ccz_create
+                                       refuses it (-6); python-chinese-chess may or may not apply such a rule
+                                       [unverified]; the default engine has none                                */
 
 /* flags for ccz_config.flags */
 #define CCZ_FLAG_REFERENCE_QUIRKS 1u /* harvest(): reproduce game.py:234-237 (all samples carry the
@@ -77,6 +83,20 @@ typedef struct ccz_config {
     int32_t reserve_nodes; /* pool nodes kept free at re-root time for the next move's expansions
                               (0 = min(128 x n_playout, max_nodes / 2)); the kept subtree is pruned
                               bottom-up to max_nodes - reserve_nodes                            */
+    /* ---- the two choices the golden traces cannot pin, as run-time tables (ABI 2) ---------------------
+     * move_rank_host: uint16 [2086] host array or NULL. The iteration order of `board.legal_moves`
+     *   (net.py:154-157) decides the children's insertion order (mcts.py:37-39), hence which unvisited
+     *   child is tried first and how PUCT ties break (mcts.py:47-48,59-61). Legal moves are listed in
+     *   ascending move_rank_host[id]; NULL = ascending id (this build's canonical order). Must be a
+     *   permutation of 0..2085. Copied at create.
+     * plane_of_type: channel (0..6) of piece type t = 1..7 inside a colour's 7-plane group, entry 0 unused;
+     *   all zero = {-, 0,1,2,3,4,5,6}, i.e. `piece_type - 1` (tools.py:100) under this build's type numbering.
+     *   With another cchess PIECE_TYPES numbering only this table changes (reference-trained weights see
+     *   their own plane order). Must be a permutation of 0..6. */
+    const uint16_t *move_rank_host;
+    uint8_t plane_of_type[8];
+    uint32_t rule_flags;   /* CCZ_RULE_*                                                         */
+    uint32_t reserved0;
 } ccz_config;
 
 typedef struct ccz_stats {
@@ -99,6 +119,7 @@ typedef struct ccz_stats {
 
 #define CCZ_ERR_NODE_POOL 1   /* a board ran out of tree nodes (raise max_nodes)                 */
 #define CCZ_ERR_DEPTH 2       /* a selection path exceeded max_depth                             */
+#define CCZ_ERR_CHAIN 64      /* more than 128 positions since the last capture (history chain)  */
 #define CCZ_ERR_MOVES 4       /* more than CCZ_MAX_LEGAL legal moves / pseudo-move overflow       */
 #define CCZ_ERR_RECORD 8      /* pi record arena overflow (game adjudicated)                     */
 #define CCZ_ERR_BAD_MOVE 16   /* forced move id invalid / nothing searched and nothing forced    */
@@ -126,6 +147,10 @@ int ccz_reset(ccz_engine *e, void *stream, const uint8_t *mask_host);
  * match play. sq_host: 90 piece codes. */
 int ccz_set_position(ccz_engine *e, void *stream, int32_t board, const uint8_t *sq_host,
                      int32_t turn, int32_t halfmove);
+/* fresh root `Node(None, 1.0)` on the boards whose mask byte is non-zero (NULL = all), keeping position,
+ * history chain, game record and clocks: MCTS.update_with_move(-1) (mcts.py:176-178, what reset_player() and
+ * the non-self-play branch of get_action call, mcts.py:200-201,228-229). The pending leaf is dropped. */
+int ccz_reset_tree(ccz_engine *e, void *stream, const uint8_t *mask_host);
 
 /* ---- one lockstep simulation = select -> (evaluator) -> expand+backup --------------------- */
 /* Replaces the first half of MCTS.playout (mcts.py:101-111) + policy_value_fn's input building

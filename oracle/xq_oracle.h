@@ -75,8 +75,12 @@ void xq_push(xq_board *b, int from, int to);
 int xq_in_check(const xq_pos *p, int color);        /* reverse-ray test          */
 int xq_in_check_slow(const xq_pos *p, int color);   /* independent: enemy movegen */
 int xq_pseudo_moves(const xq_pos *p, int color, uint8_t *from, uint8_t *to);
-/* legal move ids in ASCENDING id order (the canonical `legal_moves` order) */
+/* legal move ids in `board.legal_moves` order: ASCENDING id (the canonical order) unless
+ * xq_set_move_order installed a rank permutation (uint16[2086]; NULL = default) */
 int xq_legal_ids(const xq_board *b, uint16_t *ids);
+void xq_set_move_order(const uint16_t *rank);
+/* channel (0..6) of piece type t = 1..7 in decode_board (tools.py:100); NULL = type-1 */
+void xq_set_plane_map(const uint8_t *plane_of_type);
 int xq_insufficient_material(const xq_board *b);
 int xq_repetition_count(const xq_board *b);
 int xq_fourfold(const xq_board *b);

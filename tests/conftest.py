@@ -38,3 +38,29 @@ def golden():
     with open(os.path.join(g, "action_table.txt")) as f:
         table = f.read().split()
     return {"data": data, "meta": meta, "table": table}
+
+
+@pytest.fixture
+def rules_of_case():
+    """Install the `legal_moves` order a golden case was generated with (oracle and, if asked, the product's host mirror),
+    and restore the defaults afterwards. Returns the rank permutation (or None)."""
+    import numpy as np
+
+    import oracle
+    installed = []
+
+    def install(case, product: bool = False):
+        rank = np.random.RandomState(case["order_seed"]).permutation(2086).astype(np.uint16) if "order_seed" in case else None
+        oracle.set_rules(move_rank=rank)
+        installed.append("oracle")
+        if product:
+            from chinesechesszero_amd import tools
+            tools.set_rules(move_rank=rank)
+            installed.append("product")
+        return rank
+
+    yield install
+    oracle.set_rules()
+    if "product" in installed:
+        from chinesechesszero_amd import tools
+        tools.set_rules()

@@ -131,6 +131,10 @@ CASES = [
     dict(name="rookknight_uniform_n120", start="rook_knight", turn=1, halfmove=0, ev="uniform", n=120, plies=3, temps=[1.0, 1.0, 1.0], seed=11, selfplay=True),
     dict(name="wide80_sharp_n300", start="wide80", turn=1, halfmove=0, ev="hash_sharp", n=300, plies=2, temps=[1.0, 0.5], seed=12, selfplay=True),
     dict(name="pawns_black_n400", start="pawns", turn=0, halfmove=0, ev="hash_sharp", n=400, plies=3, temps=[1.0, 1.0, 0.5], seed=13, selfplay=True),
+    # `board.legal_moves` in a NON-canonical order (rank = RandomState(order_seed).permutation(2086)): children are inserted,
+    # first-visited and tie-broken in that order (mcts.py:37-39,47-48,59-61); pins the engine's run-time move_rank table
+    dict(name="start_sharp_shuffled_n200", start="start", ev="hash_sharp", n=200, plies=3, temps=[1.0, 1.0, 0.5], seed=14, selfplay=True, order_seed=77),
+    dict(name="wide80_uniform_shuffled_n150", start="wide80", turn=1, halfmove=0, ev="uniform", n=150, plies=2, temps=[1.0, 1.0], seed=15, selfplay=True, order_seed=78),
 ]
 
 STARTS = {"two_rooks": endgame_two_rooks, "capture_to_bare": endgame_capture_to_bare, "rook_knight": endgame_rook_knight,
@@ -204,8 +208,12 @@ def main():
         ev = EVALUATORS[case["ev"]]
         n_evals = [0]
 
-        def policy(board, red_states=None, black_states=None, _ev=ev):
+        rank = np.random.RandomState(case["order_seed"]).permutation(2086) if "order_seed" in case else None
+
+        def policy(board, red_states=None, black_states=None, _ev=ev, _rank=rank):
             ids = board.legal_ids()
+            if _rank is not None:  # what iterating a differently ordered `board.legal_moves` would hand to net.py:154-157
+                ids = sorted(ids, key=lambda i: int(_rank[i]))
             p, v = _ev(board.squares()[None, :], np.array([1 if board.turn else 0]))
             n_evals[0] += 1
             # shape/dtypes of net.py:202-205 on the CPU path
@@ -248,6 +256,28 @@ def main():
         out[f"{name}_final_sq"] = board.squares()
         meta["cases"].append({**{k: v for k, v in case.items()}, "plies_done": plies_done, "evals": n_evals[0]})
         print(name, "plies", plies_done, "evals", n_evals[0])
+
+    # ---- G7: decode_board (tools.py:74-106) under ANOTHER piece-type numbering of the rules module: the duck-typed board
+    # reports piece_type = 8 - t (KING 1 .. PAWN 7); pins the engine's run-time plane_of_type table (channel = type_ref - 1)
+    class _AltPiece:
+        def __init__(self, pc):
+            self.piece_type = 8 - (pc & 7)
+            self.color = not bool(pc & 8)
+
+    class _AltBoard:
+        def __init__(self, sq):
+            self._sq = sq
+
+        def piece_at(self, s):
+            pc = int(self._sq[s])
+            return _AltPiece(pc) if pc else None
+
+    for nm, sqs in (("start", OracleBoard().squares()), ("wide80", wide_open_80_moves())):
+        red, black = ref_tools.decode_board(_AltBoard(sqs))
+        out[f"decode_alt_{nm}_sq"] = np.asarray(sqs, dtype=np.uint8)
+        out[f"decode_alt_{nm}_red"] = np.asarray(red)
+        out[f"decode_alt_{nm}_black"] = np.asarray(black)
+    meta["decode_alt_plane_of_type"] = [0, 6, 5, 4, 3, 2, 1, 0]
 
     # ---- G5b: one end-to-end MCTS_AI.get_action call (return_prob=True), nothing done by hand
     ev = EVALUATORS["hash_sharp"]

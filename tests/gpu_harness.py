@@ -8,11 +8,16 @@ from oracle import OracleBoard, OracleMCTS
 from oracle.evaluators import hash_eval, uniform_eval
 
 
-def planes_to_squares(planes: np.ndarray):
-    """leaf input [B,17,7,10,9] (0/1) -> (squares uint8 [B,90], turn [B]); also checks the static zeros."""
+def planes_to_squares(planes: np.ndarray, plane_of_type=None):
+    """leaf input [B,17,7,10,9] (0/1) -> (squares uint8 [B,90], turn [B]); also checks the static zeros.
+    ``plane_of_type``: the engine's piece-type -> channel table (default type-1)."""
     p = planes.reshape(planes.shape[0], 17, 7, 90)
     assert p[:, :7].sum() == 0 and p[:, 8:15].sum() == 0, "history groups must stay zero on the search path"
-    types = np.arange(1, 8, dtype=np.int64)[None, :, None]
+    types = np.arange(1, 8, dtype=np.int64)
+    if plane_of_type is not None:
+        for t in range(1, 8):
+            types[int(plane_of_type[t])] = t
+    types = types[None, :, None]
     red = (p[:, 7] * types).sum(axis=1)
     black = (p[:, 15] * (types + 8)).sum(axis=1)
     assert np.all((p[:, 7].sum(axis=1) + p[:, 15].sum(axis=1)) <= 1)
@@ -58,7 +63,7 @@ class Lockstep:
         e = self.e
         planes = e.leaf_input.float().cpu().numpy()
         info = e.leaf_info()
-        sq, turn = planes_to_squares(planes)
+        sq, turn = planes_to_squares(planes, getattr(e, "plane_of_type", None))
         P, V = self.ev(sq, turn)
         pending = []
         for b in range(self.B):

@@ -1,0 +1,166 @@
+"""GPU: the run-time rule tables of ccz_config (ABI 2) -- `legal_moves` order and piece-type -> plane map --, the
+fresh-root entry point ccz_reset_tree, and the split error bits. The two tables are the choices no golden trace can
+pin against the absent cchess module: they must be switchable without touching a kernel."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(B, n, **kw):
+    from chinesechesszero_amd.engine import SelfPlayEngine
+    return SelfPlayEngine(B, n_playout=n, **kw)
+
+
+def test_shuffled_legal_move_order_matches_oracle_bit_for_bit(rules_of_case):
+    """6 boards, 3 plies x 80 sims with a shuffled `legal_moves` order: the leaf's id list (expansion order), first-visit
+    order, PUCT tie-breaks and hence N/Q/P equal the oracle's under the same rank table; and differ from ascending ids."""
+    from gpu_harness import Lockstep
+    from oracle import OracleBoard
+    B, n = 6, 80
+    rank = rules_of_case({"order_seed": 4242})
+    e = _engine(B, n, seed=9, move_rank=rank)
+    ls = Lockstep(e, [OracleBoard() for _ in range(B)], kind="hash_sharp", salts=[31, 32, 33, 34, 35, 36])
+    first_acts = None
+    for ply in range(3):
+        if ply == 1:
+            ls.run_fused(n, check_leaf=True)
+        else:
+            for _ in range(n):
+                ls.step(check_leaf=True)   # leaf ids are compared with oracle.legal_ids() (rank order) at every step
+        rc = ls.compare_roots()
+        if first_acts is None:
+            first_acts = rc["acts"][0][:rc["k"][0]].astype(int).tolist()
+        pi = e.root_pi(temps=1.0)
+        ls.play([int(rc["acts"][b][int(np.argmax(pi[b][:rc["k"][b]]))]) for b in range(B)])
+    e.check_healthy()
+    assert sorted(first_acts) != first_acts and [int(rank[a]) for a in first_acts] == sorted(int(rank[a]) for a in first_acts)
+    # uniform priors: every PUCT comparison is an exact tie, so the visit pattern IS the order
+    e2 = _engine(1, 50, move_rank=rank)
+    ls2 = Lockstep(e2, [OracleBoard()], kind="uniform")
+    for _ in range(50):
+        ls2.step(check_leaf=True)
+    rc2 = ls2.compare_roots()
+    assert rc2["visits"][0][:44].tolist() == [2] * 5 + [1] * 39  # 49 descents over 44 children in insertion order
+    with pytest.raises(Exception, match="permutation"):
+        _engine(1, 4, move_rank=np.zeros(2086, np.uint16))
+
+
+def test_plane_map_switches_the_encoding_everywhere(golden):
+    """plane_of_type (channel of a piece type, tools.py:100) reaches the evaluator input of the search path AND the
+    harvested training states; checked against the reference's own decode_board run under that numbering (golden G7)."""
+    import oracle
+    from gpu_harness import Lockstep
+    from oracle import OracleBoard
+    pot = golden["meta"]["decode_alt_plane_of_type"]
+    d = golden["data"]
+    try:
+        oracle.set_rules(plane_of_type=pot)
+        e = _engine(2, 8, seed=1, plane_of_type=pot, max_plies=3)
+        e.set_position(1, d["decode_alt_wide80_sq"], 1, 0)
+        leaf = e.select_leaves().float().cpu().numpy()
+        assert np.array_equal(leaf[0][7], d["decode_alt_start_red"]) and np.array_equal(leaf[0][15], d["decode_alt_start_black"])
+        assert np.array_equal(leaf[1][7], d["decode_alt_wide80_red"]) and np.array_equal(leaf[1][15], d["decode_alt_wide80_black"])
+        boards = [OracleBoard(), OracleBoard.from_array(d["decode_alt_wide80_sq"], 1, 0)]
+        ls = Lockstep(e, boards, kind="hash", salts=[1, 2])
+        for ply in range(3):
+            for _ in range(8):
+                ls.step(check_leaf=True)      # planes compared with oracle.leaf_planes() under the same map
+            rc = ls.compare_roots()
+            ls.play([int(rc["acts"][b][0]) for b in range(2)])
+        for _ in range(8):
+            ls.step(check_leaf=True)
+        e.finish_move()                        # ply cap 3 -> both games adjudicated
+        assert e.game_status()["over"].all()
+        states, pi, z = e.harvest()
+        states = states.cpu().numpy()
+        assert states.shape[0] == 2 * 3 * 2
+        assert np.array_equal(states[0][0], d["decode_alt_start_red"]) and np.array_equal(states[0][8], d["decode_alt_start_black"])
+        assert np.array_equal(states[6][0], d["decode_alt_wide80_red"]) and np.array_equal(states[6][8], d["decode_alt_wide80_black"])
+        e.check_healthy()
+    finally:
+        oracle.set_rules()
+    e0 = _engine(1, 4)
+    assert not np.array_equal(e0.select_leaves().float().cpu().numpy()[0][7], d["decode_alt_start_red"])  # default map differs
+    with pytest.raises(Exception, match="permutation"):
+        _engine(1, 4, plane_of_type=[0, 1, 1, 2, 3, 4, 5, 6])
+
+
+def test_host_mirror_follows_installed_rules(rules_of_case):
+    """tools.set_rules: Board.legal_ids / legal_moves iterate in the installed order, MCTS engines are created with it, and
+    a reference-style policy_value_fn therefore sees (and expands) the moves in that order."""
+    from chinesechesszero_amd import tools
+    from chinesechesszero_amd.game import Board
+    from chinesechesszero_amd.mcts import MCTS
+    from oracle import OracleBoard
+    from oracle.evaluators import hash_eval
+    rank = rules_of_case({"order_seed": 99}, product=True)
+    b = Board()
+    ob = OracleBoard()
+    assert b.legal_ids() == ob.legal_ids() and [m.uci() for m in b.legal_moves] == ob.legal_moves
+    seen = []
+
+    def policy(board, red_states=None, black_states=None):
+        ids = board.legal_ids()
+        seen.append(list(ids))
+        p, v = hash_eval(board.squares()[None, :], np.array([1 if board.turn else 0]), salt=5, scale=40.0)
+        return zip(ids, p[0][ids]), np.array([[v[0]]], dtype=np.float32)
+
+    m = MCTS(policy, c_puct=5, n_playout=30)
+    acts, probs = m.get_move_probs(b, temp=1.0)
+    assert list(acts) == ob.legal_ids() and seen[0] == ob.legal_ids()
+    assert tools.MOVE_RANK is not None and np.array_equal(m._engine.move_rank, rank)
+
+
+def test_reset_tree_keeps_position_history_and_record():
+    """ccz_reset_tree == MCTS.update_with_move(-1) (mcts.py:176-178): fresh root, everything else stays -- in particular
+    the repetition history, which a set_position-based reset would lose."""
+    from gpu_harness import Lockstep
+    from oracle import OracleBoard
+    B, n = 3, 40
+    e = _engine(B, n, seed=2)
+    boards = [OracleBoard() for _ in range(B)]
+    ls = Lockstep(e, boards, kind="hash_sharp", salts=[5, 6, 7])
+    # a repetition cycle on board 0 and 1 (knights out and back, twice), something else on board 2
+    cyc = (["b0c2", "b9c7", "c2b0", "c7b9"] * 3)[:11]   # after 11 plies the reply c7b9 repeats the start position a 4th time
+    other = ["h2e2", "h9g7", "e2e6", "g7e6", "b0c2", "b9c7", "a0a1", "a9a8", "i0i1", "i9i8", "a1a2"]
+    import oracle
+    L = oracle.lib()
+    uid = lambda u: L.xq_move_id((ord(u[0]) - 97) + 9 * int(u[1]), (ord(u[2]) - 97) + 9 * int(u[3]))
+    for i in range(11):
+        assert all(uid(u) in boards[b].legal_ids() for b, u in enumerate((cyc[i], cyc[i], other[i])))
+        ls.play([uid(cyc[i]), uid(cyc[i]), uid(other[i])])
+    for _ in range(n):
+        ls.step(check_leaf=True)
+    ls.compare_roots()
+    plies0, pos0 = e.game_status()["plies"].copy(), e.root_positions().copy()
+    e.reset_tree(np.array([1, 0, 1], np.uint8))
+    ls.mcts[0].update_with_move(-1)
+    ls.mcts[2].update_with_move(-1)
+    rc = e.root_children()
+    assert rc["k"][0] == 0 and rc["k"][2] == 0 and rc["root_visits"][0] == 0 and rc["k"][1] > 0
+    assert np.array_equal(e.game_status()["plies"], plies0) and np.array_equal(e.root_positions(), pos0)
+    # the search after the reset still sees the game history: the start position is on the chain three times, so the
+    # reply that repeats it a fourth time is a draw leaf for engine and oracle alike (leaf status compared every step)
+    t0 = e.stats()["terminal_leaves"]
+    for _ in range(n):
+        ls.step(check_leaf=True)
+    ls.compare_roots()
+    assert e.stats()["terminal_leaves"] > t0
+    e.check_healthy()
+
+
+def test_rule_flag_stub_and_error_bits():
+    from chinesechesszero_amd import _lib
+    from chinesechesszero_amd._lib import CczError
+    L = _lib.lib()
+    cfg = _lib.Config(n_boards=2, n_playout=4, c_puct=5, eps=0.25, alpha=0.2, temp=1.0, rule_flags=_lib.RULE_PERPETUAL_CHECK)
+    h = C.c_void_p()
+    assert L.ccz_create(C.byref(cfg), C.byref(h)) == -6 and b"not implemented" in L.ccz_last_error()
+    cfg.rule_flags = 8
+    assert L.ccz_create(C.byref(cfg), C.byref(h)) == -1
+    # the two overflow kinds report separate bits (round 1 shared bit 2)
+    assert _lib.ERR_BITS[2] != _lib.ERR_BITS[64] and "chain" in _lib.ERR_BITS[64] and "depth" in _lib.ERR_BITS[2]

@@ -72,8 +72,8 @@ def test_uniform_priors_exact_ties_first_max_order():
     e.check_healthy()
 
 
-@pytest.mark.parametrize("idx", range(13))
-def test_golden_traces_from_reference_mcts(golden, idx):
+@pytest.mark.parametrize("idx", range(15))
+def test_golden_traces_from_reference_mcts(golden, idx, rules_of_case):
     """Visit counts / Q / priors equal the numbers the reference's own mcts.py produced (bit-exact),
     pi within 1e-12, with the golden moves forced (tree reuse across plies)."""
     from gpu_harness import Lockstep
@@ -82,7 +82,8 @@ def test_golden_traces_from_reference_mcts(golden, idx):
     d = golden["data"]
     name = case["name"]
     sqs, turn, half = case_start(case)
-    e = _engine(1, case["n"])
+    rank = rules_of_case(case)  # cases 13, 14: a shuffled `legal_moves` order through ccz_config.move_rank_host
+    e = _engine(1, case["n"], move_rank=rank)
     if case["start"] != "start":
         e.set_position(0, sqs, turn, half)
         ob = OracleBoard.from_array(sqs, turn, half)

@@ -64,10 +64,19 @@ def _make_eval(name):
     return f
 
 
-@pytest.mark.parametrize("idx", range(13))
-def test_search_trace_matches_reference(golden, idx):
+N_CASES = 15  # 13 in the canonical ascending-id order + 2 with a shuffled `legal_moves` order (order_seed)
+
+
+def test_case_count(golden):
+    assert len(golden["meta"]["cases"]) == N_CASES
+    assert sum("order_seed" in c for c in golden["meta"]["cases"]) == 2
+
+
+@pytest.mark.parametrize("idx", range(N_CASES))
+def test_search_trace_matches_reference(golden, idx, rules_of_case):
     """Visit counts, Q, priors bit-exact; pi to 1e-12; sampled moves identical under np.random.seed."""
     case = golden["meta"]["cases"][idx]
+    rules_of_case(case)
     d = golden["data"]
     name = case["name"]
     sqs, turn, half = case_start(case)
@@ -110,3 +119,34 @@ def test_terminal_values_reached_in_traces(golden):
     mcts = OracleMCTS(_make_eval(case["ev"]), c_puct=5, n_playout=case["n"])
     mcts.get_move_probs(board, 1.0)
     assert mcts.n_evals < case["n"]  # the oracle skips the evaluator on terminal leaves (results-neutral)
+
+
+def test_shuffled_order_changes_the_search(golden):
+    """The shuffled-order traces are NOT what the canonical order gives: the order is load-bearing (mcts.py:47-48,59-61)."""
+    case = [c for c in golden["meta"]["cases"] if c["name"] == "start_sharp_shuffled_n200"][0]
+    d = golden["data"]
+    mcts = OracleMCTS(_make_eval(case["ev"]), c_puct=5, n_playout=case["n"])
+    acts, visits, _ = mcts.get_move_probs(OracleBoard(), 1.0)
+    assert sorted(acts.tolist()) == sorted(d["start_sharp_shuffled_n200_p0_acts"].tolist())
+    assert not np.array_equal(acts, d["start_sharp_shuffled_n200_p0_acts"])
+    by_id = dict(zip(d["start_sharp_shuffled_n200_p0_acts"].tolist(), d["start_sharp_shuffled_n200_p0_visits"].tolist()))
+    assert [by_id[a] for a in acts.tolist()] != visits.tolist()
+
+
+def test_decode_board_under_another_piece_type_numbering(golden):
+    """decode_board (tools.py:74-106) as the reference computes it when the rules module numbers KING 1 .. PAWN 7:
+    the oracle's plane map (twin of ccz_config.plane_of_type) reproduces the reference's planes."""
+    d = golden["data"]
+    pot = golden["meta"]["decode_alt_plane_of_type"]
+    try:
+        oracle.set_rules(plane_of_type=pot)
+        for nm in ("start", "wide80"):
+            b = OracleBoard.from_array(d[f"decode_alt_{nm}_sq"], 1, 0)
+            red, black = b.decode()
+            assert np.array_equal(red, d[f"decode_alt_{nm}_red"]) and np.array_equal(black, d[f"decode_alt_{nm}_black"])
+            planes = b.leaf_planes()
+            assert np.array_equal(planes[7], d[f"decode_alt_{nm}_red"]) and np.array_equal(planes[15], d[f"decode_alt_{nm}_black"])
+    finally:
+        oracle.set_rules()
+    red, black = OracleBoard().decode()
+    assert not np.array_equal(red, d["decode_alt_start_red"])  # the default numbering gives other planes
