@@ -25,25 +25,41 @@ class BatchedMatch:
         # eps = 0: the sampling distribution is pi itself (mcts.py:227), drawn from the board's Philox stream
         self.engine = SelfPlayEngine(n_boards, n_playout=n_playout, c_puct=c_puct, eps=0.0, alpha=0.2, temp=temp,
                                      seed=seed, device=device, max_plies=max_plies, mirror=False)
+        self.before_move = self.on_move = None
+        self._temps = np.full(n_boards, temp, np.float64)
 
-    def play(self, max_moves: int = 4096):
-        """Play every board to the end. Returns dict(red_wins, black_wins, draws, plies)."""
+    def play_move(self, turn: int):
+        """One lockstep move of every unfinished board by the player of colour ``turn`` (1 RED, 0 BLACK): n_playout
+        simulations on a fresh tree, move ~ pi at temperature 1e-3, tree discarded (mcts.py:225-229). Returns the moves
+        played (host int32 [B], -1 on finished boards)."""
         e = self.engine
-        temps = np.full(self.B, self.temp, np.float64)
+        ev = self.ev[turn]
+        leaf = e.select_leaves()
+        for i in range(self.n_playout):
+            prob, value = ev(leaf)
+            if i + 1 < self.n_playout:
+                leaf = e.step(prob, value)
+            else:
+                e.expand_backup(prob, value)
+        if self.before_move is not None:
+            self.before_move(self)
+        moves = e.finish_move(temps=self._temps, keep_tree=False).cpu().numpy()
+        if self.on_move is not None:
+            self.on_move(self, moves)
+        return moves
+
+    def play(self, max_moves: int = 4096, before_move=None, on_move=None):
+        """Play every board to the end. Returns dict(red_wins, black_wins, draws, plies). ``before_move(match)`` runs after
+        the search and before the move of every lockstep ply, ``on_move(match, moves)`` right after it (tests, logging)."""
+        e = self.engine
+        self.before_move, self.on_move = before_move, on_move
+        self._temps = np.full(self.B, self.temp, np.float64)
         turn = 1
         for _ in range(max_moves):
             st = e.game_status()
             if st["over"].all():
                 break
-            ev = self.ev[turn]
-            leaf = e.select_leaves()
-            for i in range(self.n_playout):
-                prob, value = ev(leaf)
-                if i + 1 < self.n_playout:
-                    leaf = e.step(prob, value)
-                else:
-                    e.expand_backup(prob, value)
-            e.finish_move(temps=temps, keep_tree=False)
+            self.play_move(turn)
             turn ^= 1
         st = e.game_status()
         e.check_healthy()

@@ -256,6 +256,14 @@ class InferenceNet(nn.Module):
         if self._use_fused_tower(x):
             x = self._tower_fused(x)
         else:
+            if x.is_cuda and x.dtype == torch.float16 and os.environ.get("CCZ_FUSED_CONV", "1") != "0":
+                key = (int(x.shape[0]), int(x.shape[1]))
+                seen = self.__dict__.setdefault("_off_fused_seen", set())
+                if key not in seen:  # once per shape: the caller should know this batch does not run on the MFMA kernel
+                    seen.add(key)
+                    from .tools import log
+                    log(f"evaluator: batch of {key[0]} boards x {key[1]} channels is off the fused tower kernel "
+                        f"(k_conv3x3_c256 serves 256 channels at >= {self.FUSED_MIN_BOARDS} boards): MIOpen convolutions + one-pass epilogue")
             for i in range(0, len(self.ws), 2):
                 y = self._epilogue(F.conv2d(x, self.ws[i], None, padding=1), self.bs[i])
                 x = self._epilogue(F.conv2d(y, self.ws[i + 1], None, padding=1), self.bs[i + 1], x)
@@ -289,6 +297,12 @@ class PolicyValueNet:
             self.policy_value_net.load_state_dict(torch.load(model, map_location=self.device))
         self._infer = None
         self._graph = None
+        self.weights_version = 0  # bumped whenever the inference copy is rebuilt or invalidated (hipGraphs hold its addresses)
+
+    def invalidate_inference_copy(self):
+        """The training weights changed: the fp16 inference copy is stale (rebuilt on the next evaluation)."""
+        self._infer = None
+        self.weights_version += 1
 
     # ---- batched evaluator for the lockstep engine -------------------------------------------
     def refresh_inference_copy(self):
@@ -298,6 +312,7 @@ class PolicyValueNet:
         self.policy_value_net.eval()
         self._infer = InferenceNet(self.policy_value_net).to(self.device).eval()
         self._graph = None
+        self.weights_version += 1
         return self._infer
 
     @torch.no_grad()
@@ -379,7 +394,7 @@ class PolicyValueNet:
         self.optimizer.step()
         with torch.no_grad():
             entropy = -torch.mean(torch.sum(torch.exp(log_act_probs) * log_act_probs, dim=1))
-        self._infer = None
+        self.invalidate_inference_copy()
         return loss.detach().cpu().numpy(), entropy.detach().cpu().numpy()
 
 

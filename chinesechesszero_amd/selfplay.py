@@ -25,14 +25,29 @@ class GraphedStep:
 
     def __init__(self, engine: SelfPlayEngine, evaluator, warmup: int = 3):
         self.engine = engine
+        self.evaluator = evaluator
+        self.warmup = warmup
+        self.captures = 0
+        self._capture()
+
+    def _weights_version(self):
+        """The captured graph holds the device addresses of the evaluator's inference weights. ``PolicyValueNet`` bumps
+        ``weights_version`` whenever that copy is rebuilt or invalidated (training step, hot reload): a replay against
+        the old addresses would silently search with stale or freed weights."""
+        owner = getattr(self.evaluator, "__self__", None)
+        return getattr(owner, "weights_version", None)
+
+    def _capture(self):
+        engine, evaluator = self.engine, self.evaluator
         dev = engine.device
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            for _ in range(warmup):  # results are discarded: the pending leaf is only evaluated, never stepped
-                evaluator(engine.leaf_input)
+            for _ in range(self.warmup):  # results are discarded: the pending leaf is only evaluated, never stepped
+                evaluator(engine.leaf_input)  # (also rebuilds a stale inference copy OUTSIDE the capture)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        self.version = self._weights_version()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             prob, value = evaluator(engine.leaf_input)
@@ -41,8 +56,11 @@ class GraphedStep:
             else:
                 engine.step(prob, value)
         # capture does not execute: nothing has been applied to the trees yet
+        self.captures += 1
 
     def replay(self):
+        if self._weights_version() != self.version:
+            self._capture()  # weights changed since the capture (train_step / refresh_inference_copy / broadcast_model)
         self.graph.replay()
 
 

@@ -54,6 +54,6 @@ class Trainer:
         self.steps += 1
         with torch.no_grad():
             entropy = -torch.mean(torch.sum(torch.exp(log_act_probs.float()) * log_act_probs.float(), dim=1))
-        self.pvn._infer = None  # the inference copy is stale now; refresh_inference_copy() / broadcast_model() rebuilds it
+        self.pvn.invalidate_inference_copy()  # stale now (and captured hipGraphs with it); rebuilt on the next evaluation
         out = {"loss": loss.detach(), "policy_loss": policy_loss.detach(), "value_loss": value_loss.detach(), "entropy": entropy}
         return {k: float(v) for k, v in out.items()} if sync else out  # sync=False: no host wait (concurrent self-play)

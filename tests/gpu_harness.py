@@ -134,3 +134,59 @@ class Lockstep:
             if m >= 0:
                 self.mcts[b].update_with_move(int(m))
                 self.boards[b].push_id(int(m))
+
+
+class SampleMirror:
+    """A big lockstep batch with a SAMPLE of its boards mirrored on sequential oracles.
+
+    The device evaluator runs on all B leaves; the rows of the sampled boards are copied to the host and the SAME
+    float32 numbers are fed to the oracle's expansion/backup, so N / Q / P of the sampled trees must agree bit for bit
+    with the engine's at full batch size (the batched evaluator itself is not what is being compared)."""
+
+    def __init__(self, engine, sample, boards=None, c_puct=5, check_every=16):
+        self.e = engine
+        self.sample = [int(b) for b in sample]
+        self.boards = boards if boards is not None else [OracleBoard() for _ in self.sample]
+        self.mcts = [OracleMCTS(None, c_puct=c_puct, n_playout=0) for _ in self.sample]
+        self.idx = torch.as_tensor(self.sample, device=engine.device, dtype=torch.long)
+        self.check_every = check_every
+        self.steps = 0
+
+    def backup_on_oracles(self, prob, value):
+        """Call after the evaluator, BEFORE the engine consumes (prob, value): the oracles select the same leaf and back the
+        same numbers up."""
+        e = self.e
+        P = prob.index_select(0, self.idx).cpu().numpy()
+        V = value.index_select(0, self.idx).cpu().numpy()
+        info = e.leaf_info() if self.steps % self.check_every == 0 else None
+        for j, b in enumerate(self.sample):
+            leaf, depth = self.mcts[j].select(self.boards[j])
+            ids = leaf.legal_ids()
+            if info is not None and info["status"][b] != 3:
+                assert depth == info["depth"][b] and info["k"][b] == len(ids), (b, depth, info["depth"][b])
+                assert info["ids"][b][:len(ids)].tolist() == ids, b
+                end, tie = leaf.is_game_over(), leaf.is_tie()
+                assert info["status"][b] == (0 if (not end and not tie) else (1 if (end and tie) else 2)), b
+            self.mcts[j].expand_backup(leaf, ids, P[j][ids], V[j])
+        self.steps += 1
+
+    def compare_roots(self, rc=None):
+        rc = self.e.root_children() if rc is None else rc
+        for j, b in enumerate(self.sample):
+            acts, visits, q, prior = self.mcts[j].root_children()
+            k = len(acts)
+            assert rc["k"][b] == k, (b, rc["k"][b], k)
+            assert np.array_equal(rc["acts"][b][:k], acts.astype(np.uint16)), b
+            assert np.array_equal(rc["visits"][b][:k], visits), (b, rc["visits"][b][:k], visits)
+            assert np.array_equal(rc["q"][b][:k].view(np.uint32), q.view(np.uint32)), b
+            assert np.array_equal(rc["prior"][b][:k].view(np.uint32), prior.view(np.uint32)), b
+            assert rc["root_visits"][b] == self.mcts[j].root_visits(), b
+        return rc
+
+    def played(self, moves, keep_tree=True):
+        """The engine played ``moves`` (int array [B], -1 = none): follow on the oracles."""
+        for j, b in enumerate(self.sample):
+            m = int(moves[b])
+            if m >= 0:
+                self.mcts[j].update_with_move(m if keep_tree else -1)
+                self.boards[j].push_id(m)

@@ -1,0 +1,106 @@
+"""CPU: the trainer-format tuple sink against the file format the reference's converter writes
+(convert.py:84-99) and its dataset reads (dataset.py:45-89). No GPU needed: rows are synthetic."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rows(n, seed):
+    rs = np.random.RandomState(seed)
+    s = (rs.rand(n, 17, 7, 10, 9) > 0.9).astype(np.float16)
+    p = rs.rand(n, 2086)
+    p /= p.sum(1, keepdims=True)
+    z = rs.choice([-1.0, 0.0, 1.0], size=n).astype(np.float32)
+    return s, p, z
+
+
+def test_meta_json_is_the_converters(tmp_path):
+    """tests/golden/meta_reference_format.json is hand-derived from convert.py:89-99 for 160 float64 rows: same keys, same
+    order, same values, same text layout (json.dump(..., ensure_ascii=False, indent=2)); `iters` is this build's one extra key."""
+    from chinesechesszero_amd.collect import TupleSink
+    sink = TupleSink(str(tmp_path))
+    s, p, z = _rows(160, 0)
+    sink.append(s[:100], p[:100], z[:100], games=3)
+    sink.append(s[100:], p[100:], z[100:], games=2)
+    assert not os.path.exists(tmp_path / "states.npy") and sink.rows() == 160      # collecting never rewrites the data set
+    assert sink.finalize() == 160
+    golden_text = open(os.path.join(ROOT, "tests", "golden", "meta_reference_format.json"), encoding="utf-8").read()
+    golden = json.loads(golden_text)
+    text = open(tmp_path / "meta.json", encoding="utf-8").read()
+    meta = json.loads(text)
+    assert list(meta)[:len(golden)] == list(golden) and all(meta[k] == golden[k] for k in golden)
+    assert list(meta)[len(golden):] == ["iters"] and meta["iters"] == 5
+    assert text.startswith(golden_text.rstrip()[:-1].rstrip())                       # byte-identical up to the extra key
+    assert np.load(tmp_path / "mcts.npy").dtype == np.float64 and np.array_equal(np.load(tmp_path / "mcts.npy"), p)
+    assert np.array_equal(np.load(tmp_path / "states.npy"), s) and np.array_equal(np.load(tmp_path / "winners.npy"), z)
+    assert not [f for f in os.listdir(tmp_path) if f.startswith(".shard_")]
+
+
+def test_incremental_finalize_resume_and_dataset(tmp_path):
+    from chinesechesszero_amd.collect import TupleSink
+    from chinesechesszero_amd.dataset import NpyMemmapDataset
+    s, p, z = _rows(50, 1)
+    a = TupleSink(str(tmp_path))
+    a.append(s[:20], p[:20], z[:20], games=1)
+    assert a.finalize() == 20
+    a.append(s[20:30], p[20:30], z[20:30], games=1)
+    # a new process opens the directory: the merged rows, the game counter and the pending shard are all picked up
+    b = TupleSink(str(tmp_path))
+    assert b.games == 2 and b.rows() == 10
+    b.append(s[30:], p[30:], z[30:], games=2)
+    assert b.finalize() == 50 and b.games == 4
+    ds = NpyMemmapDataset(str(tmp_path))
+    assert len(ds) == 50
+    st, pi, w = ds[37]
+    assert np.array_equal(st.numpy(), s[37]) and np.allclose(pi.numpy(), p[37].astype(np.float32)) and float(w) == float(z[37])
+    assert json.load(open(tmp_path / "meta.json"))["total_count"] == 50
+    assert b.finalize() == 50                                                           # idempotent
+
+
+def test_interrupted_finalize_is_repaired(tmp_path):
+    """A crash between the array replacements leaves files of different lengths; meta.json (written last) still says what
+    is valid, the shards are still there, and the next finalize() completes the merge."""
+    from chinesechesszero_amd.collect import TupleSink
+    s, p, z = _rows(30, 2)
+    a = TupleSink(str(tmp_path))
+    a.append(s[:10], p[:10], z[:10])
+    a.finalize()
+    a.append(s[10:], p[10:], z[10:])
+    real_replace = os.replace
+    calls = {"n": 0}
+
+    def dying_replace(src, dst):
+        calls["n"] += 1
+        if calls["n"] == 2:
+            raise KeyboardInterrupt("killed between two replacements")
+        return real_replace(src, dst)
+
+    os.replace = dying_replace
+    try:
+        with pytest.raises(KeyboardInterrupt):
+            a.finalize()
+    finally:
+        os.replace = real_replace
+    assert json.load(open(tmp_path / "meta.json"))["total_count"] == 10            # still describes the valid prefix
+    assert np.load(tmp_path / "states.npy", mmap_mode="r").shape[0] == 30 and np.load(tmp_path / "mcts.npy", mmap_mode="r").shape[0] == 10
+    b = TupleSink(str(tmp_path))
+    assert b.rows() == 20 and b.finalize() == 30
+    assert np.array_equal(np.load(tmp_path / "states.npy"), s) and np.array_equal(np.load(tmp_path / "mcts.npy"), p)
+    assert np.array_equal(np.load(tmp_path / "winners.npy"), z)
+
+
+def test_float32_option_and_dtype_guard(tmp_path):
+    from chinesechesszero_amd.collect import TupleSink
+    s, p, z = _rows(8, 3)
+    a = TupleSink(str(tmp_path), pi_dtype=np.float32)
+    a.append(s, p, z)
+    a.finalize()
+    assert np.load(tmp_path / "mcts.npy").dtype == np.float32 and json.load(open(tmp_path / "meta.json"))["mcts_dtype"] == "float32"
+    b = TupleSink(str(tmp_path))   # float64 sink on a float32 data set: refuse, do not silently convert
+    b.append(s, p, z)
+    with pytest.raises(ValueError, match="float32"):
+        b.finalize()

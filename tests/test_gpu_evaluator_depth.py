@@ -1,0 +1,117 @@
+"""GPU: the evaluator this build rewrote (stem + 80 tower convolutions on k_conv3x3_c256, BN folded) at FULL depth --
+40 blocks x 256 channels, non-trivial BatchNorm statistics, real leaf batches -- against (i) the reference architecture
+in float32 and (ii) the path the reference itself runs on a GPU: the same ``Net`` under ``torch.autocast("cuda")``
+(reference net.py:178-189). The bar: the fused path is no further from float32 than the reference's own autocast path."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _leaf_batch(B, plies, seed):
+    """Real evaluator inputs: B boards after `plies` uniformly random plies each (staggered), as the engine encodes them."""
+    from chinesechesszero_amd.engine import SelfPlayEngine
+    from chinesechesszero_amd.net import uniform_evaluator
+    e = SelfPlayEngine(B, n_playout=1, seed=seed, max_plies=plies + 8)
+    temps = np.full(B, 1e3, np.float64)
+    idx = np.arange(B)
+    for t in range(plies):
+        if t:
+            e.reset(((idx % plies) == t).astype(np.uint8))
+        leaf = e.select_leaves()
+        e.expand_backup(*uniform_evaluator(leaf))
+        e.finish_move(temps=temps, keep_tree=False)
+        if e.game_status()["over"].any():
+            e.harvest()
+    x = e.select_leaves().clone()
+    e.check_healthy()
+    e.close()
+    return x
+
+
+def _trained_like_net(dev, calib):
+    """Random weights, but BatchNorm statistics that MATCH the activations (one calibration pass in train mode, as training
+    would leave them) and random affine parameters: activations stay O(1) through all 40 blocks, like a trained net's."""
+    from chinesechesszero_amd.net import Net
+    torch.manual_seed(1234)
+    net = Net(256, 40).to(dev)
+    bns = [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    g = torch.Generator(device="cpu").manual_seed(99)
+    for m in bns:
+        m.momentum = 1.0
+        m.weight.data.copy_(torch.empty(m.num_features).uniform_(0.5, 1.5, generator=g))
+        m.bias.data.copy_(torch.empty(m.num_features).normal_(0, 0.2, generator=g))
+    net.train()
+    with torch.no_grad():
+        net(calib.float())
+    net.eval()
+    for m in bns:  # statistics that are close to, not exactly, the batch's (a trained net's running averages)
+        m.running_mean.mul_(1.0 + 0.05 * torch.randn(m.num_features, generator=g).to(dev))
+        m.running_var.mul_(torch.empty(m.num_features).uniform_(0.8, 1.25, generator=g).to(dev))
+    return net
+
+
+def _metrics(p, v, p_ref, v_ref):
+    top1 = float((p.argmax(1) == p_ref.argmax(1)).float().mean())
+    t5, t5r = p.topk(5, dim=1).indices, p_ref.topk(5, dim=1).indices
+    top5 = float((t5.unsqueeze(2) == t5r.unsqueeze(1)).any(2).float().mean())
+    kl = float((p_ref * (torch.log(p_ref.clamp_min(1e-30)) - torch.log(p.clamp_min(1e-30)))).sum(1).mean())
+    return {"max_dp": float((p - p_ref).abs().max()), "mean_dp": float((p - p_ref).abs().mean()), "max_dv": float((v - v_ref).abs().max()),
+            "mean_dv": float((v - v_ref).abs().mean()), "top1": top1, "top5": top5, "kl": kl}
+
+
+@pytest.mark.parametrize("B", [4096, 200])
+def test_fused_evaluator_at_full_depth_is_no_worse_than_the_reference_autocast_path(B):
+    from chinesechesszero_amd.net import InferenceNet
+    dev = torch.device("cuda", 0)
+    x = _leaf_batch(B, plies=60, seed=3)                       # fp16 [B,17,7,10,9], mixed positions
+    net = _trained_like_net(dev, _leaf_batch(512, plies=60, seed=4))
+    with torch.no_grad():
+        logp32, v32 = net(x.float())                           # (i) reference architecture, float32
+        p32, v32 = logp32.exp(), v32.view(-1)
+        with torch.autocast("cuda"):                           # (ii) what reference net.py:178-189 runs on a GPU
+            logp_ac, v_ac = net(x)
+        p_ac, v_ac = logp_ac.float().exp(), v_ac.float().view(-1)
+        inf = InferenceNet(net).to(dev).eval()
+        assert inf._use_fused_tower(torch.empty((B, 256, 10, 9), dtype=torch.float16, device=dev).contiguous(memory_format=torch.channels_last))
+        p16, v16 = inf(x)                                      # this build: stem + tower on k_conv3x3_c256, BN folded
+        logits, v16b = inf(x, return_logits=True)
+        os.environ["CCZ_FUSED_CONV"] = "0"                     # same folded weights through MIOpen + the one-pass epilogue
+        try:
+            p_mi, v_mi = inf(x)
+        finally:
+            del os.environ["CCZ_FUSED_CONV"]
+    assert torch.isfinite(p16).all() and torch.isfinite(v16).all() and torch.equal(v16, v16b)
+    assert torch.allclose(torch.softmax(logits.float(), 1), p16, atol=1e-6)
+    act = float(v32.abs().mean())
+    assert 0.02 < act < 0.98 and float(p32.max(1).values.mean()) > 2.0 / 2086   # a net with something to say, not a flat one
+    fused, autoc, miopen = _metrics(p16, v16, p32, v32), _metrics(p_ac, v_ac, p32, v32), _metrics(p_mi, v_mi, p32, v32)
+    print("evaluator_depth_parity", json.dumps({"B": B, "fused_vs_f32": fused, "autocast_vs_f32": autoc, "miopen_folded_vs_f32": miopen}))
+    # the bar: no further from float32 than the reference's own GPU path ...
+    assert fused["mean_dp"] <= 1.10 * autoc["mean_dp"] + 1e-9 and fused["mean_dv"] <= 1.10 * autoc["mean_dv"] + 1e-9
+    assert fused["max_dp"] <= 1.5 * autoc["max_dp"] + 1e-6 and fused["max_dv"] <= 1.5 * autoc["max_dv"] + 1e-6
+    assert fused["kl"] <= 1.10 * autoc["kl"] + 1e-9
+    assert fused["top1"] >= autoc["top1"] - 0.01 and fused["top5"] >= autoc["top5"] - 0.01
+    # ... and absolute tolerances of fp16 inference at 81 layers
+    assert fused["max_dp"] < 2e-2 and fused["max_dv"] < 6e-2 and fused["top1"] > 0.97 and fused["top5"] > 0.97
+    # the hand-written kernel and MIOpen compute the same folded network: they differ by summation order only
+    assert float((p16 - p_mi).abs().max()) < 1e-2 and float((v16 - v_mi).abs().max()) < 3e-2
+
+
+def test_shapes_off_the_fused_path_are_logged(caplog):
+    """The MFMA kernel serves 256 channels at >= 192 boards; anything else takes MIOpen + the epilogue pass and says so once."""
+    import logging
+    from chinesechesszero_amd.net import InferenceNet, Net
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    inf = InferenceNet(Net(256, 1).to(dev).eval()).to(dev).eval()
+    x = torch.zeros((64, 17, 7, 10, 9), dtype=torch.float16, device=dev)
+    with caplog.at_level(logging.INFO, logger="chinesechesszero_amd"):
+        inf(x)
+        inf(x)
+    msgs = [r.getMessage() for r in caplog.records if "fused" in r.getMessage()]
+    assert len(msgs) == 1 and "64" in msgs[0]

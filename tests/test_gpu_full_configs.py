@@ -1,0 +1,101 @@
+"""GPU: every single-GPU BASELINE.json configuration at its STATED size -- boards x sims/move -- with a sample of the
+boards mirrored on the sequential oracle (N, Q, P bit-exact at full batch size), the size-independent tree invariants on
+all boards, a move boundary and a harvest. Evaluator: a tiny deterministic device-side net (the 40x256 net costs 10 s per
+400-simulation move and is not what is compared here; its parity is tests/test_gpu_evaluator_depth.py)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _full_move(B, n, seed, sample_n=32, max_plies=1):
+    from gpu_harness import SampleMirror
+    from oracle import det_pi
+    from test_gpu_soak import LinearEvaluator
+    from chinesechesszero_amd.selfplay import BatchedSelfPlay
+    dev = torch.device("cuda", 0)
+    ev = LinearEvaluator(dev, seed=seed, sharp=9.0)
+    sp = BatchedSelfPlay(ev, B, n_playout=n, seed=seed, max_plies=max_plies)
+    e = sp.engine
+    rs = np.random.RandomState(seed)
+    sample = sorted(rs.choice(B, size=sample_n, replace=False).tolist())
+    sm = SampleMirror(e, sample)
+    # ---- one full move of n simulations through the production launch sequence: select, (evaluator, k_step) x (n-1), expand_backup
+    leaf = e.select_leaves()
+    for i in range(n):
+        prob, value = ev(leaf)
+        sm.backup_on_oracles(prob, value)
+        if i + 1 < n:
+            leaf = e.step(prob, value)
+        else:
+            e.expand_backup(prob, value)
+    rc = sm.compare_roots()                      # N, Q, P of the sampled boards: bit-exact vs the sequential oracle
+    k = rc["k"]
+    assert np.all(k == 44)                       # every board searched the opening position
+    tot = rc["visits"][:, :44].sum(1)
+    assert np.all(rc["root_visits"] == n) and np.all(tot == n - 1)   # mcts.py: the first playout expands the root
+    assert np.all(np.abs(rc["q"]) <= 1.0 + 1e-6)
+    assert all(np.all(np.diff(rc["acts"][b][:44].astype(int)) > 0) for b in range(0, B, 61))
+    pi = e.root_pi(temps=1.0)
+    assert np.allclose(pi.sum(1), 1.0, atol=1e-12)
+    for b in sample[:8]:
+        assert np.array_equal(pi[b][:44], det_pi(rc["visits"][b][:44], 1.0))
+    st = e.stats()
+    assert st["sims"] == B * n and st["error_flags"] == 0 and st["expansions"] + st["terminal_leaves"] == B * n
+    # ---- the move boundary at this size: pi record, Dirichlet-mixed device choice, re-root with tree reuse, push, game end
+    moves = sp.finish_move().cpu().numpy()
+    chosen = np.array([rc["visits"][b][list(rc["acts"][b][:44]).index(moves[b])] for b in range(B)])
+    sm.played(moves)
+    rc2 = sm.compare_roots()                     # kept subtrees of the sampled boards == oracle's update_with_move
+    assert np.array_equal(rc2["root_visits"], chosen)
+    assert len(set(moves.tolist())) > 8          # per-board Philox streams: the boards diverge
+    return sp, e, ev, sm, moves, rc
+
+
+@pytest.mark.parametrize("B,n", [(4096, 400), (1024, 400)])
+def test_baseline_config_boards_x_400_sims(B, n):
+    """BASELINE configs[2] (4096 boards x 400 sims, Dirichlet noise on) and configs[1] (1024 x 400)."""
+    sp, e, ev, sm, moves, rc = _full_move(B, n, seed=11 + B)
+    # ---- a few simulations of the next move on the kept subtrees (still mirrored), then the 1-ply cap ends every game
+    leaf = e.select_leaves()
+    for i in range(24):
+        prob, value = ev(leaf)
+        sm.backup_on_oracles(prob, value)
+        leaf = e.step(prob, value) if i + 1 < 24 else e.expand_backup(prob, value)
+    sm.compare_roots()
+    sp.finish_move()
+    stt = e.game_status()
+    assert stt["over"].all() and np.all(stt["winner"] == -1) and np.all(stt["plies"] == 1)
+    # ---- harvest at this size: one recorded ply per game + its mirror image
+    states, pi, z = e.harvest()
+    assert states.shape == (2 * B, 17, 7, 10, 9) and pi.shape == (2 * B, 2086) and z.shape == (2 * B,)
+    assert float(z.abs().max()) == 0.0
+    ps = pi.sum(1)
+    assert torch.allclose(ps, torch.ones_like(ps), atol=1e-5)
+    pin = pi.cpu().numpy()
+    from chinesechesszero_amd.tools import flip_map
+    fm = flip_map()
+    for b in sm.sample[:8]:
+        acts = rc["acts"][b][:44].astype(int)
+        want = (rc["visits"][b][:44] / float(rc["visits"][b][:44].sum())).astype(np.float32)
+        assert np.allclose(pin[2 * b][acts], want, atol=1e-6) and np.count_nonzero(pin[2 * b]) <= 44
+        assert np.array_equal(pin[2 * b + 1], pin[2 * b][fm])          # rows of a game: its samples, then their mirror images
+    s0 = states[0].float().cpu().numpy()
+    from oracle import OracleBoard
+    red, black = OracleBoard().decode()
+    assert np.array_equal(s0[0], red) and np.array_equal(s0[8], black) and np.all(s0[16] == 1)
+    assert not e.game_status()["over"].any()      # harvested boards restarted
+    e.check_healthy()
+    e.close()
+
+
+def test_baseline_config5_single_gpu_half_4096_boards_x_800_sims():
+    """configs[4]'s per-GPU half: 4096 boards x 800 sims/move (the node pool is sized from n_playout: ~72 GB here)."""
+    sp, e, ev, sm, moves, rc = _full_move(4096, 800, seed=5, sample_n=16, max_plies=0)
+    st = e.stats()
+    assert st["error_flags"] == 0 and st["pruned_subtrees"] == 0
+    assert 70e9 < st["hbm_bytes"] < 85e9, st["hbm_bytes"]
+    assert st["nodes_peak"] <= (800 + 64) * 512
+    e.check_healthy()
+    e.close()

@@ -116,10 +116,17 @@ def test_collect_pipeline_batched_writes_trainer_format(tmp_path):
     from chinesechesszero_amd.selfplay import BatchedSelfPlay
     cp.selfplay = BatchedSelfPlay(cp.policy_value_net.evaluate_leaves, 16, n_playout=4, max_plies=5, seed=2)
     cp.collect_batched(7)
+    assert not (tmp_path / "states.npy").exists() and cp.sink.rows() == 16 * 5 * 2   # rows stay in shards while collecting
+    assert cp.sink.finalize() == 16 * 5 * 2                                          # the converter step (convert.py:21-107)
+    import json
+    meta = json.load(open(tmp_path / "meta.json"))
+    assert list(meta)[:7] == ["total_count", "states_shape", "states_dtype", "mcts_shape", "mcts_dtype", "winners_shape", "winners_dtype"]
+    assert meta["total_count"] == 160 and meta["mcts_dtype"] == "float64" and meta["iters"] == 16
     states = np.load(tmp_path / "states.npy")
     pi = np.load(tmp_path / "mcts.npy")
     z = np.load(tmp_path / "winners.npy")
     assert states.dtype == np.float16 and states.shape[1:] == (17, 7, 10, 9)
+    assert pi.dtype == np.float64 and z.dtype == np.float32                           # the dtypes the reference stores
     assert pi.shape == (states.shape[0], 2086) and z.shape == (states.shape[0],)
     assert states.shape[0] == 16 * 5 * 2  # every board was adjudicated at 5 plies once, mirrored
     assert np.allclose(pi.sum(1), 1.0, atol=1e-4)
@@ -179,6 +186,7 @@ def test_collect_pipeline_single_board_host_path(tmp_path):
     finally:
         Board.is_game_over = orig
     assert iters == 1 and cp.episode_len == 5
+    cp.sink.finalize()
     states = np.load(tmp_path / "states.npy")
     pi = np.load(tmp_path / "mcts.npy")
     z = np.load(tmp_path / "winners.npy")
