@@ -58,6 +58,8 @@ def parse():
                     "with --preroll-plies equal to it every move ends ~boards/P games, so every move boundary harvests real rows")
     ap.add_argument("--no-align", dest="align", action="store_false", help="do not advance the search to the point where the timed "
                     "window straddles a move boundary (the window then starts at the first simulation of a move)")
+    ap.add_argument("--align-evaluator", choices=["net", "stub"], default="net", help="evaluator of the untimed alignment steps: the real "
+                    "net (default) or the stub (fast; for rocprofv3 PMC passes, where every kernel of an untimed step costs profiler time)")
     ap.add_argument("--gather-rows", type=int, default=8192, help="N>1: row capacity of the fused all-gather buffer (29,768 B per row)")
     return ap.parse_args()
 
@@ -337,7 +339,19 @@ def main():
     st_pre = e.game_status()
     half = min(a.steps, n) // 2
     phase = (n - half - a.warmup) % n if a.align else 0
-    run(phase, False)
+    if a.align_evaluator == "stub" and a.evaluator == "net":
+        real, evaluator = evaluator, uniform_evaluator
+        logits_in = False
+        run(phase, False)
+        if state["leaf"] is not None:   # the pending leaf of the stub phase is consumed through the dense entry point
+            e.expand_backup(*uniform_evaluator(state["leaf"]))
+            state["leaf"] = None
+            step_no[0] += 1
+            if step_no[0] % n == 0:
+                per_move(False)
+        evaluator, logits_in = real, bool(getattr(real, "returns_logits", False))
+    else:
+        run(phase, False)
     setup_s = time.perf_counter() - t_setup
 
     run(a.warmup, False)

@@ -115,14 +115,20 @@ class InferenceNet(nn.Module):
         self.bs = nn.ParameterList(bs)
         # float32 copies of the tower biases for the fused convolution kernel (bias is added to the fp32 accumulator)
         self.bs32 = nn.ParameterList([nn.Parameter(b.detach().float().clone(), requires_grad=False) for b in bs])
-        # both 1x1 head convs in one GEMM: 17 policy + 7 value output channels
+        # both 1x1 head convs as ONE plain GEMM on the NHWC rows: [pixels, C] x [C, 17 policy + 7 value channels]. (As an
+        # MIOpen 1x1 convolution the same product was NOT bit-reproducible from call to call below ~300 boards --
+        # profiles/determinism_probe.py -- which made small-batch searches irreproducible; a GEMM is, and it leaves its
+        # output pixel-major, so the FC weights are stored with their input columns permuted from the reference's
+        # (channel, pixel) flatten order (net.py:98,103) to (pixel, channel) instead of copying activations around.)
         wp, bp = _fold(net.policy_conv, net.policy_bn)
         wv, bv = _fold(net.value_conv, net.value_bn)
-        self.head_w = nn.Parameter(torch.cat([wp, wv], 0).to(dtype).contiguous(memory_format=cl), requires_grad=False)
+        C_in = wp.shape[1]
+        self.head_wT = nn.Parameter(torch.cat([wp, wv], 0).reshape(PLAYS + PIECES, C_in).t().contiguous().to(dtype), requires_grad=False)
         self.head_b = nn.Parameter(torch.cat([bp, bv], 0).to(dtype), requires_grad=False)
-        self.policy_fc_w = nn.Parameter(net.policy_fc.weight.detach().to(dtype), requires_grad=False)
+        pc = lambda w, c: w.detach().reshape(w.shape[0], c, 90).permute(0, 2, 1).reshape(w.shape[0], c * 90).contiguous()
+        self.policy_fc_w = nn.Parameter(pc(net.policy_fc.weight, PLAYS).to(dtype), requires_grad=False)
         self.policy_fc_b = nn.Parameter(net.policy_fc.bias.detach().to(dtype), requires_grad=False)
-        self.value_fc1_w = nn.Parameter(net.value_fc1.weight.detach().to(dtype), requires_grad=False)
+        self.value_fc1_w = nn.Parameter(pc(net.value_fc1.weight, PIECES).to(dtype), requires_grad=False)
         self.value_fc1_b = nn.Parameter(net.value_fc1.bias.detach().to(dtype), requires_grad=False)
         self.value_fc2_w = nn.Parameter(net.value_fc2.weight.detach().to(dtype), requires_grad=False)
         self.value_fc2_b = nn.Parameter(net.value_fc2.bias.detach().to(dtype), requires_grad=False)
@@ -267,9 +273,10 @@ class InferenceNet(nn.Module):
             for i in range(0, len(self.ws), 2):
                 y = self._epilogue(F.conv2d(x, self.ws[i], None, padding=1), self.bs[i])
                 x = self._epilogue(F.conv2d(y, self.ws[i + 1], None, padding=1), self.bs[i + 1], x)
-        h = F.relu_(F.conv2d(x, self.head_w, self.head_b))
-        pol = h[:, :PLAYS].reshape(B, PLAYS * 90)          # NCHW flatten order, as torch.reshape in net.py:98
-        val = h[:, PLAYS:].reshape(B, PIECES * 90)
+        rows = x.permute(0, 2, 3, 1).reshape(B * 90, x.shape[1])   # a view of the NHWC activations: one row per pixel
+        h = F.relu_(torch.addmm(self.head_b, rows, self.head_wT)).view(B, 90, PLAYS + PIECES)
+        pol = h[:, :, :PLAYS].reshape(B, 90 * PLAYS)       # (pixel, channel) order: the FC weights' columns are permuted to match
+        val = h[:, :, PLAYS:].reshape(B, 90 * PIECES)
         logits = F.linear(pol, self.policy_fc_w, self.policy_fc_b)
         v = F.relu_(F.linear(val, self.value_fc1_w, self.value_fc1_b))
         v = torch.tanh(F.linear(v, self.value_fc2_w, self.value_fc2_b).float()).view(B)

@@ -55,6 +55,24 @@ def main():
             if n:
                 summary.setdefault(k, {})[counter + "_raw_per_launch"] = tot / n
                 summary[k][counter + "_launches"] = n
+    cc = find(os.path.join(out_dir, "pmc_sq"), "*counter_collection.csv")
+    if cc:  # SQ counters per launch (quad-cycle units for the *_CYCLES / WAIT / ACTIVE counters, MI355X_MICROARCH.md)
+        acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+        for r in csv.DictReader(open(cc)):
+            name = r.get("Kernel_Name", "")
+            for k in ("k_step", "k_softmax_gather", "k_finish_move", "k_harvest", "k_conv3x3"):
+                if k in name:
+                    a = acc[k][r.get("Counter_Name")]
+                    a[0] += float(r.get("Counter_Value", 0) or 0)
+                    a[1] += 1
+        for k, d in acc.items():
+            sq = {c: v[0] / v[1] for c, v in d.items() if v[1]}
+            wc = sq.get("SQ_WAVE_CYCLES")
+            if wc:
+                sq["wait_any_frac"] = sq.get("SQ_WAIT_ANY", 0.0) / wc
+                sq["wait_inst_any_frac"] = sq.get("SQ_WAIT_INST_ANY", 0.0) / wc
+                sq["active_inst_any_frac"] = sq.get("SQ_ACTIVE_INST_ANY", 0.0) / wc
+            summary.setdefault(k, {})["sq_per_launch"] = sq
     for k, d in summary.items():
         f = d.get("FETCH_SIZE_raw_per_launch")
         w = d.get("WRITE_SIZE_raw_per_launch")
@@ -62,7 +80,7 @@ def main():
             # rocprofv3 FETCH_SIZE / WRITE_SIZE are in kilobytes; gfx950: double the fetch side
             d["hbm_bytes_per_launch"] = (2.0 * f + w) * 1024.0
             d["hbm_bytes_per_launch_uncorrected"] = (f + w) * 1024.0
-    for name in ("trace_bench.json", "pmc_fetch_bench.json", "pmc_write_bench.json"):
+    for name in ("trace_bench.json", "pmc_fetch_bench.json", "pmc_write_bench.json", "pmc_sq_bench.json"):
         p = os.path.join(out_dir, name)
         if os.path.exists(p):
             try:
@@ -72,8 +90,10 @@ def main():
                 pass
     with open(os.path.join(root, f"{tag}_summary.json"), "w") as f:
         json.dump(summary, f, indent=1)
+    pm = {k: v for k, v in summary.items() if not k.startswith("_")}
+    pm["run"] = f"profiles/run_profile.sh {tag}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes of bench.py --steps 24"
     with open(os.path.join(root, "pmc_summary.json"), "w") as f:
-        json.dump({k: v for k, v in summary.items() if not k.startswith("_")}, f, indent=1)
+        json.dump(pm, f, indent=1)
     print(json.dumps({k: v for k, v in summary.items() if not k.startswith("_")}, indent=1))
 
 
