@@ -207,6 +207,18 @@ __device__ __forceinline__ void cv_halfstep(const CvCtx &c, cv_f32x4 (&acc)[8][4
     cv_read_w<0>(c, ring_rd, alo);
     cv_read_x<(Un >> 1), (Un & 1)>(c, tap, bnxt);
     cv_mfma16<1>(c, acc, ahi, bcur);
+#if defined(CV_IGLP2) && !defined(CCZ_STAMPS)
+    __builtin_amdgcn_iglp_opt(1); // A/B: the same MFMA / DS interleave for the region behind the barrier
+#endif
+#if defined(CV_SGB2) && !defined(CCZ_STAMPS)
+    // A/B: pin the region behind the barrier as (2 MFMA, 1 DS read) x 8: the MFMAs' operands are in registers when the
+    // barrier opens, the 8 fragment reads of the NEXT half-step then issue in the MFMAs' shadow instead of in front of them
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+#endif
 }
 
 template <bool RES>
@@ -299,6 +311,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict
 #ifdef CCZ_STAMPS
     const unsigned long long st_loop0 = cv_stamp(), st_real0 = __builtin_amdgcn_s_memrealtime();
 #endif
+#ifdef CV_PRIO_YOUNG
+    if (w >= 4) __builtin_amdgcn_s_setprio(1); // A/B: static priority for the later-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+#endif
     for (int chunk = 0; chunk <= c.cmask; ++chunk) {
 #define CV_HE(u) cv_halfstep<u>(c, acc, chunk, ring_rd, ring_wr, tap, alo, ahi, b0, b1)
 #define CV_HO(u) cv_halfstep<u>(c, acc, chunk, ring_rd, ring_wr, tap, alo, ahi, b1, b0)
@@ -307,6 +322,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict
 #undef CV_HE
 #undef CV_HO
     }
+#ifdef CV_PRIO_YOUNG
+    __builtin_amdgcn_s_setprio(0);
+#endif
     cv_wait_vm<0>(); // the wrapped-around DMA loads must land before the LDS is reused / released
 #ifdef CCZ_STAMPS
     const unsigned long long st_loop1 = cv_stamp(), st_real1 = __builtin_amdgcn_s_memrealtime();

@@ -18,7 +18,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def load(name):
-    L = C.CDLL(os.path.join(ROOT, "chinesechesszero_amd", name))
+    path = os.path.join(ROOT, "chinesechesszero_amd", name)
+    if not os.path.exists(path):  # A/B and diagnostic builds: build/diag (make -C chinesechesszero_amd/csrc ab NAME=...)
+        path = os.path.join(ROOT, "build", "diag", name)
+    L = C.CDLL(path)
     L.ccz_conv3x3_c256_f16.restype = C.c_int
     L.ccz_conv3x3_c256_f16.argtypes = [C.c_void_p] * 6 + [C.c_int64, C.c_int32]
     return L

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from chinesechesszero_amd import _lib  # noqa: E402
 
 if os.environ.get("CCZ_LIB"):  # diagnostic build (libcczero_stamps.so): CONV_DBG=1,2,4,... times ablated variants
-    _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "chinesechesszero_amd", os.environ["CCZ_LIB"])
+    _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "diag", os.environ["CCZ_LIB"])
 
 
 def fused(x, w, bias32, res, y, relu=1):

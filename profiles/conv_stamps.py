@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from chinesechesszero_amd import _lib  # noqa: E402
 
-_lib.LIB_PATH = os.path.join(ROOT, "chinesechesszero_amd", "libcczero_stamps.so")
+_lib.LIB_PATH = os.path.join(ROOT, "build", "diag", "libcczero_stamps.so")  # make -C chinesechesszero_amd/csrc stamps
 
 
 def main():

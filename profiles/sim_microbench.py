@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from chinesechesszero_amd import _lib  # noqa: E402
 
 if os.environ.get("CCZ_LIB"):  # A/B: load another build of the library
-    _lib.LIB_PATH = os.path.join(ROOT, "chinesechesszero_amd", os.environ["CCZ_LIB"])
+    _lib.LIB_PATH = os.path.join(ROOT, "build", "diag", os.environ["CCZ_LIB"])
 from chinesechesszero_amd.selfplay import BatchedSelfPlay  # noqa: E402
 from test_gpu_soak import LinearEvaluator  # noqa: E402
 

@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from chinesechesszero_amd import _lib  # noqa: E402
 
-_lib.LIB_PATH = os.path.join(ROOT, "chinesechesszero_amd", "libcczero_stamps.so")
+_lib.LIB_PATH = os.path.join(ROOT, "build", "diag", "libcczero_stamps.so")  # make -C chinesechesszero_amd/csrc stamps
 from chinesechesszero_amd.selfplay import BatchedSelfPlay  # noqa: E402
 from test_gpu_soak import LinearEvaluator  # noqa: E402
 

@@ -184,3 +184,26 @@ def test_memmap_dataset_reads_the_sink_format(tmp_path):
     loader = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False)
     b = next(iter(loader))
     assert b[0].shape == (4, 17, 7, 10, 9) and b[1].shape == (4, 2086) and b[2].shape == (4,)
+
+
+def test_conv_entry_point_refuses_more_boards_than_its_32_bit_offsets_cover():
+    """include/cczero.h: at most 93,206 boards per ccz_conv3x3_c256_f16 call (element offsets are 32-bit in the kernel).
+    The check precedes any device work, so it is testable without a GPU: nothing is dereferenced."""
+    from chinesechesszero_amd import _lib
+    L = _lib.lib()
+    fake = ctypes.c_void_p(0x10000)
+    other = ctypes.c_void_p(0x20000)
+    ok_boards, bad_boards = 93206, 93207
+    assert ok_boards * 90 * 256 <= 2**31 - 1 < bad_boards * 90 * 256
+    assert L.ccz_conv3x3_c256_f16(None, fake, fake, fake, None, other, bad_boards * 90, 1) == -1
+    assert b"93206" in L.ccz_last_error()
+    assert L.ccz_conv3x3_c256_f16(None, fake, fake, fake, None, other, 91, 1) == -1          # not a whole number of boards
+    assert L.ccz_conv3x3_c256_f16(None, fake, fake, fake, None, fake, 90, 1) == -1           # output aliases the input
+    assert L.ccz_conv3x3_c256_f16(None, ctypes.c_void_p(0x10008), fake, fake, None, other, 90, 1) == -1   # misaligned
+    assert L.ccz_conv3x3_c256_f16(None, fake, fake, fake, None, other, 0, 1) == 0            # empty batch: nothing to do
+
+
+def test_no_diagnostic_library_travels_with_the_product():
+    """Only libcczero.so lives next to the package; diagnostic (-DCCZ_STAMPS) and A/B builds are made on demand by profiles/."""
+    pkg = os.path.join(ROOT, "chinesechesszero_amd")
+    assert sorted(f for f in os.listdir(pkg) if f.endswith(".so")) == ["libcczero.so"]
