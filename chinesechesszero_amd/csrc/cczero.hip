@@ -504,7 +504,7 @@ int ccz_harvest(ccz_engine *e, void *stream, void *states_f16_dev, float *pi_dev
     if (rows > 0 && (!states_f16_dev || !pi_dev || !z_dev)) return fail(-1, "ccz_harvest: null output buffer");
     if (rows > 0) {
         HIP_TRY(hipMemcpyAsync(e->st_rowbase, base.data(), (size_t)B * 8, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_harvest, dim3(B), dim3(256), 0, s, e->d, (const long long *)e->st_rowbase,
+        hipLaunchKernelGGL(k_harvest, dim3(B, kHarvestSlices), dim3(256), 0, s, e->d, (const long long *)e->st_rowbase,
                            (uint16_t *)states_f16_dev, pi_dev, z_dev);
         HIP_TRY(hipGetLastError());
     }

@@ -42,7 +42,13 @@
 // passes and their register pressure cost more than the prologue they save), ONE wave per SIMD with a 128 x 128 block per
 // wave (256 accumulator registers, a third fewer LDS fragment bytes per MFMA) (-14 % as compiled by hipcc, -20 % with the
 // DMA and the reads pinned between the MFMAs by sched_group_barrier: a single instruction stream per SIMD does not hide its
-// own DMA issue and waits without hand scheduling).
+// own DMA issue and waits without hand scheduling). Round 2 (profiles/r02_conv_ab.json): static s_setprio 1 for waves 4-7
+// (-0.2 % time, noise), iglp_opt(1) also for the region behind the barrier (-1.7 % median, equal minimum: noise), that region
+// pinned as (2 MFMA, 1 DS read) x 8 by sched_group_barrier (+6 % time). The compiled loop is already tight: between two
+// barriers 32 MFMAs, 12 ds_read_b128, 2-3 DMA, 8-24 VALU and <= 7 instructions in front of the first MFMA (one region per
+// chunk carries the ring-slot SALU arithmetic); what is left is DMA issue cost and the lockstep of the two waves of a SIMD.
+// A Winograd F(2x2,3x3) form was sized and dropped: 16 weight matrices instead of 9 and 4 pixels per tile make it need ~8x the
+// weight bytes per flop of this tiling at the largest accumulator block the register file holds (~290 GB/s per CU from L2).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -207,18 +213,6 @@ __device__ __forceinline__ void cv_halfstep(const CvCtx &c, cv_f32x4 (&acc)[8][4
     cv_read_w<0>(c, ring_rd, alo);
     cv_read_x<(Un >> 1), (Un & 1)>(c, tap, bnxt);
     cv_mfma16<1>(c, acc, ahi, bcur);
-#if defined(CV_IGLP2) && !defined(CCZ_STAMPS)
-    __builtin_amdgcn_iglp_opt(1); // A/B: the same MFMA / DS interleave for the region behind the barrier
-#endif
-#if defined(CV_SGB2) && !defined(CCZ_STAMPS)
-    // A/B: pin the region behind the barrier as (2 MFMA, 1 DS read) x 8: the MFMAs' operands are in registers when the
-    // barrier opens, the 8 fragment reads of the NEXT half-step then issue in the MFMAs' shadow instead of in front of them
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-#endif
 }
 
 template <bool RES>
@@ -311,9 +305,6 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict
 #ifdef CCZ_STAMPS
     const unsigned long long st_loop0 = cv_stamp(), st_real0 = __builtin_amdgcn_s_memrealtime();
 #endif
-#ifdef CV_PRIO_YOUNG
-    if (w >= 4) __builtin_amdgcn_s_setprio(1); // A/B: static priority for the later-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
-#endif
     for (int chunk = 0; chunk <= c.cmask; ++chunk) {
 #define CV_HE(u) cv_halfstep<u>(c, acc, chunk, ring_rd, ring_wr, tap, alo, ahi, b0, b1)
 #define CV_HO(u) cv_halfstep<u>(c, acc, chunk, ring_rd, ring_wr, tap, alo, ahi, b1, b0)
@@ -322,9 +313,6 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict
 #undef CV_HE
 #undef CV_HO
     }
-#ifdef CV_PRIO_YOUNG
-    __builtin_amdgcn_s_setprio(0);
-#endif
     cv_wait_vm<0>(); // the wrapped-around DMA loads must land before the LDS is reused / released
 #ifdef CCZ_STAMPS
     const unsigned long long st_loop1 = cv_stamp(), st_real1 = __builtin_amdgcn_s_memrealtime();

@@ -813,7 +813,10 @@ __global__ __launch_bounds__(64) void k_finish_move(Dev D, const int32_t *forced
 
 // ------------------------------------------------------------------ harvest: finished games -> training rows
 // rows of board b start at row_base[b] (< 0: board not harvested). Per game: T samples then, unless
-// CCZ_FLAG_NO_MIRROR, their T mirror images (collect.py:112-131: data + data_flip).
+// CCZ_FLAG_NO_MIRROR, their T mirror images (collect.py:112-131: data + data_flip). Grid = (boards, kHarvestSlices):
+// only a few dozen games end per move, so the plies of a game are spread over kHarvestSlices blocks (one 256-thread
+// block per game left the chip nearly empty: 1.8 ms for 28 k rows; the blocks of boards that are not harvested exit at once).
+constexpr int kHarvestSlices = 32;
 __global__ __launch_bounds__(256) void k_harvest(Dev D, const long long *row_base, uint16_t *states, float *pi, float *z)
 {
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -823,7 +826,7 @@ __global__ __launch_bounds__(256) void k_harvest(Dev D, const long long *row_bas
     const int T = m.ply;
     const bool quirks = (D.flags & 1u) != 0, mirror = (D.flags & 2u) == 0;
     const uint8_t *rsq = D.rec_sq + (size_t)b * D.max_plies * 96;
-    for (int t = 0; t < T; ++t) {
+    for (int t = blockIdx.y; t < T; t += gridDim.y) {
         const size_t r = (size_t)b * D.max_plies + t;
         // game.py:23-44: index i of the 8-deep history holds the position i plies back (start position
         // before that); reference quirk: every sample aliases the history at the LAST recorded ply

@@ -20,3 +20,7 @@ echo "write pass done"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d "$OUT/pmc_sq" -o sq -- python3 "$ROOT/bench.py" --steps 24 --warmup 2 --no-cpu-baseline --align-evaluator stub > "$OUT/pmc_sq_bench.json" 2> "$OUT/pmc_sq.err"
 echo "sq pass done"
 python3 "$ROOT/profiles/summarize.py" "$OUT" "$TAG"
+# gpurun merges at most 64 MiB back: keep the summaries and the small per-pass outputs, drop the raw per-dispatch traces
+du -sh "$OUT" || true
+find "$OUT" -type f -size +2M -delete || true
+mkdir -p "$ROOT/gpurun_out/profiles_$TAG" && cp "$ROOT/profiles/${TAG}_summary.json" "$ROOT/profiles/${TAG}_kernel_stats.csv" "$ROOT/profiles/pmc_summary.json" "$ROOT/gpurun_out/profiles_$TAG/"
