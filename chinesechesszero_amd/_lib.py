@@ -25,6 +25,7 @@ ABI_VERSION = 2
 RULE_PERPETUAL_CHECK = 1
 FLAG_REFERENCE_QUIRKS = 1
 FLAG_NO_MIRROR = 2
+FLAG_VALUE_F16 = 4
 LEAF_EXPAND, LEAF_DRAW, LEAF_LOSS, LEAF_SKIP = 0, 1, 2, 3
 
 ERR_BITS = {1: "node pool exhausted (raise max_nodes)", 2: "selection path deeper than max_depth", 64: "history chain overflow (> 128 positions since the last capture)",

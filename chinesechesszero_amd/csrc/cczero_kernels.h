@@ -477,11 +477,23 @@ __device__ inline TopPatch expand_backup_phase(const Dev &D, int b, int lane, co
         const int n = A[node].N + 1;
         const float q = A[node].Q;
         // visits += 1 ; value += 1.0*(leaf_value - value)/visits   in float32 (mcts.py:68-71)
-        float delta = val - q;
-        delta = delta / (float)n;
+        float qn;
+        if (D.flags & 4u) {
+            // CCZ_FLAG_VALUE_F16: the same expression on a float16 value (reference CUDA path). Every operation is done
+            // in float32 and rounded once to float16, which is what NumPy's half loops do (and equals IEEE binary16
+            // arithmetic: 24 >= 2*11 + 2); `visits` is a weak Python int, i.e. converted to float16 as well.
+            const float vh = (float)(_Float16)val, qh = (float)(_Float16)q;
+            float dh = (float)(_Float16)(vh - qh);
+            dh = (float)(_Float16)(dh / (float)(_Float16)(float)n);
+            qn = (float)(_Float16)(qh + dh);
+        } else {
+            float delta = val - q;
+            delta = delta / (float)n;
+            qn = q + delta;
+        }
         A[node].N = n;
-        A[node].Q = q + delta;
-        if (j < 64) { myN = n; myQ = q + delta; }
+        A[node].Q = qn;
+        if (j < 64) { myN = n; myQ = qn; }
     }
     tp.active = true;
     tp.rootN = __builtin_amdgcn_readlane(myN, 0);

@@ -31,7 +31,7 @@ class SelfPlayEngine:
                  alpha: float = 0.2, temp: float = 1.0, seed: int = 0, board_id_base: int = 0,
                  device: int = 0, max_nodes: int = 0, max_depth: int = 0, max_plies: int = 0,
                  reference_quirks: bool = False, mirror: bool = True, reserve_nodes: int = 0,
-                 move_rank="tools", plane_of_type="tools"):
+                 move_rank="tools", plane_of_type="tools", value_f16: bool = False):
         """``move_rank`` (uint16[2086] permutation, None = ascending id) and ``plane_of_type`` (8 entries, None = type-1)
         are the run-time rule tables of ``ccz_config`` (ABI 2); the default "tools" takes the process-wide choice of
         :func:`chinesechesszero_amd.tools.set_rules`."""
@@ -41,7 +41,8 @@ class SelfPlayEngine:
         self.device = torch.device("cuda", device)
         self.B = int(n_boards)
         self.n_playout = int(n_playout)
-        flags = (_lib.FLAG_REFERENCE_QUIRKS if reference_quirks else 0) | (0 if mirror else _lib.FLAG_NO_MIRROR)
+        flags = (_lib.FLAG_REFERENCE_QUIRKS if reference_quirks else 0) | (0 if mirror else _lib.FLAG_NO_MIRROR) \
+            | (_lib.FLAG_VALUE_F16 if value_f16 else 0)  # value_f16: Q accumulated in float16 as on the reference's CUDA path
         self.mirror = mirror
         from . import tools
         if isinstance(move_rank, str):

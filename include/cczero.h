@@ -57,6 +57,11 @@ extern "C" {
 #define CCZ_FLAG_REFERENCE_QUIRKS 1u /* harvest(): reproduce game.py:234-237 (all samples carry the
                                         final 8-ply history) and collect.py:78 (turn plane all ones) */
 #define CCZ_FLAG_NO_MIRROR 2u        /* harvest(): do not append collect.py:112-131 mirror samples  */
+#define CCZ_FLAG_VALUE_F16 4u        /* reference CUDA-path quirk: under autocast (net.py:178-189) the value reaches
+                                        Node.update as a float16 ndarray and NumPy accumulates Node.value in float16
+                                        (mcts.py:63-71 under NEP 50). With this flag the leaf value is rounded to float16
+                                        and every operation of the incremental mean rounds to float16; default (off) is
+                                        the float32 arithmetic of the reference's CPU path                              */
 
 /* leaf status written by ccz_select_leaves */
 #define CCZ_LEAF_EXPAND 0 /* non-terminal: children are created from the evaluator's priors */

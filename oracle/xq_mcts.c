@@ -19,6 +19,27 @@
 
 enum { V_INT0 = 0, V_PYFLOAT = 1, V_F32 = 2 };
 
+/* IEEE binary16 rounding (round to nearest even) of a float, returned as a float: what a NumPy float16 operation
+   leaves (its half loops compute in float32 and round once; double rounding is innocuous, 24 >= 2*11+2). */
+static float f16_round(float x)
+{
+    union { float f; uint32_t u; } a;
+    uint32_t sign, m;
+    a.f = x;
+    sign = a.u & 0x80000000u;
+    m = a.u & 0x7fffffffu;
+    if (m >= 0x7f800000u) return x;                 /* inf / nan */
+    if (m >= 0x477ff000u) { a.u = sign | 0x7f800000u; return a.f; } /* >= 65520 rounds to inf */
+    if (m < 0x38800000u) {                          /* below 2^-14: half subnormals, quantum 2^-24 */
+        float q = nearbyintf(fabsf(x) * 16777216.0f) / 16777216.0f; /* default rounding mode = nearest even */
+        return sign ? -q : q;
+    }
+    m += 0xfffu + ((m >> 13) & 1u);
+    m &= ~0x1fffu;
+    a.u = sign | m;
+    return a.f;
+}
+
 typedef struct node {
     struct node *parent;
     int nchild;
@@ -35,6 +56,7 @@ struct xq_mcts {
     node *root;
     int c_puct;
     int n_playout;
+    int value_f16;  /* the evaluator's value is a float16 ndarray (reference CUDA/autocast path, net.py:178-189) */
     node *cur_leaf; /* set by xq_mcts_select */
     int64_t live_nodes;
 };
@@ -90,11 +112,21 @@ static double puct_value(const node *n, int c_puct)
     return q + u;
 }
 
-/* Node.update  mcts.py:63-71 ; leaf value is either an ndarray float32 (is_f32) or a Python float */
-static void node_update(node *n, int is_f32, float lf, double ld)
+/* Node.update  mcts.py:63-71 ; leaf value is either an ndarray float32 (is_f32) or a Python float.
+   f16: the ndarray is float16 instead (autocast path): every operation of `value += 1.0*(leaf_value - value)/visits`
+   then rounds to float16 (NEP 50: Python scalars are weak, so `visits` is converted to float16 too). */
+static void node_update(node *n, int is_f32, float lf, double ld, int f16)
 {
     n->visits += 1;
-    if (is_f32 || n->vkind == V_F32) {
+    if (f16 && (is_f32 || n->vkind == V_F32)) {
+        float v = f16_round(is_f32 ? lf : (float)ld);
+        float cur = n->vkind == V_F32 ? n->vf : (n->vkind == V_PYFLOAT ? f16_round((float)n->vd) : 0.0f);
+        float delta = f16_round(v - cur);
+        delta = f16_round(1.0f * delta);
+        delta = f16_round(delta / f16_round((float)n->visits));
+        n->vf = f16_round(cur + delta);
+        n->vkind = V_F32; /* vf holds a float16-representable number */
+    } else if (is_f32 || n->vkind == V_F32) {
         /* any float32 ndarray operand makes the whole expression float32 (Python scalars are weak) */
         float v = is_f32 ? lf : (float)ld;
         float cur = n->vkind == V_F32 ? n->vf : (n->vkind == V_PYFLOAT ? (float)n->vd : 0.0f);
@@ -111,11 +143,13 @@ static void node_update(node *n, int is_f32, float lf, double ld)
 }
 
 /* Node.update_recursive  mcts.py:73-78 : parent first, with the negated value */
-static void node_update_recursive(node *n, int is_f32, float lf, double ld)
+static void node_update_recursive(node *n, int is_f32, float lf, double ld, int f16)
 {
-    if (n->parent) node_update_recursive(n->parent, is_f32, -lf, -ld);
-    node_update(n, is_f32, lf, ld);
+    if (n->parent) node_update_recursive(n->parent, is_f32, -lf, -ld, f16);
+    node_update(n, is_f32, lf, ld, f16);
 }
+
+void xq_mcts_set_value_f16(xq_mcts *t, int on) { t->value_f16 = on != 0; }
 
 /* descend from the root pushing moves (mcts.py:105-111); returns the leaf */
 int xq_mcts_select(xq_mcts *t, const xq_board *root_board, xq_board *leaf_out, int *depth_out)
@@ -156,15 +190,15 @@ void xq_mcts_expand_backup(xq_mcts *t, const xq_board *leaf, int k, const uint16
             n->child[i] = node_new(t, n, prob[i]);
         }
         n->nchild = k;
-        node_update_recursive(n, 1, -value, 0.0);
+        node_update_recursive(n, 1, -value, 0.0, t->value_f16);
     } else if (end && tie) {
-        node_update_recursive(n, 0, 0.0f, -0.0); /* leaf_value = 0.0 */
+        node_update_recursive(n, 0, 0.0f, -0.0, t->value_f16); /* leaf_value = 0.0 */
     } else {
         /* winner = RED if outcome().winner else BLACK ; +1 if winner == board.turn  (mcts.py:125-126) */
         int w = xq_outcome_winner(leaf, k);
         int winner = (w == 1) ? XQ_RED : XQ_BLACK; /* None is falsy -> BLACK */
         double lv = winner == leaf->pos.turn ? 1.0 : -1.0;
-        node_update_recursive(n, 0, 0.0f, -lv);
+        node_update_recursive(n, 0, 0.0f, -lv, t->value_f16);
     }
     t->cur_leaf = NULL;
 }

@@ -135,6 +135,10 @@ CASES = [
     # first-visited and tie-broken in that order (mcts.py:37-39,47-48,59-61); pins the engine's run-time move_rank table
     dict(name="start_sharp_shuffled_n200", start="start", ev="hash_sharp", n=200, plies=3, temps=[1.0, 1.0, 0.5], seed=14, selfplay=True, order_seed=77),
     dict(name="wide80_uniform_shuffled_n150", start="wide80", turn=1, halfmove=0, ev="uniform", n=150, plies=2, temps=[1.0, 1.0], seed=15, selfplay=True, order_seed=78),
+    # the reference's CUDA path: under autocast the value is a float16 ndarray (net.py:178-189) and Node.value is then
+    # accumulated in float16 (NEP 50); priors stay float32. Pins the engine's CCZ_FLAG_VALUE_F16 / the oracle's value_f16.
+    dict(name="start_sharp_f16value_n300", start="start", ev="hash_sharp", n=300, plies=3, temps=[1.0, 1.0, 0.5], seed=16, selfplay=True, value_dtype="float16"),
+    dict(name="rooks_f16value_n200", start="two_rooks", turn=1, halfmove=0, ev="hash", n=200, plies=3, temps=[1.0, 1.0, 1.0], seed=17, selfplay=True, value_dtype="float16"),
 ]
 
 STARTS = {"two_rooks": endgame_two_rooks, "capture_to_bare": endgame_capture_to_bare, "rook_knight": endgame_rook_knight,
@@ -201,6 +205,12 @@ def main():
     facts["q_dtype_mixed"] = str(np.asarray(t.value).dtype)
     unv = ref_mcts.Node(root, np.float32(0.1))
     facts["unvisited_is_inf"] = bool(unv.puct_value(5) == float("inf"))
+    h = ref_mcts.Node(root, np.float32(0.1))
+    h.update(-np.array([[0.3]], dtype=np.float16))
+    facts["q_dtype_after_f16_backup"] = str(np.asarray(h.value).dtype)
+    facts["puct_dtype_with_f16_q"] = str(np.asarray(h.puct_value(5)).dtype)
+    h.update(1.0)
+    facts["q_dtype_f16_then_terminal"] = str(np.asarray(h.value).dtype)
     meta["dtype_facts"] = facts
 
     # ---- G3/G5 search traces: the reference's MCTS_AI on the oracle-rules board
@@ -210,14 +220,16 @@ def main():
 
         rank = np.random.RandomState(case["order_seed"]).permutation(2086) if "order_seed" in case else None
 
-        def policy(board, red_states=None, black_states=None, _ev=ev, _rank=rank):
+        vdt = np.dtype(case.get("value_dtype", "float32"))
+
+        def policy(board, red_states=None, black_states=None, _ev=ev, _rank=rank, _vdt=vdt):
             ids = board.legal_ids()
             if _rank is not None:  # what iterating a differently ordered `board.legal_moves` would hand to net.py:154-157
                 ids = sorted(ids, key=lambda i: int(_rank[i]))
             p, v = _ev(board.squares()[None, :], np.array([1 if board.turn else 0]))
             n_evals[0] += 1
-            # shape/dtypes of net.py:202-205 on the CPU path
-            return zip(ids, p[0][ids]), np.array([[v[0]]], dtype=np.float32)
+            # shape/dtypes of net.py:202-205: float32 value on the CPU path, float16 on the CUDA (autocast) path
+            return zip(ids, p[0][ids]), np.array([[v[0]]], dtype=np.float32).astype(_vdt)
 
         board = make_board(case)
         ai = ref_mcts.MCTS_AI(policy, c_puct=5, n_playout=case["n"], is_selfplay=case["selfplay"])

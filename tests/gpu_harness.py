@@ -50,13 +50,13 @@ def make_evaluator(kind: str, salts):
 class Lockstep:
     """B engine boards next to B independent sequential oracles (reference mcts.py restated in C)."""
 
-    def __init__(self, engine, boards, kind="hash", salts=None, c_puct=5):
+    def __init__(self, engine, boards, kind="hash", salts=None, c_puct=5, value_f16=False):
         self.e = engine
         self.B = engine.B
         self.boards = boards  # list[OracleBoard], root positions (also set on the engine by the caller)
         self.salts = list(range(self.B)) if salts is None else salts
         self.ev = make_evaluator(kind, self.salts)
-        self.mcts = [OracleMCTS(None, c_puct=c_puct, n_playout=0) for _ in range(self.B)]
+        self.mcts = [OracleMCTS(None, c_puct=c_puct, n_playout=0, value_f16=value_f16) for _ in range(self.B)]
 
     def _after_select(self, check_leaf):
         """Leaf of every board is selected on the engine: select on the oracles too, compare, evaluate."""

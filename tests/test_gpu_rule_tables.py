@@ -164,3 +164,46 @@ def test_rule_flag_stub_and_error_bits():
     assert L.ccz_create(C.byref(cfg), C.byref(h)) == -1
     # the two overflow kinds report separate bits (round 1 shared bit 2)
     assert _lib.ERR_BITS[2] != _lib.ERR_BITS[64] and "chain" in _lib.ERR_BITS[64] and "depth" in _lib.ERR_BITS[2]
+
+
+def test_float16_value_quirk_matches_oracle_and_differs_from_float32():
+    """CCZ_FLAG_VALUE_F16: Q accumulated in float16 as on the reference's CUDA (autocast) path -- lockstep against the
+    oracle's float16 twin (itself pinned by two golden traces of the reference run with a float16 value), fused and
+    two-kernel launch sequences, terminal leaves included; and NOT what the default float32 engine computes."""
+    from gpu_harness import Lockstep
+    from golden_cases import STARTS
+    from oracle import OracleBoard
+    B, n = 6, 120
+    e = _engine(B, n, seed=5, value_f16=True)
+    e32 = _engine(B, n, seed=5)
+    boards, boards32 = [], []
+    for b in range(B):
+        if b % 3 == 2:   # an endgame with mates in reach: terminal (Python-float) values meet float16 nodes
+            e.set_position(b, STARTS["two_rooks"], 1, 0)
+            e32.set_position(b, STARTS["two_rooks"], 1, 0)
+            boards.append(OracleBoard.from_array(STARTS["two_rooks"], 1, 0))
+            boards32.append(OracleBoard.from_array(STARTS["two_rooks"], 1, 0))
+        else:
+            boards.append(OracleBoard())
+            boards32.append(OracleBoard())
+    salts = [41, 42, 43, 44, 45, 46]
+    ls = Lockstep(e, boards, kind="hash_sharp", salts=salts, value_f16=True)
+    ls32 = Lockstep(e32, boards32, kind="hash_sharp", salts=salts)
+    for ply in range(2):
+        if ply == 0:
+            ls.run_fused(n, check_leaf=True)
+            ls32.run_fused(n, check_leaf=False)
+        else:
+            for _ in range(n):
+                ls.step(check_leaf=True)
+                ls32.step(check_leaf=False)
+        rc, rc32 = ls.compare_roots(), ls32.compare_roots()
+        q = np.concatenate([rc["q"][b][:rc["k"][b]] for b in range(B)])
+        assert np.array_equal(q, q.astype(np.float16).astype(np.float32))      # every Q is a float16 number
+        assert not all(np.array_equal(rc["q"][b], rc32["q"][b]) for b in range(B))
+        mv = [int(rc["acts"][b][int(np.argmax(rc["visits"][b][:rc["k"][b]]))]) for b in range(B)]
+        mv32 = [int(rc32["acts"][b][int(np.argmax(rc32["visits"][b][:rc32["k"][b]]))]) for b in range(B)]
+        ls.play(mv)
+        ls32.play(mv32)
+    assert e.stats()["terminal_leaves"] > 0
+    e.check_healthy()

@@ -72,7 +72,7 @@ def test_uniform_priors_exact_ties_first_max_order():
     e.check_healthy()
 
 
-@pytest.mark.parametrize("idx", range(15))
+@pytest.mark.parametrize("idx", range(17))
 def test_golden_traces_from_reference_mcts(golden, idx, rules_of_case):
     """Visit counts / Q / priors equal the numbers the reference's own mcts.py produced (bit-exact),
     pi within 1e-12, with the golden moves forced (tree reuse across plies)."""
@@ -83,14 +83,15 @@ def test_golden_traces_from_reference_mcts(golden, idx, rules_of_case):
     name = case["name"]
     sqs, turn, half = case_start(case)
     rank = rules_of_case(case)  # cases 13, 14: a shuffled `legal_moves` order through ccz_config.move_rank_host
-    e = _engine(1, case["n"], move_rank=rank)
+    f16 = case.get("value_dtype") == "float16"    # cases 15, 16: the reference's CUDA-path Q dtype (CCZ_FLAG_VALUE_F16)
+    e = _engine(1, case["n"], move_rank=rank, value_f16=f16)
     if case["start"] != "start":
         e.set_position(0, sqs, turn, half)
         ob = OracleBoard.from_array(sqs, turn, half)
     else:
         ob = OracleBoard()
     salt = {"hash": 0, "hash_sharp": 7, "uniform": 0}[case["ev"]]
-    ls = Lockstep(e, [ob], kind=case["ev"], salts=[salt])
+    ls = Lockstep(e, [ob], kind=case["ev"], salts=[salt], value_f16=f16)
     for ply in range(case["plies_done"]):
         if idx % 2 == 0:   # even cases through the fused launch sequence, odd ones through select + expand_backup
             ls.run_fused(case["n"], check_leaf=False)

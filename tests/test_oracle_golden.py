@@ -39,6 +39,9 @@ def test_dtype_facts(golden):
     assert f["q_type_terminal_only"] == "float"
     assert f["q_dtype_mixed"] == "float32"
     assert f["unvisited_is_inf"] is True
+    # the CUDA (autocast) path of the reference hands Node.update a float16 value: Q is then float16, PUCT still float64
+    assert f["q_dtype_after_f16_backup"] == "float16" and f["puct_dtype_with_f16_q"] == "float64"
+    assert f["q_dtype_f16_then_terminal"] == "float16"
 
 
 def test_pi_from_visits(golden):
@@ -64,12 +67,13 @@ def _make_eval(name):
     return f
 
 
-N_CASES = 15  # 13 in the canonical ascending-id order + 2 with a shuffled `legal_moves` order (order_seed)
+N_CASES = 17  # 13 canonical + 2 with a shuffled `legal_moves` order (order_seed) + 2 with a float16 value (value_dtype)
 
 
 def test_case_count(golden):
     assert len(golden["meta"]["cases"]) == N_CASES
     assert sum("order_seed" in c for c in golden["meta"]["cases"]) == 2
+    assert sum(c.get("value_dtype") == "float16" for c in golden["meta"]["cases"]) == 2
 
 
 @pytest.mark.parametrize("idx", range(N_CASES))
@@ -81,7 +85,7 @@ def test_search_trace_matches_reference(golden, idx, rules_of_case):
     name = case["name"]
     sqs, turn, half = case_start(case)
     board = OracleBoard.from_array(sqs, turn, half) if case["start"] != "start" else OracleBoard()
-    mcts = OracleMCTS(_make_eval(case["ev"]), c_puct=5, n_playout=case["n"])
+    mcts = OracleMCTS(_make_eval(case["ev"]), c_puct=5, n_playout=case["n"], value_f16=case.get("value_dtype") == "float16")
     rs = np.random.RandomState(case["seed"])
     for ply in range(case["plies_done"]):
         acts, visits, probs = mcts.get_move_probs(board, case["temps"][ply])
@@ -150,3 +154,16 @@ def test_decode_board_under_another_piece_type_numbering(golden):
         oracle.set_rules()
     red, black = OracleBoard().decode()
     assert not np.array_equal(red, d["decode_alt_start_red"])  # the default numbering gives other planes
+
+
+def test_float16_value_changes_the_search(golden):
+    """The float16-value traces differ from what float32 arithmetic gives on the same inputs (the dtype is load-bearing),
+    and every stored Q is a float16-representable number."""
+    case = [c for c in golden["meta"]["cases"] if c["name"] == "start_sharp_f16value_n300"][0]
+    d = golden["data"]
+    q = d["start_sharp_f16value_n300_p0_q"]
+    assert np.array_equal(q, q.astype(np.float16).astype(np.float32))
+    m32 = OracleMCTS(_make_eval(case["ev"]), c_puct=5, n_playout=case["n"])
+    m32.get_move_probs(OracleBoard(), 1.0)
+    _, v32, q32, _ = m32.root_children()
+    assert not np.array_equal(q32, q)
