@@ -249,12 +249,15 @@ class Game:
 
     def graphic(self, board):
         """game.py:47-75: push the position to the viewer window (status line as the reference formats it); the SVG
-        rendering of ``cchess.svg`` is not part of this build, the viewer receives the text board and the FEN."""
+        rendering of ``cchess.svg`` is not part of this build: :func:`frontend.board_svg` draws the position."""
         current_player = "red" if board.turn == RED else "black"
         status_text = f"to move: {current_player} - ply: {len(board.move_stack)}"
         if self.viewer is not None:
             try:
-                self.viewer.update_board(str(board) + "\n" + board.fen(), status_text)
+                from .frontend import board_svg
+                last = board.peek()
+                lm = (int(MOVE_FROM[last.id]), int(MOVE_TO[last.id])) if last is not None else None
+                self.viewer.update_board(board_svg(board.squares(), lm), status_text)
                 return
             except Exception as e:  # the reference falls back to terminal display when the window fails
                 log(f"viewer update failed: {e}", "WARNING")

@@ -121,7 +121,30 @@ class BatchedSelfPlay:
                 acc = 0
         return self.finish_move()
 
+    def watch(self, board_index: int, viewer):
+        """Show ONE selected board of the batch in a viewer window (``frontend.ChessWindow`` or anything with
+        ``update_board(svg, status)``): its position is pushed after every move (one small device read per move; nothing is
+        read when no board is watched). The batched counterpart of ``Game.graphic`` (reference game.py:47-75)."""
+        self._watch = (int(board_index), viewer)
+
+    def _show(self, moves):
+        b, viewer = self._watch
+        from .frontend import board_svg
+        from .tools import MOVE_FROM, MOVE_TO
+        sq = self.engine.root_positions()[b]
+        st = self.engine.game_status()
+        mv = int(moves[b].item())
+        lm = (int(MOVE_FROM[mv]), int(MOVE_TO[mv])) if mv >= 0 else None
+        viewer.update_board(board_svg(sq, lm), f"board {b} - to move: {'red' if st['turn'][b] else 'black'} - ply: {int(st['plies'][b])}"
+                            + (" - game over" if st["over"][b] else ""))
+
     def finish_move(self):
+        moves = self._finish_move()
+        if getattr(self, "_watch", None) is not None:
+            self._show(moves)
+        return moves
+
+    def _finish_move(self):
         e = self.engine
         if self.sampling == "device":
             return e.finish_move()

@@ -207,3 +207,26 @@ def test_no_diagnostic_library_travels_with_the_product():
     """Only libcczero.so lives next to the package; diagnostic (-DCCZ_STAMPS) and A/B builds are made on demand by profiles/."""
     pkg = os.path.join(ROOT, "chinesechesszero_amd")
     assert sorted(f for f in os.listdir(pkg) if f.endswith(".so")) == ["libcczero.so"]
+
+
+def test_viewer_window_serves_the_selected_board():
+    """frontend.ChessWindow: update_board(svg, status) then GET /board returns the reference's JSON keys (frontend.py:120-136)."""
+    import json
+    import urllib.request
+    from chinesechesszero_amd.frontend import ChessWindow, board_svg
+    sq = np.zeros(90, np.uint8)
+    sq[4], sq[85], sq[0] = 7, 15, 3
+    svg = board_svg(sq, last_move=(0, 9))
+    assert svg.startswith("<svg") and svg.count("<circle") == 3 and ">K<" in svg and ">k<" in svg and ">R<" in svg
+    w = ChessWindow("127.0.0.1", 0).start()
+    try:
+        w.update_board(svg, "to move: red - ply: 0")
+        d = json.loads(urllib.request.urlopen(f"http://127.0.0.1:{w.port}/board", timeout=5).read())
+        assert set(d) == {"svg", "status", "timestamp"} and d["svg"] == svg and d["status"].startswith("to move: red")
+        page = urllib.request.urlopen(f"http://127.0.0.1:{w.port}/", timeout=5).read().decode()
+        assert "/board" in page
+        w.update_board("plain text board", "x")
+        d = json.loads(urllib.request.urlopen(f"http://127.0.0.1:{w.port}/board", timeout=5).read())
+        assert d["svg"].startswith("<pre>") and w.updates == 2
+    finally:
+        w.stop()

@@ -90,3 +90,32 @@ def test_inference_net_fp16_fused_epilogue_matches_fp32_reference_architecture()
     _lib.check(_lib.lib().ccz_bias_act_f16(s, C.c_void_p(y1.data_ptr()), C.c_void_p(b.data_ptr()), None, 7 * 90, 64))
     _lib.check(_lib.lib().ccz_bias_act_f16(s, C.c_void_p(y2.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(r.data_ptr()), 7 * 90, 64))
     assert torch.equal(y1, want1) and torch.equal(y2, want2)
+
+
+def test_viewer_hook_shows_one_selected_board_of_the_batch_and_the_single_board_game():
+    """SURVEY 8f row 3, second half: Game.graphic / frontend viewer hook-up (reference game.py:47-75, frontend.py:328)."""
+    from chinesechesszero_amd.frontend import ChessWindow
+    from chinesechesszero_amd.game import Board, Game
+    from chinesechesszero_amd.mcts import MCTS_AI
+    from chinesechesszero_amd.net import uniform_evaluator
+    from chinesechesszero_amd.selfplay import BatchedSelfPlay
+    w = ChessWindow("127.0.0.1", 0)          # not started: update_board only stores the state
+    sp = BatchedSelfPlay(uniform_evaluator, 8, n_playout=6, seed=1)
+    sp.watch(5, w)
+    for ply in range(3):
+        sp.run_move()
+    assert w.updates == 3
+    assert w._state["svg"].count("<circle") == int((sp.engine.root_positions()[5] != 0).sum())
+    assert w._state["status"].startswith("board 5 - to move: black - ply: 3")
+    assert 'fill-opacity="0.45"' in w._state["svg"]      # the last move is highlighted
+    # the single-board loop: Game.graphic pushes every position when is_shown (game.py:103-104)
+    orig = Board.is_game_over
+    Board.is_game_over = lambda self: len(self.move_stack) >= 3 or orig(self)
+    try:
+        g = Game(viewer=w)
+        a = MCTS_AI(uniform_evaluator, n_playout=5, is_selfplay=False)
+        b = MCTS_AI(uniform_evaluator, n_playout=5, is_selfplay=False)
+        g.start_play(a, b, is_shown=True)
+    finally:
+        Board.is_game_over = orig
+    assert w.updates == 6 and "ply: 3" in w._state["status"]
