@@ -325,7 +325,7 @@ def main():
                 with torch.cuda.stream(side):
                     trainer.step(*rb.sample(2048), sync=False)
                     side_done.record(side)
-                train_steps[0] += 1
+                train_steps[0] += 1 if timed else 0  # updates inside the timed window
             if last_of_move:
                 per_move(timed)
         return pairs
