@@ -201,8 +201,9 @@ def test_float16_value_quirk_matches_oracle_and_differs_from_float32():
         q = np.concatenate([rc["q"][b][:rc["k"][b]] for b in range(B)])
         assert np.array_equal(q, q.astype(np.float16).astype(np.float32))      # every Q is a float16 number
         assert not all(np.array_equal(rc["q"][b], rc32["q"][b]) for b in range(B))
-        mv = [int(rc["acts"][b][int(np.argmax(rc["visits"][b][:rc["k"][b]]))]) for b in range(B)]
-        mv32 = [int(rc32["acts"][b][int(np.argmax(rc32["visits"][b][:rc32["k"][b]]))]) for b in range(B)]
+        pick = lambda r, b: int(r["acts"][b][int(np.argmax(r["visits"][b][:r["k"][b]]))]) if r["k"][b] else -1  # -1: game over
+        mv = [pick(rc, b) for b in range(B)]
+        mv32 = [pick(rc32, b) for b in range(B)]
         ls.play(mv)
         ls32.play(mv32)
     assert e.stats()["terminal_leaves"] > 0
