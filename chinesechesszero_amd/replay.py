@@ -40,7 +40,9 @@ class TupleGatherer:
     P_BYTES = NMOVES * 4
     ROW_BYTES = STATE_ELEMS * 2 + NMOVES * 4 + 4
 
-    def __init__(self, capacity_rows: int, device, group=None):
+    def __init__(self, capacity_rows: int, device, group=None, always_collective: bool = False):
+        """``always_collective``: issue the collective even in a group of one (exercises the RCCL path on a single GPU)."""
+        self.always_collective = bool(always_collective)
         self.cap = int(capacity_rows)
         if self.cap <= 0:
             raise ValueError("capacity_rows must be positive")
@@ -86,7 +88,7 @@ class TupleGatherer:
         ``self.user_sum`` (finished-game counts ride along instead of needing their own all-reduce)."""
         n = int(states.shape[0])
         self.rounds = self.collectives = 0
-        if self.world == 1:
+        if self.world == 1 and not (self.always_collective and dist.is_initialized()):
             self.any_more, self.user_sum, self.rows_per_rank = bool(more), int(user), [n]
             return states, pi, z
         sbits = states.contiguous().reshape(n, STATE_ELEMS).view(torch.uint8) if n else None

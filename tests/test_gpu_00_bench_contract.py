@@ -85,3 +85,49 @@ def test_bench_single_gpu_line_contract():
     nr = j["net_roofline"]
     assert nr["bound"] == "mfma" and nr["peak"] == 2500.0 and 0 < nr["frac"] < 1
     assert j["plies"]["start_mean"] > 3
+
+
+_RCCL_PROBE = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", sys.argv[1])
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+from chinesechesszero_amd.replay import TupleGatherer
+from chinesechesszero_amd.selfplay import BatchedSelfPlay
+from chinesechesszero_amd.net import uniform_evaluator
+g = TupleGatherer(96, dev, always_collective=True)
+sp = BatchedSelfPlay(uniform_evaluator, 16, n_playout=3, seed=1, max_plies=4)
+for _ in range(5):
+    sp.run_move()
+assert sp.engine.game_status()["over"].all()
+rows = 0
+it = iter(sp.harvest_chunks(g.cap))
+chunk = next(it)
+while chunk is not None:
+    nxt = next(it, None)
+    s, p, z = g.gather(*chunk, more=nxt is not None, user=16 if rows == 0 else 0)
+    assert g.collectives == 1 and g.rows_per_rank == [int(chunk[2].shape[0])] and g.any_more == (nxt is not None)
+    assert torch.equal(s, chunk[0]) and torch.equal(p, chunk[1]) and torch.equal(z, chunk[2])   # bytes survive the fused buffer
+    rows += int(z.shape[0])
+    chunk = nxt
+assert rows == 16 * 4 * 2, rows
+big = torch.rand((250, 2086), device=dev)
+S, P, Z = g.gather(torch.zeros((250, 17, 7, 10, 9), dtype=torch.float16, device=dev), big, torch.arange(250, device=dev).float())
+assert g.collectives == 3 and torch.equal(P, big) and torch.equal(Z, torch.arange(250, device=dev).float())   # 250 rows through 96-row rounds
+t = torch.ones(1, dtype=torch.float64, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_PROBE_OK", rows)
+"""
+
+
+def test_fused_gather_on_the_rccl_backend_group_of_one():
+    """The collective itself on backend nccl (= RCCL) with real device buffers: uint8 all_gather_into_tensor of the fused
+    buffer, the pinned header copy, float64 all-reduce and barrier as bench.py issues them. A group of one is all a single
+    GPU allows (RCCL refuses two ranks on one device); the N > 1 control flow is the gloo rehearsal above."""
+    r = subprocess.run([sys.executable, "-c", _RCCL_PROBE, str(_free_port())], cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_PROBE_OK 128" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
