@@ -15,6 +15,9 @@
 #include "cczero_kernels.h"
 #include "cczero_netops.h"
 #include "cczero_conv.h"
+#ifdef CCZ_CONV2 // experimental second form of the tower kernel: diagnostic / A-B builds only (make ab NAME=v2 ABFLAGS=-DCCZ_CONV2)
+#include "cczero_conv2.h"
+#endif
 
 using namespace ccz;
 
@@ -593,6 +596,19 @@ static int conv3x3_launch(const char *who, void *stream, const void *x_dev, cons
     if (x_dev == y_dev) return fail(-1, "%s: the output may alias the residual but not the input", who);
     if (n_pixels == 0) return 0;
     const unsigned tiles = (unsigned)((n_pixels + kCvBM - 1) / kCvBM);
+#ifdef CCZ_CONV2
+    if (relu & 4) { // bit 2: the two-workgroups-per-CU form (cczero_conv2.h): same results up to float32 summation order
+        const unsigned grid = ((tiles + 7) / 8) * 16;
+        if (residual_dev)
+            hipLaunchKernelGGL(k_conv3x3_v2<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev,
+                               (const float *)bias_f32_dev, (const _Float16 *)residual_dev, (_Float16 *)y_dev, (int)n_pixels, (int)(relu & 3), cin, (int)tiles);
+        else
+            hipLaunchKernelGGL(k_conv3x3_v2<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev,
+                               (const float *)bias_f32_dev, (const _Float16 *)nullptr, (_Float16 *)y_dev, (int)n_pixels, (int)(relu & 3), cin, (int)tiles);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+#endif
 #ifndef CCZ_STAMPS
     relu &= 3; // bit 0: ReLU, bit 1: descending tile order; the diagnostic build passes ablation switches in bits 8.. (profiles/conv_microbench.py)
 #endif

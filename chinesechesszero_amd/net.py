@@ -220,12 +220,14 @@ class InferenceNet(nn.Module):
         # alternates from layer to layer: what the previous layer wrote last (still in the Infinity Cache) is read
         # first (-0.7 % on the step; CCZ_CONV_ZIGZAG=0 switches it off).
         down = 2 if os.environ.get("CCZ_CONV_ZIGZAG", "1") == "1" else 0
+        v2 = 4 if os.environ.get("CCZ_CONV_V2", "0") == "1" else 0  # A/B only: the experimental two-workgroups-per-CU form
+        # (cczero_conv2.h, compiled into diagnostic builds with -DCCZ_CONV2; the shipped library ignores the bit)
         for i in range(0, len(self.ws), 2):
             w1, b1_, w2, b2_ = (C.c_void_p(t.data_ptr()) for t in (self.ws[i], self.bs32[i], self.ws[i + 1], self.bs32[i + 1]))
             for _, s, xp, yp, n_pixels in chains:
-                _lib.check(L.ccz_conv3x3_c256_f16(s, xp, w1, b1_, None, yp, n_pixels, 1 | down))
+                _lib.check(L.ccz_conv3x3_c256_f16(s, xp, w1, b1_, None, yp, n_pixels, 1 | down | v2))
             for _, s, xp, yp, n_pixels in chains:
-                _lib.check(L.ccz_conv3x3_c256_f16(s, yp, w2, b2_, xp, xp, n_pixels, 1))  # output written over the residual input
+                _lib.check(L.ccz_conv3x3_c256_f16(s, yp, w2, b2_, xp, xp, n_pixels, 1 | v2))  # output written over the residual input
         for st, *_ in chains[1:]:  # every side stream is joined into the current stream
             join = torch.cuda.Event()
             join.record(st)

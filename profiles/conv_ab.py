@@ -43,30 +43,41 @@ def main():
     res = (torch.randn(B, 256, 10, 9, generator=g) * 0.5).to(dev).half().contiguous(memory_format=cl)
     w = (torch.randn(256, 256, 3, 3, generator=g) * 0.03).to(dev).half().contiguous(memory_format=cl)
     bias = (torch.randn(256, generator=g) * 0.1).to(dev)
-    libs = [(n, load(n)) for n in a.libs]
+    # "name.so:FLAGS" selects the relu/flags word (bit 0 ReLU, bit 1 descending tiles, bit 2 the two-workgroups-per-CU kernel)
+    specs = [(n.split(":")[0], int(n.split(":")[1]) if ":" in n else 1) for n in a.libs]
+    cache = {}
+    libs = []
+    for name, fl in specs:
+        if name not in cache:
+            cache[name] = load(name)
+        libs.append((f"{name}:{fl}", cache[name], fl))
     ys = [torch.empty_like(x) for _ in libs]
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    def run(L, y):
-        rc = L.ccz_conv3x3_c256_f16(s, x.data_ptr(), w.data_ptr(), bias.data_ptr(), res.data_ptr() if a.res else None, y.data_ptr(), B * 90, 1)
+    def run(L, y, fl=1):
+        rc = L.ccz_conv3x3_c256_f16(s, x.data_ptr(), w.data_ptr(), bias.data_ptr(), res.data_ptr() if a.res else None, y.data_ptr(), B * 90, fl)
         assert rc == 0
 
-    for (n, L), y in zip(libs, ys):
-        run(L, y)
+    for (n, L, fl), y in zip(libs, ys):
+        run(L, y, fl)
     torch.cuda.synchronize()
     sample = sorted({0, 1, B // 2, B - 1})
     ref = F.conv2d(x[sample].float(), w.float(), bias, padding=1)
     ref = F.relu(ref + res[sample].float()) if a.res else F.relu(ref)
     out = {"boards": B, "res": a.res, "err_vs_fp32": (ys[0][sample].float() - ref).abs().max().item(),
            "max_diff_vs_first": [(y.float() - ys[0].float()).abs().max().item() for y in ys]}
-    times = {n: [] for n, _ in libs}
+    ref_all = F.conv2d(x.float(), w.float(), bias, padding=1)
+    ref_all = F.relu(ref_all + res.float()) if a.res else F.relu(ref_all)
+    out["err_vs_fp32_all"] = [(y.float() - ref_all).abs().max().item() for y in ys]
+    del ref_all
+    times = {n: [] for n, _, _ in libs}
     for _ in range(a.rounds):
-        for (n, L), y in zip(libs, ys):
+        for (n, L, fl), y in zip(libs, ys):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            run(L, y)
+            run(L, y, fl)
             e0.record()
             for _ in range(a.iters):
-                run(L, y)
+                run(L, y, fl)
             e1.record()
             torch.cuda.synchronize()
             times[n].append(e0.elapsed_time(e1) / a.iters * 1e3)
