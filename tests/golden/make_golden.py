@@ -139,6 +139,8 @@ CASES = [
     # accumulated in float16 (NEP 50); priors stay float32. Pins the engine's CCZ_FLAG_VALUE_F16 / the oracle's value_f16.
     dict(name="start_sharp_f16value_n300", start="start", ev="hash_sharp", n=300, plies=3, temps=[1.0, 1.0, 0.5], seed=16, selfplay=True, value_dtype="float16"),
     dict(name="rooks_f16value_n200", start="two_rooks", turn=1, halfmove=0, ev="hash", n=200, plies=3, temps=[1.0, 1.0, 1.0], seed=17, selfplay=True, value_dtype="float16"),
+    # the reference's default search size (parameters.py:14 PLAYOUT = 1600) with tree reuse into a second move
+    dict(name="start_sharp_n1600", start="start", ev="hash_sharp", n=1600, plies=2, temps=[1.0, 1.0], seed=18, selfplay=True),
 ]
 
 STARTS = {"two_rooks": endgame_two_rooks, "capture_to_bare": endgame_capture_to_bare, "rook_knight": endgame_rook_knight,

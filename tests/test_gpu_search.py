@@ -72,7 +72,7 @@ def test_uniform_priors_exact_ties_first_max_order():
     e.check_healthy()
 
 
-@pytest.mark.parametrize("idx", range(17))
+@pytest.mark.parametrize("idx", range(18))
 def test_golden_traces_from_reference_mcts(golden, idx, rules_of_case):
     """Visit counts / Q / priors equal the numbers the reference's own mcts.py produced (bit-exact),
     pi within 1e-12, with the golden moves forced (tree reuse across plies)."""

@@ -67,7 +67,7 @@ def _make_eval(name):
     return f
 
 
-N_CASES = 17  # 13 canonical + 2 with a shuffled `legal_moves` order (order_seed) + 2 with a float16 value (value_dtype)
+N_CASES = 18  # 13 canonical + 2 shuffled `legal_moves` order (order_seed) + 2 float16 value (value_dtype) + PLAYOUT = 1600
 
 
 def test_case_count(golden):
