@@ -23,8 +23,8 @@
 // in the workload (best of five group/chain settings); 1024 boards 96.7 against 110.5 in isolation (finer tail) but 7.15
 // against 6.90 ms per step in the workload, where the two concurrent chains already fill the tail. +18 % VALU per wave (tap
 // addressing every half-step instead of every second one, ~9 v_readlane of spilled scalars) and +6 % wave cycles; a three
-// half-tile lead of the weight DMA instead of two changed nothing. What would be next here: plane-major slab (tap offsets
-// become instruction immediates), CIN as a template parameter, a 3-slot ring with compile-time slots.
+// half-tile lead of the weight DMA instead of two changed nothing, and neither did removing the tap masks (-12 VALU per
+// half-step, timing ablation -DC2_NOMASK): the deficit is not instruction issue, so a leaner addressing scheme would not close it.
 #pragma once
 #include "cczero_conv.h"
 
@@ -89,8 +89,13 @@ template <int TAP> __device__ __forceinline__ void c2_read_x(const C2Ctx &c, int
     const int zoff = kC2ZeroOff + (off0 & 0x3f0); // same bank group as the real row: piece * 256 + (row & 15) * 16
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
+#ifdef C2_NOMASK // timing ablation only (wrong results at the board edges)
+        const int off = off0;
+        (void)zoff;
+#else
         const bool ok = (c.vmask[n] >> TAP) & 1u; // a tap that leaves the board reads a zero block
         const int off = ok ? off0 : zoff;
+#endif
         b[n] = *(const cv_half8 *)(c.lds + off + n * 1024);
     }
 }
