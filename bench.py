@@ -365,10 +365,11 @@ def main():
     t0 = time.perf_counter()
     pairs = run(a.steps, True)
     torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0  # this rank's own time (the per-rank rates); the job's time is taken behind the barrier
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    dt_local = dt = time.perf_counter() - t0
+    dt = time.perf_counter() - t0
     ranks_seen, per_rank = 1, None
     if world > 1:
         t = torch.zeros(world + 1, dtype=torch.float64, device=xdev)
