@@ -427,13 +427,14 @@ def main():
         a_step = a_sel + a_exp
         a_sim_survey = a_step - 3780 + 21420
         ach = a_step * B / t_step if t_step == t_step else None
-        traffic = traffic_source = None
+        traffic = traffic_source = rocprof_ns = None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
             try:
                 with open(pmc) as f:
                     pm = json.load(f)
                 traffic = pm.get("k_step", {}).get("hbm_bytes_per_launch")
+                rocprof_ns = pm.get("k_step", {}).get("avg_ns")
                 # NOT measured in this run: rocprofv3 PMC passes cannot run inside bench.py; these are the committed counters
                 traffic_source = f"profiles/pmc_summary.json ({pm.get('run', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, separate runs')}), replayed, not live"
                 if net_roofline is not None:  # HBM bytes of one convolution launch (PMC passes of profiles/run_profile.sh)
@@ -472,7 +473,10 @@ def main():
                          "achieved": (ach or 0) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": (ach or 0) / HBM_PEAK,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": a_step * B, "avg_launch_us": t_step * 1e6,
-                         "k_bar": kbar, "d_bar": dbar, "event_floor_us": event_floor_us},
+                         "k_bar": kbar, "d_bar": dbar, "event_floor_us": event_floor_us,
+                         # cross-check against the committed rocprofv3 --kernel-trace --stats duration of the same kernel (replayed)
+                         "rocprofv3_avg_launch_us": (rocprof_ns * 1e-3 if rocprof_ns else None),
+                         "frac_at_rocprofv3_duration": (a_step * B / (rocprof_ns * 1e-9) / HBM_PEAK if rocprof_ns else None)},
             "survey_a_sim_bytes": a_sim_survey,
             "step_split_us": {"k_step": t_step * 1e6, "evaluator": t_net * 1e6},
             "trainer_updates": (train_steps[0] if trainer is not None else 0),
