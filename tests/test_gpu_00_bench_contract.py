@@ -63,6 +63,22 @@ def test_bench_two_ranks_exchange_inside_the_timed_window():
     assert abs(j["ms_per_step"] * 12 * 1e-3 * j["value"] - 2 * 256 * 12) < 1e-3 * 2 * 256 * 12
 
 
+def test_bench_two_ranks_with_concurrent_trainer_on_rank0():
+    """BASELINE configs[4]'s control flow (N ranks of self-play, all-gather of the tuples, a trainer on rank 0 consuming the
+    gathered rows from its replay buffer on a side stream) rehearsed with two ranks on the one GPU."""
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "16", "--warmup", "2",
+           "--backend", "gloo", "--share-gpu", "--gather-rows", "1024", "--playout", "16", "--train-every", "4"] + SMALL
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    j = _json_line(r.stdout)
+    assert j["multi_gpu"]["ranks_seen"] == 2 and j["multi_gpu"]["exchanges_in_window"] == 1
+    assert j["multi_gpu"]["rows_gathered"] >= 2 * 22 * 12 * 2     # both ranks' finished games reached rank 0's buffer
+    assert j["trainer_updates"] == 4                               # one 2048-row update per 4 steps, inside the window
+    assert j["value"] > 0
+
+
 def test_bench_single_gpu_line_contract():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3", "--cpu-baseline-seconds", "3", "--playout", "64"] + SMALL
     r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
