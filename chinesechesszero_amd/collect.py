@@ -147,7 +147,7 @@ class TupleSink:
 class CollectPipeline:
     def __init__(self, init_model=None, n_boards: int = 1, n_playout: int = PLAYOUT, device: int = 0, seed: int = 0,
                  data_dir: str = DATA_DIR, reference_quirks: bool = False, num_channels: int = 256, resblocks_num: int = 40,
-                 finalize_every: int = 0, on_playout=None):
+                 finalize_every: int = 0, on_playout=None, max_plies: int = 0):
         self.board = Board()                       # collect.py:28 (never advanced: source of the turn-plane quirk)
         self.game = Game(self.board, reference_quirks=reference_quirks)
         self.temp = 1.0
@@ -165,6 +165,7 @@ class CollectPipeline:
         self.sink = TupleSink(data_dir)
         self.iters = self.sink.games
         self.episode_len = 0
+        self.max_plies = max_plies  # batched path: games adjudicated as draws at this many plies (0 = the engine's 2048)
         self.finalize_every = finalize_every
         self._finalized_at = self.sink.games
         self.on_playout = on_playout  # progress sink of the batched path (reference game.py:162-185 feeds a progress bar)
@@ -247,7 +248,9 @@ class CollectPipeline:
             rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
             self.selfplay = BatchedSelfPlay(self.policy_value_net.evaluate_leaves, self.n_boards, n_playout=self.n_playout,
                                             c_puct=self.c_puct, temp=self.temp, seed=self.seed, board_id_base=rank * self.n_boards,
-                                            device=self.device, reference_quirks=self.reference_quirks)
+                                            device=self.device, reference_quirks=self.reference_quirks, max_plies=self.max_plies)
+            if getattr(self, "_viewer", None) is not None:
+                self.selfplay.watch(0, self._viewer)
         for _ in range(n_moves):
             self.selfplay.run_move(on_playout=self.on_playout)
             st = self.selfplay.engine.game_status()
@@ -285,11 +288,18 @@ class CollectPipeline:
         self.selfplay.engine.check_healthy()
         return self.iters
 
-    def run(self, is_shown=False):
-        """collect.py:178-186"""
+    def run(self, is_shown=False, max_calls: int = 0):
+        """collect.py:178-186: collect until interrupted (``max_calls`` > 0 stops after that many ``collect_data`` calls:
+        games on the single-board path, lockstep moves on the batched one). ``is_shown`` opens the viewer window
+        (reference ``--show``): the single game, or board 0 of the batch."""
+        if is_shown and self.n_boards > 1:
+            from .frontend import get_chess_window
+            self._viewer = get_chess_window()
+        calls = 0
         try:
-            while True:
+            while max_calls <= 0 or calls < max_calls:
                 iters = self.collect_data(is_shown=is_shown)
+                calls += 1
                 log(f"Episode {iters}, steps {self.episode_len}")
         except KeyboardInterrupt:
             log("Exit")
@@ -302,7 +312,14 @@ if __name__ == "__main__":
     parser = argparse.ArgumentParser(description="collect Xiangqi self-play data on MI355X")
     parser.add_argument("--show", action="store_true", default=False)
     parser.add_argument("--model", type=str, default="current_policy.pkl")
-    parser.add_argument("--boards", type=int, default=4096)
+    parser.add_argument("--boards", type=int, default=4096, help="concurrent boards on this GPU (1 = the reference's one-game-at-a-time loop)")
     parser.add_argument("--playout", type=int, default=PLAYOUT)
+    parser.add_argument("--moves", type=int, default=0, help="stop after this many collect_data calls (0 = until interrupted, as the reference)")
+    parser.add_argument("--max-plies", type=int, default=0, help="batched path: adjudicate games at this many plies (0 = 2048)")
+    parser.add_argument("--data-dir", type=str, default=DATA_DIR)
+    parser.add_argument("--channels", type=int, default=256)
+    parser.add_argument("--blocks", type=int, default=40)
+    parser.add_argument("--seed", type=int, default=0)
     args = parser.parse_args()
-    CollectPipeline(init_model=args.model, n_boards=args.boards, n_playout=args.playout).run(is_shown=args.show)
+    CollectPipeline(init_model=args.model, n_boards=args.boards, n_playout=args.playout, data_dir=args.data_dir, seed=args.seed,
+                    num_channels=args.channels, resblocks_num=args.blocks, max_plies=args.max_plies).run(is_shown=args.show, max_calls=args.moves)

@@ -147,3 +147,22 @@ def test_fused_gather_on_the_rccl_backend_group_of_one():
     GPU allows (RCCL refuses two ranks on one device); the N > 1 control flow is the gloo rehearsal above."""
     r = subprocess.run([sys.executable, "-c", _RCCL_PROBE, str(_free_port())], cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_PROBE_OK 128" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_collect_cli_writes_the_trainer_files(tmp_path):
+    """`python -m chinesechesszero_amd.collect` as a user runs it (reference collect.py:188-198 CLI: --show / --model; here also
+    --boards / --playout / --moves ...): lockstep self-play on the GPU, harvest, shards, and on exit the converter step."""
+    cmd = [sys.executable, "-m", "chinesechesszero_amd.collect", "--boards", "32", "--playout", "4", "--blocks", "1", "--channels", "32",
+           "--max-plies", "5", "--moves", "13", "--model", "no_such_model.pkl", "--data-dir", str(tmp_path / "data")]
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    import numpy as np
+    meta = json.load(open(tmp_path / "data" / "meta.json"))
+    # 13 moves with a 5-ply cap: every board is adjudicated at its 6th and 12th move -> 2 games x 5 plies x 2 (mirror) per board
+    assert meta["total_count"] == 32 * 2 * 5 * 2 and meta["iters"] == 64 and meta["mcts_dtype"] == "float64"
+    states = np.load(tmp_path / "data" / "states.npy", mmap_mode="r")
+    pi = np.load(tmp_path / "data" / "mcts.npy", mmap_mode="r")
+    z = np.load(tmp_path / "data" / "winners.npy", mmap_mode="r")
+    assert states.shape == (640, 17, 7, 10, 9) and states.dtype == np.float16 and pi.shape == (640, 2086) and z.shape == (640,)
+    assert np.allclose(np.asarray(pi).sum(1), 1.0, atol=1e-5) and float(np.abs(np.asarray(z)).max()) == 0.0
+    assert not [f for f in os.listdir(tmp_path / "data") if f.startswith(".shard_")]
