@@ -166,3 +166,20 @@ def test_collect_cli_writes_the_trainer_files(tmp_path):
     assert states.shape == (640, 17, 7, 10, 9) and states.dtype == np.float16 and pi.shape == (640, 2086) and z.shape == (640,)
     assert np.allclose(np.asarray(pi).sum(1), 1.0, atol=1e-5) and float(np.abs(np.asarray(z)).max()) == 0.0
     assert not [f for f in os.listdir(tmp_path / "data") if f.startswith(".shard_")]
+
+
+def test_uci_cli_over_stdin_with_the_real_net():
+    """`python -m chinesechesszero_amd.uci` (the README's "standard UCI protocol", README.md:3, which the reference never
+    implemented): a session over stdin/stdout with the default 40x256 net, single-board search replayed as a hipGraph."""
+    from oracle import OracleBoard
+    script = "\n".join(["uci", "isready", "ucinewgame", "position startpos moves h2e2 h9g7", "go nodes 24", "d", "quit"]) + "\n"
+    r = subprocess.run([sys.executable, "-m", "chinesechesszero_amd.uci"], input=script, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    out = r.stdout.splitlines()
+    assert "uciok" in out and "readyok" in out
+    best = [l for l in out if l.startswith("bestmove")]
+    assert len(best) == 1 and any(l.startswith("info nodes 24 ") for l in out)
+    b = OracleBoard()          # the CPU checker: nothing in this file may touch the GPU in the pytest process itself
+    b.push("h2e2")
+    b.push("h9g7")
+    assert best[0].split()[1] in b.legal_moves
