@@ -197,3 +197,30 @@ def test_collect_pipeline_single_board_host_path(tmp_path):
         assert np.allclose(pi[5 + t], pi[t][fm]) and z[5 + t] == z[t]
         assert np.all(states[t][16] == (1 if t % 2 == 0 else 0))               # side-to-move plane (fixed mode)
     assert np.allclose(pi.sum(1), 1.0, atol=1e-6)
+
+
+def test_policy_value_fn_matches_the_reference_end_to_end():
+    """PolicyValueNet.policy_value_fn (net.py:151-205) against the reference's own function run on the same positions with
+    the same closed-form weights (tests/golden/make_golden_net.py): legal ids in the same order, exp(log p) of exactly those
+    ids, value as an ndarray (1,1) float32 -- the net on the CPU path (float32, as the golden), the rules on the GPU."""
+    import json
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import net_recipe
+    from chinesechesszero_amd.game import Board
+    from chinesechesszero_amd.net import PolicyValueNet
+    d = dict(np.load(os.path.join(here, "golden", "reference_net.npz")))
+    meta = json.load(open(os.path.join(here, "golden", "reference_net.json")))
+    pvn = PolicyValueNet(use_gpu=False, device="cpu")
+    net_recipe.fill_state_dict(pvn.policy_value_net)
+    for name in ("start", "wide80_black"):
+        board = Board(d[f"pvfn_{name}_sq"], bool(d[f"pvfn_{name}_turn"]))
+        act_probs, value = pvn.policy_value_fn(board)
+        pairs = list(act_probs)
+        assert [a for a, _ in pairs] == d[f"pvfn_{name}_ids"].tolist()
+        assert np.allclose(np.array([p for _, p in pairs], np.float32), d[f"pvfn_{name}_probs"], rtol=2e-3, atol=1e-8)
+        value = np.asarray(value)
+        assert list(value.shape) == meta[f"pvfn_{name}_value_shape"] == [1, 1] and str(value.dtype) == meta[f"pvfn_{name}_value_dtype"] == "float32"
+        assert np.allclose(value, d[f"pvfn_{name}_value"], rtol=0, atol=5e-4)
