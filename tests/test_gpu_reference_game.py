@@ -1,0 +1,112 @@
+"""GPU: one WHOLE self-play game and its tuple post-processing against vectors produced by executing the reference's own
+game.py and collect.py (tests/golden/make_golden_game.py): Game.start_self_play (game.py:133-237) played by the reference's
+MCTS_AI under np.random.seed, then CollectPipeline.preprocess / flip_data (collect.py:64-131). Rows a15 and a16 of SURVEY 8
+are thereby pinned to the reference's code (given the oracle's rules), for the host mirror AND for the device harvest."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def ref_game():
+    d = dict(np.load(os.path.join(HERE, "golden", "reference_game.npz")))
+    meta = json.load(open(os.path.join(HERE, "golden", "reference_game.json")))
+    return d, meta
+
+
+def _policy(meta):
+    from oracle.evaluators import hash_eval
+
+    def policy(board, red_states=None, black_states=None):
+        ids = board.legal_ids()
+        p, v = hash_eval(board.squares()[None, :], np.array([1 if board.turn else 0]), salt=meta["salt"], scale=meta["scale"])
+        return zip(ids, p[0][ids]), np.array([[v[0]]], dtype=np.float32)
+
+    return policy
+
+
+def test_host_game_loop_and_collect_reproduce_the_reference_game(ref_game, tmp_path):
+    """The reference's own call sequence on the mirror modules: same moves, pi bit for bit, z, the aliased history lists of
+    quirk mode, then preprocess + flip_data equal to what the reference's collect.py made of that game."""
+    from chinesechesszero_amd.collect import CollectPipeline
+    from chinesechesszero_amd.game import Game
+    from chinesechesszero_amd.mcts import MCTS_AI
+    d, meta = ref_game
+    T = meta["plies"]
+    player = MCTS_AI(_policy(meta), c_puct=5, n_playout=meta["n_playout"], is_selfplay=True)
+    progress = []
+    game = Game(reference_quirks=True, progress=lambda gi, step, adv, total, avg: progress.append((gi, step, adv, total)))
+    np.random.seed(meta["seed"])
+    play_data = game.start_self_play(player, is_shown=False, temp=1.0, game_index=7)
+    assert len(play_data) == T
+    assert [m.id for m in game.board.move_stack] == d["moves"].tolist()
+    assert np.array_equal(np.stack([t[2] for t in play_data]), d["pi"])                 # float64, bit for bit
+    assert np.array_equal(np.array([t[3] for t in play_data]), d["z"])
+    assert all(t[0] is play_data[0][0] and t[1] is play_data[0][1] for t in play_data)   # game.py:234-237: aliased lists
+    assert np.array_equal(np.stack(play_data[0][0]), d["final_red_states"]) and np.array_equal(np.stack(play_data[0][1]), d["final_black_states"])
+    assert np.array_equal(game.board.squares(), d["final_sq"]) and game.board.is_game_over()
+    assert game.board.outcome().winner is meta["winner"]
+    # the progress sink saw every playout of every move (game.py:162-185)
+    assert sum(p[2] for p in progress) == T * meta["n_playout"] and {p[0] for p in progress} == {7} and progress[-1][1] == T
+    # ---- collect.py:64-131 in quirk mode
+    cp = CollectPipeline(init_model=None, n_boards=1, data_dir=str(tmp_path), reference_quirks=True)
+    processed = cp.preprocess(play_data)
+    assert cp.episode_len == T and len(processed) == T
+    st = np.stack([np.asarray(p[0]) for p in processed])
+    assert str(st.dtype) == meta["processed_state_dtype"] == "float16" and list(st.shape) == meta["processed_state_shape"]
+    assert all(np.array_equal(s, d["processed_state"]) for s in st)
+    assert np.array_equal(np.stack([p[1] for p in processed]), d["processed_pi"]) and np.array_equal(np.array([p[2] for p in processed]), d["processed_z"])
+    flipped = cp.flip_data(processed)
+    assert len(flipped) == 2 * T
+    assert all(np.array_equal(np.asarray(p[0]), d["flipped_state"]) for p in flipped[T:])
+    assert np.array_equal(np.stack([p[1] for p in flipped[T:]]), d["flipped_pi"]) and np.array_equal(np.array([p[2] for p in flipped[T:]]), d["flipped_z"])
+
+
+@pytest.mark.parametrize("quirks", [True, False])
+def test_device_harvest_reproduces_the_reference_tuples(ref_game, quirks):
+    """The same game on the lockstep engine (the golden moves forced, the same evaluator, tree reuse): the rows k_harvest
+    writes equal the reference's preprocess + flip_data output -- in quirk mode state for state; in the default (fixed)
+    mode pi / z / mirror are the same and every state carries ITS OWN history and side-to-move plane instead."""
+    from gpu_harness import Lockstep
+    from oracle import OracleBoard
+    from chinesechesszero_amd.engine import SelfPlayEngine
+    d, meta = ref_game
+    T, n = meta["plies"], meta["n_playout"]
+    e = SelfPlayEngine(1, n_playout=n, seed=1, reference_quirks=quirks)
+    ob = OracleBoard()
+    ls = Lockstep(e, [ob], kind="hash_sharp", salts=[meta["salt"]])
+    positions = []
+    for t in range(T):
+        positions.append((ob.decode(), ob.turn))
+        ls.run_fused(n, check_leaf=False)
+        rc = ls.compare_roots()
+        k = int(rc["k"][0])
+        want = d["pi"][t]
+        acts = rc["acts"][0][:k].astype(int)
+        assert np.count_nonzero(want) <= k and np.allclose(e.root_pi()[0][:k], want[acts], rtol=0, atol=1e-12)   # schedule temp: 1.0 then 0.5
+        ls.play([int(d["moves"][t])])
+    st = e.game_status()
+    assert st["over"][0] == 1 and st["plies"][0] == T and int(st["winner"][0]) == (-1 if meta["winner"] is None else int(meta["winner"]))
+    states, pi, z = e.harvest()
+    states, pi, z = states.cpu().numpy(), pi.cpu().numpy(), z.cpu().numpy()
+    assert states.shape == (2 * T, 17, 7, 10, 9) and states.dtype == np.float16
+    assert np.allclose(pi[:T], d["processed_pi"], rtol=0, atol=1e-6) and np.allclose(pi[T:], d["flipped_pi"], rtol=0, atol=1e-6)
+    assert np.array_equal(z[:T], d["processed_z"].astype(np.float32)) and np.array_equal(z[T:], d["flipped_z"].astype(np.float32))
+    if quirks:
+        assert all(np.array_equal(s, d["processed_state"]) for s in states[:T])
+        assert all(np.array_equal(s, d["flipped_state"]) for s in states[T:])
+    else:
+        for t in (0, 1, 9, T - 1):
+            (red, black), turn = positions[t]
+            assert np.array_equal(states[t][0], red) and np.array_equal(states[t][8], black) and np.all(states[t][16] == (1 if turn else 0))
+            back = max(0, t - 3)
+            assert np.array_equal(states[t][3], positions[back][0][0]) and np.array_equal(states[t][11], positions[back][0][1])
+            assert np.array_equal(states[T + t], states[t][:, :, :, ::-1])
+        # the LAST sample's history is what the reference aliases into every sample; its turn plane differs (collect.py:78 quirk)
+        assert np.array_equal(states[T - 1][:16], d["processed_state"][:16])
+    e.check_healthy()
