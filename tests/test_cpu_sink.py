@@ -104,3 +104,37 @@ def test_float32_option_and_dtype_guard(tmp_path):
     b.append(s, p, z)
     with pytest.raises(ValueError, match="float32"):
         b.finalize()
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/dataset.py"), reason="the reference tree is only mounted in the build container")
+def test_the_references_own_dataset_reads_what_the_sink_writes(tmp_path):
+    """Not a fixture but the real consumer: reference dataset.py (numpy + torch only, importable as is) opens the directory
+    TupleSink.finalize() produced -- the check train.py:100 would make -- and hands back the rows, also after pickling
+    (DataLoader workers, dataset.py:64-73). Build container only: the reference never travels."""
+    import importlib.util
+    import pickle
+    from chinesechesszero_amd.collect import TupleSink
+    spec = importlib.util.spec_from_file_location("ref_dataset", "/root/reference/dataset.py")
+    ref = importlib.util.module_from_spec(spec)
+    sys_dont = __import__("sys")
+    old = sys_dont.dont_write_bytecode
+    sys_dont.dont_write_bytecode = True
+    try:
+        spec.loader.exec_module(ref)
+    finally:
+        sys_dont.dont_write_bytecode = old
+    s, p, z = _rows(40, 9)
+    sink = TupleSink(str(tmp_path))
+    sink.append(s[:25], p[:25], z[:25], games=1)
+    sink.append(s[25:], p[25:], z[25:], games=1)
+    sink.finalize()
+    ds = ref.NpyMemmapDataset(str(tmp_path))
+    assert len(ds) == 40
+    st, pi, w = ds[31]
+    assert st.dtype == np.float16 and pi.dtype == np.float64 and w.dtype == np.float32     # what collect.py:146-167 + convert.py store
+    assert np.array_equal(st, s[31]) and np.array_equal(pi, p[31]) and w == z[31]
+    ds2 = pickle.loads(pickle.dumps(ds))
+    assert len(ds2) == 40 and np.array_equal(ds2[7][1], p[7])
+    from chinesechesszero_amd.dataset import NpyMemmapDataset
+    mine = NpyMemmapDataset(str(tmp_path))
+    assert len(mine) == len(ds) and np.array_equal(mine[31][0].numpy(), st)
