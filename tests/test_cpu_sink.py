@@ -121,6 +121,7 @@ def test_the_references_own_dataset_reads_what_the_sink_writes(tmp_path):
     sys_dont.dont_write_bytecode = True
     try:
         spec.loader.exec_module(ref)
+        sys_dont.modules["ref_dataset"] = ref     # pickle looks the class up by module name
     finally:
         sys_dont.dont_write_bytecode = old
     s, p, z = _rows(40, 9)
