@@ -312,6 +312,10 @@ def main():
         board.push(ref_tools.move_id2move_action[int(move)])
     meta["on_playout_calls"] = calls[:200]
 
+    # ---- the reference's module-level constants (parameters.py:1-28)
+    import parameters as ref_params  # noqa
+    meta["parameters"] = {k: getattr(ref_params, k) for k in dir(ref_params) if k.isupper()}
+
     np.savez_compressed(os.path.join(HERE, "reference_search.npz"), **out)
     with open(os.path.join(HERE, "reference_search.json"), "w") as f:
         json.dump(meta, f, indent=1, default=lambda o: o if not isinstance(o, np.generic) else o.item())
