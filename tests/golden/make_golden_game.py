@@ -123,6 +123,34 @@ def main():
     out["flipped_pi"] = np.stack([np.asarray(p[1]) for p in flipped[T:]])
     out["flipped_z"] = np.array([p[2] for p in flipped[T:]], dtype=np.float64)
     meta["flipped_state_dtype"] = str(fs.dtype)
+    # ---- Game.start_play (game.py:77-130) between two non-self-play MCTS_AI players (mcts.py:225-229: temp 1e-3, tree
+    # discarded after every move): the match path as the reference's own loop runs it
+    def pol(salt):
+        def f(board, red_states=None, black_states=None):
+            ids = board.legal_ids()
+            p, v = hash_eval(board.squares()[None, :], np.array([1 if board.turn else 0]), salt=salt, scale=SCALE)
+            return zip(ids, p[0][ids]), np.array([[v[0]]], dtype=np.float32)
+        return f
+
+    red = ref_mcts.MCTS_AI(pol(31), c_puct=5, n_playout=30, is_selfplay=False)
+    black = ref_mcts.MCTS_AI(pol(32), c_puct=5, n_playout=30, is_selfplay=False)
+    match_moves = []
+    for pl in (red, black):
+        o = pl.get_action
+
+        def lg(board, temp=1e-3, return_prob=False, on_playout=None, _o=o):
+            r = _o(board, temp=temp, return_prob=return_prob, on_playout=on_playout)
+            match_moves.append(int(r))
+            return r
+        pl.get_action = lg
+    np.random.seed(SEED + 1)
+    g2 = ref_game.Game(OracleBoard())
+    winner = g2.start_play(red, black, is_shown=False)
+    out["match_moves"] = np.array(match_moves, dtype=np.int32)
+    out["match_final_sq"] = g2.board.squares()
+    meta["match"] = {"salts": [31, 32], "n_playout": 30, "seed": SEED + 1, "plies": len(match_moves),
+                     "winner": (-1 if winner == -1 else bool(winner)), "red_player_idx": red.player, "black_player_idx": black.player}
+
     np.savez_compressed(os.path.join(HERE, "reference_game.npz"), **out)
     with open(os.path.join(HERE, "reference_game.json"), "w") as f:
         json.dump(meta, f, indent=1)

@@ -110,3 +110,49 @@ def test_device_harvest_reproduces_the_reference_tuples(ref_game, quirks):
         # the LAST sample's history is what the reference aliases into every sample; its turn plane differs (collect.py:78 quirk)
         assert np.array_equal(states[T - 1][:16], d["processed_state"][:16])
     e.check_healthy()
+
+
+def test_start_play_reproduces_the_reference_match(ref_game):
+    """Game.start_play (game.py:77-130) with two non-self-play MCTS_AI players, each on its own engine, under the golden seed:
+    the same 183 moves and the same winner as the reference's own loop; and the lockstep match engine, fed the golden moves,
+    agrees ply by ply that each one is an arg-max-visit child of a fresh 30-simulation search (what temperature 1e-3 picks)."""
+    from gpu_harness import Lockstep
+    from oracle import OracleBoard
+    from oracle.evaluators import hash_eval
+    from chinesechesszero_amd.engine import SelfPlayEngine
+    from chinesechesszero_amd.game import Game
+    from chinesechesszero_amd.mcts import MCTS_AI
+    d, meta = ref_game
+    m = meta["match"]
+
+    def pol(salt):
+        def f(board, red_states=None, black_states=None):
+            ids = board.legal_ids()
+            p, v = hash_eval(board.squares()[None, :], np.array([1 if board.turn else 0]), salt=salt, scale=meta["scale"])
+            return zip(ids, p[0][ids]), np.array([[v[0]]], dtype=np.float32)
+        return f
+
+    red = MCTS_AI(pol(m["salts"][0]), c_puct=5, n_playout=m["n_playout"], is_selfplay=False)
+    black = MCTS_AI(pol(m["salts"][1]), c_puct=5, n_playout=m["n_playout"], is_selfplay=False)
+    np.random.seed(m["seed"])
+    g = Game()
+    winner = g.start_play(red, black, is_shown=False)
+    assert [mv.id for mv in g.board.move_stack] == d["match_moves"].tolist() and len(g.board.move_stack) == m["plies"]
+    assert winner == m["winner"] and red.player == m["red_player_idx"] and black.player == m["black_player_idx"]
+    assert np.array_equal(g.board.squares(), d["match_final_sq"])
+    # the batched engine on the same game (first 40 plies): fresh tree every move, alternating evaluators
+    e = SelfPlayEngine(1, n_playout=m["n_playout"], eps=0.0, seed=2)
+    ob = OracleBoard()
+    ls = {1: Lockstep(e, [ob], kind="hash_sharp", salts=[m["salts"][0]]), 0: Lockstep(e, [ob], kind="hash_sharp", salts=[m["salts"][1]])}
+    for t in range(40):
+        cur = ls[1 if ob.turn else 0]
+        cur.mcts[0].update_with_move(-1)
+        cur.run_fused(m["n_playout"], check_leaf=False)
+        rc = cur.compare_roots()
+        k = int(rc["k"][0])
+        v = rc["visits"][0][:k]
+        mv = int(d["match_moves"][t])
+        assert rc["root_visits"][0] == m["n_playout"] and v[list(rc["acts"][0][:k]).index(mv)] == v.max()
+        e.finish_move(forced_moves=np.array([mv], np.int32), keep_tree=False)
+        ob.push_id(mv)
+    e.check_healthy()
