@@ -82,6 +82,24 @@ def main():
         out[f"pvfn_{name}_turn"] = np.int32(1 if b.turn else 0)
         meta[f"pvfn_{name}_value_shape"] = list(np.asarray(value).shape)
         meta[f"pvfn_{name}_value_dtype"] = str(np.asarray(value).dtype)
+    # ---- PolicyValueNet.train_step (net.py:212-247) and policy_value (net.py:137-148): one Adam step on a fixed batch
+    # from the recipe weights (train-mode BatchNorm on the batch, l2 inside the optimiser), then the batched evaluation
+    net_recipe.fill_state_dict(pvn.policy_value_net)
+    xb = net_recipe.inputs(4)
+    pib = np.abs(net_recipe._wave("train_pi", 4 * 2086).reshape(4, 2086)) ** 4
+    pib = (pib / pib.sum(1, keepdims=True)).astype(np.float32)
+    zb = np.array([1.0, -1.0, 0.0, 1.0], dtype=np.float32)
+    act_probs, value = pvn.policy_value(xb)            # batched evaluation with the recipe weights (eval mode)
+    out["policy_value_probs"] = np.asarray(act_probs)
+    out["policy_value_value"] = np.asarray(value)
+    loss, entropy = pvn.train_step(xb, pib, zb, lr=0.002)
+    out["train_loss"] = np.asarray(loss, dtype=np.float64)
+    out["train_entropy"] = np.asarray(entropy, dtype=np.float64)
+    sd = pvn.policy_value_net.state_dict()
+    for k in ("conv_block.weight", "res_blocks.39.conv2.weight", "policy_fc.bias", "value_fc2.weight", "conv_block_bn.running_mean"):
+        out["train_after_" + k] = sd[k].detach().numpy().ravel()[:16].copy()
+    out["train_pi"] = pib
+
     np.savez_compressed(os.path.join(HERE, "reference_net.npz"), **out)
     with open(os.path.join(HERE, "reference_net.json"), "w") as f:
         json.dump(meta, f, indent=1)

@@ -45,3 +45,26 @@ def test_forward_matches_the_reference_net_at_full_size():
     assert np.allclose(v_inf.numpy(), d["forward_value"].ravel(), rtol=0, atol=1e-3)
     # the vectors are not flat: a wrong flatten order or head wiring would be far outside these tolerances
     assert float(np.exp(d["forward_logp"]).max()) > 2.2 / 2086 and float(np.ptp(d["forward_value"])) > 0.03
+
+
+def test_policy_value_and_train_step_match_the_reference():
+    """PolicyValueNet.policy_value (net.py:137-148) and train_step (net.py:212-247: train-mode BatchNorm, mse + cross-entropy,
+    Adam with weight decay; the `lr` argument is ignored by the reference too) on a fixed batch from the recipe weights."""
+    from chinesechesszero_amd.net import PolicyValueNet
+    d, _ = _golden()
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    pvn = PolicyValueNet(use_gpu=False, device="cpu")
+    net_recipe.fill_state_dict(pvn.policy_value_net)
+    xb = net_recipe.inputs(4)
+    zb = np.array([1.0, -1.0, 0.0, 1.0], dtype=np.float32)
+    act_probs, value = pvn.policy_value(xb)
+    assert act_probs.shape == (4, 2086) and value.shape == (4, 1)
+    assert np.allclose(act_probs, d["policy_value_probs"], rtol=2e-3, atol=1e-8) and np.allclose(value, d["policy_value_value"], rtol=0, atol=5e-4)
+    v0 = pvn.weights_version
+    loss, entropy = pvn.train_step(xb, d["train_pi"], zb, lr=0.002)
+    assert abs(float(loss) - float(d["train_loss"])) < 2e-3 * abs(float(d["train_loss"])) and abs(float(entropy) - float(d["train_entropy"])) < 2e-3
+    sd = pvn.policy_value_net.state_dict()
+    for k in ("conv_block.weight", "res_blocks.39.conv2.weight", "policy_fc.bias", "value_fc2.weight", "conv_block_bn.running_mean"):
+        got = sd[k].detach().numpy().ravel()[:16]
+        assert np.allclose(got, d["train_after_" + k], rtol=5e-3, atol=2e-5), (k, got[:4], d["train_after_" + k][:4])
+    assert pvn.weights_version > v0          # the fp16 inference copy (and any captured hipGraph) is stale after a step
