@@ -44,6 +44,7 @@ class Config(C.Structure):
         ("max_plies", C.c_int32), ("flags", C.c_uint32), ("seed", C.c_uint64), ("board_id_base", C.c_uint64),
         ("device", C.c_int32), ("reserve_nodes", C.c_int32),
         ("move_rank_host", C.c_void_p), ("plane_of_type", C.c_uint8 * 8), ("rule_flags", C.c_uint32), ("reserved0", C.c_uint32),
+        ("type_rank", C.c_uint8 * 8),
     ]
 
 

@@ -167,6 +167,11 @@ int ccz_create(const ccz_config *cfg, ccz_engine **out)
             d.typepack |= (uint32_t)(t - 1) << (3 * pot[t]);
         }
     }
+    d.trankpack = 0;
+    for (int t = 1; t <= 7; ++t) {
+        if (cfg->type_rank[t] > 7) { delete e; return fail(-1, "ccz_create: type_rank[%d] must be 0..7", t); }
+        d.trankpack |= (uint32_t)cfg->type_rank[t] << (3 * t);
+    }
     std::vector<uint16_t> h_rank, h_unrank;
     if (cfg->move_rank_host) {
         h_rank.assign(cfg->move_rank_host, cfg->move_rank_host + kNMoves);

@@ -86,6 +86,7 @@ struct Dev {
     const uint16_t *unrank; // [2086] inverse of rank
     uint32_t chanpack;      // 3 bits per piece type t (bits 3t..3t+2): plane channel of type t (tools.py:100)
     uint32_t typepack;      // 3 bits per channel c (bits 3c..3c+2): piece type - 1 encoded in channel c
+    uint32_t trankpack;     // 3 bits per piece type: major key of `legal_moves` order by the mover's type; 0 = none
 };
 __device__ __forceinline__ int plane_of(const Dev &D, int type) { return (int)((D.chanpack >> (3 * type)) & 7u); }
 __device__ __forceinline__ int type_in_plane(const Dev &D, int chan) { return (int)((D.typepack >> (3 * chan)) & 7u) + 1; }
@@ -326,7 +327,8 @@ struct GenResult {
 // Lane 4p+d generates direction d of piece p; lane j then tests pseudo-move j for king safety.
 // Must be called by all 64 lanes of the wave; sq[90..95] must be 0.
 __device__ inline GenResult gen_legal(const uint8_t *sq, int turn, GenScratch &S, uint16_t *ids_out, int lane,
-                                   unsigned long long *sp = nullptr, const uint16_t *rank = nullptr, const uint16_t *unrank = nullptr)
+                                   unsigned long long *sp = nullptr, const uint16_t *rank = nullptr, const uint16_t *unrank = nullptr,
+                                   uint32_t trankpack = 0u)
 {
     GenResult R;
     (void)sp;
@@ -475,6 +477,8 @@ __device__ inline GenResult gen_legal(const uint8_t *sq, int turn, GenScratch &S
     const int c64 = __builtin_amdgcn_readlane(c1, 0), c65 = __builtin_amdgcn_readlane(c1, 1);
     R.n_legal = total0 + c64 + c65;
     if (R.n_legal > kMaxLegal) R.overflow = true;
+    uint16_t *const ids_final = ids_out;
+    if (ids_out && trankpack) ids_out = S.list; // major key by piece type: list by rank into LDS first, partition below
     if (ids_out) {
         int o = incl0 - c0;
         uint32_t w = w0;
@@ -494,6 +498,27 @@ __device__ inline GenResult gen_legal(const uint8_t *sq, int turn, GenScratch &S
                 ++o;
             }
         }
+    }
+    if (ids_final && trankpack) {
+        // stable partition of the rank-ordered list by the major key of the mover's piece type (<= 8 classes): the final
+        // position of an entry = entries of smaller classes + earlier entries of its own class (two ballots per class)
+        wave_sync();
+        const int n = R.n_legal < kMaxLegal ? R.n_legal : kMaxLegal;
+        const int i0 = lane, i1 = 64 + lane;
+        const int id0 = i0 < n ? S.list[i0] : 0, id1 = i1 < n ? S.list[i1] : 0;
+        const int cl0 = i0 < n ? (int)((trankpack >> (3 * (sq[c_tab.from[id0]] & 7))) & 7u) : 8;
+        const int cl1 = i1 < n ? (int)((trankpack >> (3 * (sq[c_tab.from[id1]] & 7))) & 7u) : 8;
+        int base = 0, p0 = 0, p1 = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const uint64_t m0 = __ballot(cl0 == c), m1 = __ballot(cl1 == c);
+            const int n0c = __popcll(m0);
+            if (cl0 == c) p0 = base + __popcll(m0 & lanemask_lt(lane));
+            if (cl1 == c) p1 = base + n0c + __popcll(m1 & lanemask_lt(lane));
+            base += n0c + __popcll(m1);
+        }
+        if (i0 < n) ids_final[p0] = (uint16_t)id0;
+        if (i1 < n) ids_final[p1] = (uint16_t)id1;
     }
     CCZ_GSTAMP(sp, lane, 14)
 #undef OWN

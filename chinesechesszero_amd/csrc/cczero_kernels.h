@@ -106,9 +106,9 @@ struct LeafEval {
 __device__ inline LeafEval eval_position(const uint8_t *s_sq, int turn, int halfmove, uint64_t key,
                                          const uint64_t *s_chain, int chain_len, GenScratch &S,
                                          uint16_t *ids_out, int lane, bool &overflow, unsigned long long *sp = nullptr,
-                                         const uint16_t *rank = nullptr, const uint16_t *unrank = nullptr)
+                                         const uint16_t *rank = nullptr, const uint16_t *unrank = nullptr, uint32_t trankpack = 0u)
 {
-    const GenResult g = gen_legal(s_sq, turn, S, ids_out, lane, sp, rank, unrank);
+    const GenResult g = gen_legal(s_sq, turn, S, ids_out, lane, sp, rank, unrank, trankpack);
     overflow = g.overflow;
     int rep = 0;
     for (int i0 = 0; i0 < chain_len; i0 += 64) {
@@ -346,7 +346,7 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
     unsigned long long *sp = nullptr;
 #endif
     const LeafEval L = eval_position(s_sq, turn, halfmove, key, s_chain, chain_len, sh.S,
-                                     D.leaf_ids + (size_t)b * kMaxLegal, lane, overflow, sp, D.rank, D.unrank);
+                                     D.leaf_ids + (size_t)b * kMaxLegal, lane, overflow, sp, D.rank, D.unrank, D.trankpack);
     if (overflow) set_err(D, 4);
     CCZ_STAMP(D, b, lane, 6)
     if (lane == 0) {

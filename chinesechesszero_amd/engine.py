@@ -31,7 +31,7 @@ class SelfPlayEngine:
                  alpha: float = 0.2, temp: float = 1.0, seed: int = 0, board_id_base: int = 0,
                  device: int = 0, max_nodes: int = 0, max_depth: int = 0, max_plies: int = 0,
                  reference_quirks: bool = False, mirror: bool = True, reserve_nodes: int = 0,
-                 move_rank="tools", plane_of_type="tools", value_f16: bool = False):
+                 move_rank="tools", plane_of_type="tools", value_f16: bool = False, type_rank="tools"):
         """``move_rank`` (uint16[2086] permutation, None = ascending id) and ``plane_of_type`` (8 entries, None = type-1)
         are the run-time rule tables of ``ccz_config`` (ABI 2); the default "tools" takes the process-wide choice of
         :func:`chinesechesszero_amd.tools.set_rules`."""
@@ -49,6 +49,8 @@ class SelfPlayEngine:
             move_rank = tools.MOVE_RANK
         if isinstance(plane_of_type, str):
             plane_of_type = tools.PLANE_OF_TYPE
+        if isinstance(type_rank, str):
+            type_rank = tools.TYPE_RANK
         cfg = Config(n_boards=self.B, n_playout=self.n_playout, c_puct=float(c_puct), eps=float(eps),
                      alpha=float(alpha), temp=float(temp), max_nodes=int(max_nodes), max_depth=int(max_depth),
                      max_plies=int(max_plies), flags=flags, seed=int(seed) & (2**64 - 1),
@@ -61,6 +63,11 @@ class SelfPlayEngine:
         self.plane_of_type = (0, 0, 1, 2, 3, 4, 5, 6) if plane_of_type is None else tuple(int(x) for x in plane_of_type)
         if plane_of_type is not None:
             cfg.plane_of_type = (C.c_uint8 * 8)(*self.plane_of_type)
+        self.type_rank = None if type_rank is None else tuple(int(x) for x in type_rank)
+        if self.type_rank is not None:
+            if len(self.type_rank) != 8:
+                raise ValueError("type_rank must have 8 entries")
+            cfg.type_rank = (C.c_uint8 * 8)(*self.type_rank)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             check(self.L.ccz_create(C.byref(cfg), C.byref(h)))

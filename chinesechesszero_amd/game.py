@@ -171,7 +171,7 @@ class Board:
             from .engine import legal_moves
             mask, cnt, flags = legal_moves(self._sq[None, :], np.array([1 if self.turn else 0], np.uint8),
                                            np.array([self.halfmove_clock], np.int32), device=self._device)
-            self._cache = (tools.order_ids(np.nonzero(mask[0])[0].astype(np.int64).tolist()), int(flags[0]))
+            self._cache = (tools.order_ids(np.nonzero(mask[0])[0].astype(np.int64).tolist(), self._sq), int(flags[0]))
         return self._cache
 
     def legal_ids(self) -> list[int]:

@@ -52,10 +52,18 @@ move_action2move_id = {s: i for i, s in enumerate(_names)}
 # installing another cchess version; engines created afterwards (MCTS, BatchedSelfPlay, ...) pick them up.
 MOVE_RANK: np.ndarray | None = None
 PLANE_OF_TYPE: tuple = (0, 0, 1, 2, 3, 4, 5, 6)
+TYPE_RANK: tuple | None = None   # major key of the order by the mover's piece type (index 1..7), None = no major key
 
 
-def set_rules(move_rank=None, plane_of_type=None):
-    global MOVE_RANK, PLANE_OF_TYPE
+def set_rules(move_rank=None, plane_of_type=None, type_rank=None):
+    global MOVE_RANK, PLANE_OF_TYPE, TYPE_RANK
+    if type_rank is not None:
+        tr = tuple(int(x) for x in type_rank)
+        if len(tr) != 8 or max(tr) > 7 or min(tr) < 0:
+            raise ValueError("type_rank must be 8 entries in 0..7 (index = piece type, entry 0 unused)")
+        TYPE_RANK = tr if any(tr[1:]) else None
+    else:
+        TYPE_RANK = None
     if move_rank is not None:
         r = np.ascontiguousarray(move_rank, dtype=np.uint16)
         if r.shape != (_lib.NMOVES,) or not np.array_equal(np.sort(r), np.arange(_lib.NMOVES)):
@@ -72,12 +80,16 @@ def set_rules(move_rank=None, plane_of_type=None):
         PLANE_OF_TYPE = (0, 0, 1, 2, 3, 4, 5, 6)
 
 
-def order_ids(ids):
-    """Legal move ids in ``board.legal_moves`` order (ascending id, or ascending MOVE_RANK)."""
+def order_ids(ids, squares=None):
+    """Legal move ids in ``board.legal_moves`` order: ascending (TYPE_RANK[type of the mover], MOVE_RANK[id]); without
+    installed tables that is ascending id. ``squares`` (90 piece codes) is needed only when TYPE_RANK is installed."""
     ids = list(ids)
-    if MOVE_RANK is None:
-        return sorted(ids)
-    return sorted(ids, key=lambda i: int(MOVE_RANK[i]))
+    minor = (lambda i: i) if MOVE_RANK is None else (lambda i: int(MOVE_RANK[i]))
+    if TYPE_RANK is None:
+        return sorted(ids, key=minor)
+    if squares is None:
+        raise ValueError("a type-major order needs the position")
+    return sorted(ids, key=lambda i: (TYPE_RANK[int(squares[int(MOVE_FROM[i])]) & 7], minor(i)))
 
 
 def flip_map() -> np.ndarray:

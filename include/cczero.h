@@ -94,6 +94,11 @@ typedef struct ccz_config {
      *   child is tried first and how PUCT ties break (mcts.py:47-48,59-61). Legal moves are listed in
      *   ascending move_rank_host[id]; NULL = ascending id (this build's canonical order). Must be a
      *   permutation of 0..2085. Copied at create.
+     * type_rank: major sort key by the PIECE TYPE of the mover (index 1..7, entry 0 unused, values 0..7; all zero = no
+     *   major key): legal moves are listed in ascending (type_rank[type], move_rank[id]). Bitboard libraries iterate
+     *   piece sets, so their order is typically "these piece types first, squares in scan order within" -- e.g. the
+     *   python-chess scheme (non-pawn moves by from-square and to-square descending, then pawn moves) is
+     *   type_rank = {PAWN: 1, others: 0} with move_rank = the rank of (from, to) in descending order.
      * plane_of_type: channel (0..6) of piece type t = 1..7 inside a colour's 7-plane group, entry 0 unused;
      *   all zero = {-, 0,1,2,3,4,5,6}, i.e. `piece_type - 1` (tools.py:100) under this build's type numbering.
      *   With another cchess PIECE_TYPES numbering only this table changes (reference-trained weights see
@@ -102,6 +107,7 @@ typedef struct ccz_config {
     uint8_t plane_of_type[8];
     uint32_t rule_flags;   /* CCZ_RULE_*                                                         */
     uint32_t reserved0;
+    uint8_t type_rank[8];
 } ccz_config;
 
 typedef struct ccz_stats {

@@ -79,6 +79,8 @@ int xq_pseudo_moves(const xq_pos *p, int color, uint8_t *from, uint8_t *to);
  * xq_set_move_order installed a rank permutation (uint16[2086]; NULL = default) */
 int xq_legal_ids(const xq_board *b, uint16_t *ids);
 void xq_set_move_order(const uint16_t *rank);
+/* major key by the mover's piece type (uint8[8], index 1..7; NULL = none): order = ascending (type_rank[type], rank[id]) */
+void xq_set_type_order(const uint8_t *type_rank);
 /* channel (0..6) of piece type t = 1..7 in decode_board (tools.py:100); NULL = type-1 */
 void xq_set_plane_map(const uint8_t *plane_of_type);
 int xq_insufficient_material(const xq_board *b);

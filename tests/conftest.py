@@ -49,15 +49,17 @@ def rules_of_case():
     import oracle
     installed = []
 
-    def install(case, product: bool = False):
-        rank = np.random.RandomState(case["order_seed"]).permutation(2086).astype(np.uint16) if "order_seed" in case else None
-        oracle.set_rules(move_rank=rank)
+    def install(case, product: bool = False, both: bool = False):
+        from golden_cases import case_order
+        L = oracle.lib()
+        rank, trank = case_order(case, [L.xq_move_from(i) for i in range(2086)], [L.xq_move_to(i) for i in range(2086)])
+        oracle.set_rules(move_rank=rank, type_rank=trank)
         installed.append("oracle")
         if product:
             from chinesechesszero_amd import tools
-            tools.set_rules(move_rank=rank)
+            tools.set_rules(move_rank=rank, type_rank=trank)
             installed.append("product")
-        return rank
+        return (rank, trank) if both else rank
 
     yield install
     oracle.set_rules()

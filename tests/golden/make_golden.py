@@ -33,8 +33,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle as _oracle  # noqa: E402
+from golden_cases import case_order  # noqa: E402
 from oracle import OracleBoard  # noqa: E402
 from oracle.evaluators import EVALUATORS  # noqa: E402
+
+MOVE_FROM = [_oracle.lib().xq_move_from(i) for i in range(2086)]
+MOVE_TO = [_oracle.lib().xq_move_to(i) for i in range(2086)]
 
 REF = "/root/reference"
 
@@ -141,6 +147,10 @@ CASES = [
     dict(name="rooks_f16value_n200", start="two_rooks", turn=1, halfmove=0, ev="hash", n=200, plies=3, temps=[1.0, 1.0, 1.0], seed=17, selfplay=True, value_dtype="float16"),
     # the reference's default search size (parameters.py:14 PLAYOUT = 1600) with tree reuse into a second move
     dict(name="start_sharp_n1600", start="start", ev="hash_sharp", n=1600, plies=2, temps=[1.0, 1.0], seed=18, selfplay=True),
+    # a position-dependent order (major key = piece type of the mover): non-pawn moves by from / to square descending, pawn
+    # moves last -- the iteration scheme of python-chess-style bitboard libraries; pins the engine's type_rank table
+    dict(name="start_sharp_scanorder_n200", start="start", ev="hash_sharp", n=200, plies=3, temps=[1.0, 1.0, 0.5], seed=19, selfplay=True, order="scan_desc_pawns_last"),
+    dict(name="wide80_scanorder_n150", start="wide80", turn=1, halfmove=0, ev="hash", n=150, plies=2, temps=[1.0, 1.0], seed=20, selfplay=True, order="scan_desc_pawns_last"),
 ]
 
 STARTS = {"two_rooks": endgame_two_rooks, "capture_to_bare": endgame_capture_to_bare, "rook_knight": endgame_rook_knight,
@@ -220,14 +230,15 @@ def main():
         ev = EVALUATORS[case["ev"]]
         n_evals = [0]
 
-        rank = np.random.RandomState(case["order_seed"]).permutation(2086) if "order_seed" in case else None
+        rank, trank = case_order(case, MOVE_FROM, MOVE_TO)
 
         vdt = np.dtype(case.get("value_dtype", "float32"))
 
-        def policy(board, red_states=None, black_states=None, _ev=ev, _rank=rank, _vdt=vdt):
+        def policy(board, red_states=None, black_states=None, _ev=ev, _rank=rank, _trank=trank, _vdt=vdt):
             ids = board.legal_ids()
             if _rank is not None:  # what iterating a differently ordered `board.legal_moves` would hand to net.py:154-157
-                ids = sorted(ids, key=lambda i: int(_rank[i]))
+                sq_ = board.squares()
+                ids = sorted(ids, key=lambda i: ((_trank[int(sq_[MOVE_FROM[i]]) & 7] if _trank else 0), int(_rank[i])))
             p, v = _ev(board.squares()[None, :], np.array([1 if board.turn else 0]))
             n_evals[0] += 1
             # shape/dtypes of net.py:202-205: float32 value on the CPU path, float16 on the CUDA (autocast) path

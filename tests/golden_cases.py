@@ -41,3 +41,18 @@ def case_start(case):
     if case["start"] == "start":
         return start_position(), 1, 0
     return STARTS[case["start"]].copy(), case["turn"], case["halfmove"]
+
+
+def case_order(case, move_from=None, move_to=None):
+    """(move_rank uint16[2086] | None, type_rank list[8] | None) of a golden case: the `board.legal_moves` order it was
+    generated with. ``order_seed``: a random permutation of the ids. ``order == "scan_desc_pawns_last"``: the scheme of
+    bitboard libraries in the python-chess family -- non-pawn moves by from-square then to-square in DESCENDING square order,
+    pawn moves after them -- which needs the major key by piece type (move_from / move_to: the action table's squares)."""
+    if "order_seed" in case:
+        return np.random.RandomState(case["order_seed"]).permutation(2086).astype(np.uint16), None
+    if case.get("order") == "scan_desc_pawns_last":
+        order = np.lexsort((-np.asarray(move_to, np.int64), -np.asarray(move_from, np.int64)))
+        rank = np.empty(2086, np.uint16)
+        rank[order] = np.arange(2086, dtype=np.uint16)
+        return rank, [0, 1, 0, 0, 0, 0, 0, 0]
+    return None, None

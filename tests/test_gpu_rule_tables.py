@@ -208,3 +208,47 @@ def test_float16_value_quirk_matches_oracle_and_differs_from_float32():
         ls32.play(mv32)
     assert e.stats()["terminal_leaves"] > 0
     e.check_healthy()
+
+
+def test_type_major_scan_order_matches_oracle_and_reaches_the_host_mirror(rules_of_case):
+    """A POSITION-DEPENDENT `legal_moves` order -- major key = piece type of the mover (ccz_config.type_rank), minor key =
+    move_rank: the python-chess-family scheme "non-pawn moves by from / to square descending, then pawn moves". A static
+    permutation of the ids cannot express it (the same id is a pawn move in one position and a rook move in another)."""
+    from gpu_harness import Lockstep
+    from golden_cases import STARTS
+    from oracle import OracleBoard
+    from chinesechesszero_amd.game import Board
+    from chinesechesszero_amd.mcts import MCTS
+    rank, trank = rules_of_case({"order": "scan_desc_pawns_last"}, product=True, both=True)
+    B, n = 4, 70
+    e = _engine(B, n, seed=3, move_rank=rank, type_rank=trank)
+    boards = []
+    for b in range(B):
+        if b == 3:
+            e.set_position(b, STARTS["wide80"], 1, 0)       # 80 legal moves: both 64-lane halves of the partition
+            boards.append(OracleBoard.from_array(STARTS["wide80"], 1, 0))
+        else:
+            boards.append(OracleBoard())
+    ls = Lockstep(e, boards, kind="hash_sharp", salts=[51, 52, 53, 54])
+    for ply in range(2):
+        for _ in range(n):
+            ls.step(check_leaf=True)           # leaf id lists vs oracle.legal_ids() in the installed order, every step
+        rc = ls.compare_roots()
+        ls.play([int(rc["acts"][b][int(np.argmax(rc["visits"][b][:rc["k"][b]]))]) for b in range(B)])
+    e.check_healthy()
+    # pawn moves come last at the opening position: the five pawn pushes close the list
+    ob = OracleBoard()
+    ids = ob.legal_ids()
+    import oracle
+    L = oracle.lib()
+    is_pawn = [(ob.squares()[L.xq_move_from(i)] & 7) == 1 for i in ids]
+    assert is_pawn == [False] * 39 + [True] * 5
+    # host mirror: Board and the engines MCTS creates follow tools.set_rules
+    hb = Board()
+    assert hb.legal_ids() == ids
+    m = MCTS(lambda board, r=None, b=None: (zip(board.legal_ids(), np.full(len(board.legal_ids()), 1.0 / 2086, np.float32)), np.zeros((1, 1), np.float32)),
+             c_puct=5, n_playout=10)
+    acts, _ = m.get_move_probs(hb, temp=1.0)
+    assert list(acts) == ids and m._engine.type_rank == tuple(trank)
+    with pytest.raises(Exception, match="type_rank"):
+        _engine(1, 4, type_rank=[0, 9, 0, 0, 0, 0, 0, 0])

@@ -72,7 +72,7 @@ def test_uniform_priors_exact_ties_first_max_order():
     e.check_healthy()
 
 
-@pytest.mark.parametrize("idx", range(18))
+@pytest.mark.parametrize("idx", range(20))
 def test_golden_traces_from_reference_mcts(golden, idx, rules_of_case):
     """Visit counts / Q / priors equal the numbers the reference's own mcts.py produced (bit-exact),
     pi within 1e-12, with the golden moves forced (tree reuse across plies)."""
@@ -82,9 +82,9 @@ def test_golden_traces_from_reference_mcts(golden, idx, rules_of_case):
     d = golden["data"]
     name = case["name"]
     sqs, turn, half = case_start(case)
-    rank = rules_of_case(case)  # cases 13, 14: a shuffled `legal_moves` order through ccz_config.move_rank_host
+    rank, trank = rules_of_case(case, both=True)  # shuffled / type-major `legal_moves` orders through ccz_config.move_rank_host, type_rank
     f16 = case.get("value_dtype") == "float16"    # cases 15, 16: the reference's CUDA-path Q dtype (CCZ_FLAG_VALUE_F16)
-    e = _engine(1, case["n"], move_rank=rank, value_f16=f16)
+    e = _engine(1, case["n"], move_rank=rank, type_rank=trank, value_f16=f16)
     if case["start"] != "start":
         e.set_position(0, sqs, turn, half)
         ob = OracleBoard.from_array(sqs, turn, half)

@@ -67,13 +67,14 @@ def _make_eval(name):
     return f
 
 
-N_CASES = 18  # 13 canonical + 2 shuffled `legal_moves` order (order_seed) + 2 float16 value (value_dtype) + PLAYOUT = 1600
+N_CASES = 20  # 13 canonical + 2 shuffled order (order_seed) + 2 float16 value + PLAYOUT = 1600 + 2 type-major scan order
 
 
 def test_case_count(golden):
     assert len(golden["meta"]["cases"]) == N_CASES
     assert sum("order_seed" in c for c in golden["meta"]["cases"]) == 2
     assert sum(c.get("value_dtype") == "float16" for c in golden["meta"]["cases"]) == 2
+    assert sum(c.get("order") == "scan_desc_pawns_last" for c in golden["meta"]["cases"]) == 2
 
 
 @pytest.mark.parametrize("idx", range(N_CASES))
