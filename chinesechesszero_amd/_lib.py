@@ -23,6 +23,7 @@ PLANES = 10710
 
 ABI_VERSION = 2
 RULE_PERPETUAL_CHECK = 1
+RULE_PAWN_MOVE_RESETS_CLOCK = 2
 FLAG_REFERENCE_QUIRKS = 1
 FLAG_NO_MIRROR = 2
 FLAG_VALUE_F16 = 4

@@ -147,7 +147,8 @@ int ccz_create(const ccz_config *cfg, ccz_engine **out)
     d.board_id_base = cfg->board_id_base;
     // ---- run-time rule tables (ABI 2)
     if (cfg->rule_flags & CCZ_RULE_PERPETUAL_CHECK) { delete e; return fail(-6, "ccz_create: CCZ_RULE_PERPETUAL_CHECK is reserved and not implemented"); }
-    if (cfg->rule_flags & ~CCZ_RULE_PERPETUAL_CHECK) { delete e; return fail(-1, "ccz_create: unknown rule_flags 0x%x", cfg->rule_flags); }
+    if (cfg->rule_flags & ~(CCZ_RULE_PERPETUAL_CHECK | CCZ_RULE_PAWN_MOVE_RESETS_CLOCK)) { delete e; return fail(-1, "ccz_create: unknown rule_flags 0x%x", cfg->rule_flags); }
+    d.rule_flags = cfg->rule_flags;
     {
         uint8_t pot[8] = {0, 0, 1, 2, 3, 4, 5, 6};
         bool all_zero = true;

@@ -87,6 +87,7 @@ struct Dev {
     uint32_t chanpack;      // 3 bits per piece type t (bits 3t..3t+2): plane channel of type t (tools.py:100)
     uint32_t typepack;      // 3 bits per channel c (bits 3c..3c+2): piece type - 1 encoded in channel c
     uint32_t trankpack;     // 3 bits per piece type: major key of `legal_moves` order by the mover's type; 0 = none
+    uint32_t rule_flags;    // CCZ_RULE_*: bit 1 = pawn moves restart the sixty-move clock and the history chain like captures
 };
 __device__ __forceinline__ int plane_of(const Dev &D, int type) { return (int)((D.chanpack >> (3 * type)) & 7u); }
 __device__ __forceinline__ int type_in_plane(const Dev &D, int chan) { return (int)((D.typepack >> (3 * chan)) & 7u) + 1; }

@@ -295,6 +295,7 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
         }
         wave_sync();
         int lastcap = -1;
+        const bool pawn_zeroes = (D.rule_flags & 2u) != 0;
         if (lane == 0) {
             for (int j = 0; j < depth; ++j) {
                 const int fr = sh.pm.from[j], to = sh.pm.to[j];
@@ -303,7 +304,7 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
                 s_sq[fr] = 0;
                 sh.pm.pc[j] = pc;
                 sh.pm.cap[j] = cp;
-                if (cp) lastcap = j;
+                if (cp || (pawn_zeroes && (pc & 7) == PAWN)) lastcap = j; // "lastcap" = last clock-resetting move
             }
         }
         lastcap = __builtin_amdgcn_readfirstlane(lastcap);
@@ -788,8 +789,9 @@ __global__ __launch_bounds__(64) void k_finish_move(Dev D, const int32_t *forced
     uint64_t key = m.key ^ zob(pc, from) ^ zob(pc, to) ^ kTurnKey;
     if (cap) key ^= zob(cap, to);
     const int turn = m.turn ^ 1;
-    int halfmove = cap ? 0 : m.halfmove + 1;
-    int chain_len = cap ? 0 : m.chain_len;
+    const bool zeroing = cap || ((D.rule_flags & 2u) && (pc & 7) == PAWN); // CCZ_RULE_PAWN_MOVE_RESETS_CLOCK
+    int halfmove = zeroing ? 0 : m.halfmove + 1;
+    int chain_len = zeroing ? 0 : m.chain_len;
     if (chain_len >= kChainCap) { chain_len = kChainCap - 1; set_err(D, 64); }
     for (int i = lane; i < chain_len; i += 64) s_chain[i] = D.chain[(size_t)b * kChainCap + i];
     if (lane == 0) { s_chain[chain_len] = key; D.chain[(size_t)b * kChainCap + chain_len] = key; }

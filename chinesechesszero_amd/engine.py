@@ -31,7 +31,8 @@ class SelfPlayEngine:
                  alpha: float = 0.2, temp: float = 1.0, seed: int = 0, board_id_base: int = 0,
                  device: int = 0, max_nodes: int = 0, max_depth: int = 0, max_plies: int = 0,
                  reference_quirks: bool = False, mirror: bool = True, reserve_nodes: int = 0,
-                 move_rank="tools", plane_of_type="tools", value_f16: bool = False, type_rank="tools"):
+                 move_rank="tools", plane_of_type="tools", value_f16: bool = False, type_rank="tools",
+                 pawn_move_resets_clock="tools"):
         """``move_rank`` (uint16[2086] permutation, None = ascending id) and ``plane_of_type`` (8 entries, None = type-1)
         are the run-time rule tables of ``ccz_config`` (ABI 2); the default "tools" takes the process-wide choice of
         :func:`chinesechesszero_amd.tools.set_rules`."""
@@ -63,6 +64,11 @@ class SelfPlayEngine:
         self.plane_of_type = (0, 0, 1, 2, 3, 4, 5, 6) if plane_of_type is None else tuple(int(x) for x in plane_of_type)
         if plane_of_type is not None:
             cfg.plane_of_type = (C.c_uint8 * 8)(*self.plane_of_type)
+        if isinstance(pawn_move_resets_clock, str):
+            pawn_move_resets_clock = tools.PAWN_MOVE_RESETS_CLOCK
+        self.pawn_move_resets_clock = bool(pawn_move_resets_clock)
+        if self.pawn_move_resets_clock:
+            cfg.rule_flags = _lib.RULE_PAWN_MOVE_RESETS_CLOCK
         self.type_rank = None if type_rank is None else tuple(int(x) for x in type_rank)
         if self.type_rank is not None:
             if len(self.type_rank) != 8:

@@ -131,7 +131,7 @@ class Board:
         """Make a move (assumed legal, as in cchess); a capture resets the half-move clock."""
         mid = _move_id(move)
         fr, to = int(MOVE_FROM[mid]), int(MOVE_TO[mid])
-        capture = self._sq[to] != 0
+        capture = self._sq[to] != 0 or (tools.PAWN_MOVE_RESETS_CLOCK and (int(self._sq[fr]) & 7) == PAWN)  # "zeroing" move
         self._sq[to] = self._sq[fr]
         self._sq[fr] = 0
         self.turn = not self.turn

@@ -53,10 +53,12 @@ move_action2move_id = {s: i for i, s in enumerate(_names)}
 MOVE_RANK: np.ndarray | None = None
 PLANE_OF_TYPE: tuple = (0, 0, 1, 2, 3, 4, 5, 6)
 TYPE_RANK: tuple | None = None   # major key of the order by the mover's piece type (index 1..7), None = no major key
+PAWN_MOVE_RESETS_CLOCK = False   # sixty-move clock / repetition history restart on pawn moves too (python-chess `is_zeroing`)
 
 
-def set_rules(move_rank=None, plane_of_type=None, type_rank=None):
-    global MOVE_RANK, PLANE_OF_TYPE, TYPE_RANK
+def set_rules(move_rank=None, plane_of_type=None, type_rank=None, pawn_move_resets_clock=False):
+    global MOVE_RANK, PLANE_OF_TYPE, TYPE_RANK, PAWN_MOVE_RESETS_CLOCK
+    PAWN_MOVE_RESETS_CLOCK = bool(pawn_move_resets_clock)
     if type_rank is not None:
         tr = tuple(int(x) for x in type_rank)
         if len(tr) != 8 or max(tr) > 7 or min(tr) < 0:

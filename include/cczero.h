@@ -49,6 +49,9 @@ extern "C" {
  * colours as in cchess: RED = 1 (True), BLACK = 0 (False). square = file + 9*rank (tools.py:91). */
 
 /* ccz_config.rule_flags: rule variants of the absent `cchess` module that cannot be checked here */
+#define CCZ_RULE_PAWN_MOVE_RESETS_CLOCK 2u /* the sixty-move clock (and the repetition history with it) restarts on pawn
+                                       moves as well as on captures -- python-chess's `is_zeroing`, which a port may have kept;
+                                       default: captures only. A pawn never moves backwards, so no earlier position can recur */
 #define CCZ_RULE_PERPETUAL_CHECK 1u /* reserved: adjudicate perpetual check / chase. NOT implemented -- ccz_create
                                        refuses it (-6); python-chinese-chess may or may not apply such a rule
                                        [unverified]; the default engine has none                                */

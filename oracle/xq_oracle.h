@@ -81,6 +81,8 @@ int xq_legal_ids(const xq_board *b, uint16_t *ids);
 void xq_set_move_order(const uint16_t *rank);
 /* major key by the mover's piece type (uint8[8], index 1..7; NULL = none): order = ascending (type_rank[type], rank[id]) */
 void xq_set_type_order(const uint8_t *type_rank);
+/* the sixty-move clock and the repetition history restart on pawn moves as well as on captures (default: captures only) */
+void xq_set_pawn_move_resets_clock(int on);
 /* channel (0..6) of piece type t = 1..7 in decode_board (tools.py:100); NULL = type-1 */
 void xq_set_plane_map(const uint8_t *plane_of_type);
 int xq_insufficient_material(const xq_board *b);

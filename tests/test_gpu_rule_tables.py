@@ -252,3 +252,50 @@ def test_type_major_scan_order_matches_oracle_and_reaches_the_host_mirror(rules_
     assert list(acts) == ids and m._engine.type_rank == tuple(trank)
     with pytest.raises(Exception, match="type_rank"):
         _engine(1, 4, type_rank=[0, 9, 0, 0, 0, 0, 0, 0])
+
+
+def test_pawn_move_clock_rule_is_switchable():
+    """CCZ_RULE_PAWN_MOVE_RESETS_CLOCK: the sixty-move clock (and the repetition history) restarts on pawn moves too --
+    python-chess's `is_zeroing`, which the cchess port may have kept. Engine, oracle and host Board flip together."""
+    import oracle
+    from gpu_harness import Lockstep
+    from golden_cases import STARTS, sq as S
+    from oracle import OracleBoard
+    from chinesechesszero_amd import tools
+    from chinesechesszero_amd.game import Board
+    L = oracle.lib()
+    uid = lambda u: L.xq_move_id(S(u[:2]), S(u[2:]))
+    pos = STARTS["pawns"]                      # kings and five pawns each; RED to move, 118 plies without a capture
+    seq = ["a3a4", "f9f8", "d0d1"]            # pawn move, king move, king move
+    results = {}
+    for flag in (False, True):
+        try:
+            oracle.set_rules(pawn_move_resets_clock=flag)
+            tools.set_rules(pawn_move_resets_clock=flag)
+            e = _engine(1, 40, seed=1)        # picks the rule up from tools.set_rules
+            assert e.pawn_move_resets_clock is flag
+            e.set_position(0, pos, 1, 118)
+            ob = OracleBoard.from_array(pos, 1, 118)
+            hb = Board(pos, True, 118)
+            over = []
+            for u in seq:
+                e.finish_move(forced_moves=np.array([uid(u)], np.int32), keep_tree=False)
+                ob.push(u)
+                hb.push(u)
+                st = e.game_status()
+                assert bool(st["over"][0]) == ob.is_game_over() == hb.is_game_over(), (flag, u)
+                assert hb.halfmove_clock == ob.halfmove
+                over.append(bool(st["over"][0]))
+                if st["over"][0]:
+                    break
+            results[flag] = over
+            if not over[-1]:                   # searches below the new root agree on clocks and draws leaf by leaf
+                ls = Lockstep(e, [ob], kind="hash_sharp", salts=[9])
+                ls.run_fused(40, check_leaf=True)
+                ls.compare_roots()
+            e.check_healthy()
+        finally:
+            oracle.set_rules()
+            tools.set_rules()
+    assert results[False] == [False, True]     # 118 + 2 quiet plies: the sixty-move rule ends the game
+    assert results[True] == [False, False, False]   # the pawn move restarted the clock
