@@ -57,6 +57,8 @@ PAWN_MOVE_RESETS_CLOCK = False   # sixty-move clock / repetition history restart
 
 
 def set_rules(move_rank=None, plane_of_type=None, type_rank=None, pawn_move_resets_clock=False):
+    """Install the rule profile of the process. Every call sets ALL four choices: what is omitted returns to this build's
+    default (``set_rules()`` restores them all). Boards cache their legal-move list: change the profile between games."""
     global MOVE_RANK, PLANE_OF_TYPE, TYPE_RANK, PAWN_MOVE_RESETS_CLOCK
     PAWN_MOVE_RESETS_CLOCK = bool(pawn_move_resets_clock)
     if type_rank is not None:
