@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- self-play MCTS throughput of the MI355X lockstep engine (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]      (N > 1 without a launcher: bench.py starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one lockstep simulation of every board: select+make-move+movegen+encode (HIP) ->
@@ -60,7 +60,12 @@ def parse():
                     "window straddles a move boundary (the window then starts at the first simulation of a move)")
     ap.add_argument("--align-evaluator", choices=["net", "stub"], default="net", help="evaluator of the untimed alignment steps: the real "
                     "net (default) or the stub (fast; for rocprofv3 PMC passes, where every kernel of an untimed step costs profiler time)")
-    ap.add_argument("--gather-rows", type=int, default=8192, help="N>1: row capacity of the fused all-gather buffer (29,768 B per row)")
+    ap.add_argument("--gather-plies", type=int, default=32768, help="N>1: ply capacity of the fused all-gather slot (880 B per ply record; "
+                    "one move of 4096 boards finishes ~14 k plies = ~28 k dense rows)")
+    ap.add_argument("--replay-rows", type=int, default=0, help="N>1 / trainer: rows of the dense replay ring every rank keeps in HBM "
+                    "(0 = 40,000 x world size: more than one move's rows of all ranks)")
+    ap.add_argument("--value-f16", action="store_true", help="accumulate Q in float16 as the reference's CUDA path does (CCZ_FLAG_VALUE_F16, "
+                    "net.py:178-189 -> mcts.py:63-71); default: float32, its CPU path")
     return ap.parse_args()
 
 
@@ -131,6 +136,24 @@ def cpu_baseline(seconds: float, blocks: int, channels: int):
             "moves_per_sec": moves / dt if moves else sims / dt / 200.0}
 
 
+def self_launch(n: int) -> int:
+    """``python bench.py --gpus N`` without a launcher: run ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    bench.py <the same arguments>`` as a CHILD process (one rank per GPU over RCCL) and return its exit code. Called before
+    anything has initialised the GPU in this process, which only waits; rank 0's JSON line goes to the inherited stdout.
+    (Never an exec: replacing a process is refused on the GPU boxes, and a child keeps the exit code honest.)"""
+    import socket
+    import subprocess
+    with socket.socket() as s:  # a free rendezvous port on the loopback
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's intra-node transport needs it on these hosts
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    return subprocess.call(cmd, env=env)
+
+
 def preroll(e, plies: int, stagger: bool):
     """Untimed setup: bring the boards to a steady-state spread of game phases.
 
@@ -162,10 +185,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world and world > 1:
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (a child process; nothing has touched the GPU yet)
+        raise SystemExit(self_launch(a.gpus))
+    if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if a.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with python -m torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     if world > 1:  # every rank runs MIOpen's find step: keep their user perf-db / kernel caches apart
@@ -186,7 +210,7 @@ def main():
     xdev = dev if a.backend == "nccl" else torch.device("cpu")  # where the exchange buffers live
 
     from chinesechesszero_amd.net import PolicyValueNet, uniform_evaluator
-    from chinesechesszero_amd.replay import TupleGatherer
+    from chinesechesszero_amd.replay import RecordGatherer, ReplayBuffer, exchange_finished_games
     from chinesechesszero_amd.selfplay import BatchedSelfPlay
 
     B, n = a.boards, a.playout
@@ -198,19 +222,21 @@ def main():
     else:
         evaluator = uniform_evaluator
     sp = BatchedSelfPlay(evaluator, B, n_playout=n, seed=0, board_id_base=rank * B, device=local_rank,
-                         sampling="device", max_plies=a.max_plies)
+                         sampling="device", max_plies=a.max_plies, value_f16=a.value_f16)
     e = sp.engine
-    gather = TupleGatherer(a.gather_rows, xdev) if world > 1 else None
+    gather = RecordGatherer(max(a.gather_plies, e.max_plies), xdev) if world > 1 else None
+    # the "shared replay buffer" of BASELINE configs[3]: every rank keeps the union of all ranks' rows as a dense ring in
+    # its own HBM; finished games arrive as compact records and are expanded straight into the ring (ccz_expand_records)
+    rb = ReplayBuffer(a.replay_rows or 40000 * world, dev) if (world > 1 or a.train_every > 0) else None
+    bad_records = torch.zeros(1, dtype=torch.int32, device=dev)
 
     trainer = None
     if a.train_every > 0 and rank == 0:
-        from chinesechesszero_amd.replay import ReplayBuffer
         from chinesechesszero_amd.trainer import Trainer
         torch.manual_seed(1)
         # bf16 autocast, no GradScaler: the fp16 scaler's step() reads found_inf on the host and would stall the self-play
         # launch loop on every update
         trainer = Trainer(PolicyValueNet(device=dev, num_channels=a.channels, resblocks_num=a.blocks), amp_dtype="bf16")
-        rb = ReplayBuffer(32768, dev)
         # the buffer is prefilled with synthetic rows so that the trainer runs at its steady-state cadence from the first
         # step ("data": "synthetic"); harvested rows are appended as games finish
         g = torch.Generator(device=dev).manual_seed(2)
@@ -223,7 +249,7 @@ def main():
         train_steps = [0]
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
-    boundary = {"events": [], "host_s": 0.0, "n": 0, "rows": 0, "rows_local": 0, "games": 0, "gather_s": 0.0, "collectives": 0}
+    boundary = {"events": [], "host_s": 0.0, "n": 0, "rows": 0, "rows_local": 0, "games": 0, "gather_s": 0.0, "collectives": 0, "expand_s": 0.0}
 
     def per_move(timed):
         """The move boundary: pi + Dirichlet-mixed choice + re-root + push + game end (k_finish_move, k_flip_half), tuple
@@ -239,7 +265,6 @@ def main():
         sp.finish_move()
         st = e.game_status()
         done = int(st["over"].sum())
-        empty = lambda: (e.leaf_input[:0], torch.empty((0, 2086), device=dev), torch.empty((0,), device=dev))
         if gather is None:
             chunks = list(e.harvest_chunks(1 << 19)) if done else []
             rows = sum(int(c[2].shape[0]) for c in chunks)
@@ -249,28 +274,19 @@ def main():
                     rb.append(*c)
             loc = rows
         else:
-            it = iter(e.harvest_chunks(gather.cap)) if done else iter(())
-            chunk = next(it, None)
             rows = loc = 0
-            first = True
-            while True:
-                nxt = next(it, None) if chunk is not None else None
-                s, p, z = chunk if chunk is not None else empty()
-                loc += int(z.shape[0])
-                g0 = time.perf_counter()
-                s, p, z = gather.gather(s.to(xdev), p.to(xdev), z.to(xdev), more=nxt is not None, user=done if first else 0)
+            for union, games in exchange_finished_games(sp, gather, done):   # k_harvest_records + ONE collective per iteration
+                g1 = time.perf_counter()
+                if trainer is not None:
+                    torch.cuda.current_stream(dev).wait_event(side_done)  # the trainer's gather reads must not race the append
+                # every rank rebuilds the dense rows of ALL ranks' games in its replay ring (k_expand_records, asynchronous)
+                rows += rb.append_records(union.to(dev, non_blocking=True), e.record_flags(), e.plane_of_type, bad=bad_records)
                 if timed:
-                    boundary["gather_s"] += time.perf_counter() - g0
+                    boundary["gather_s"] += gather.seconds
                     boundary["collectives"] += gather.collectives
-                    boundary["games"] += gather.user_sum
-                first = False
-                rows += int(z.shape[0])
-                if trainer is not None and z.shape[0]:
-                    torch.cuda.current_stream(dev).wait_event(side_done)
-                    rb.append(s.to(dev), p.to(dev), z.to(dev))
-                if not gather.any_more:
-                    break
-                chunk = nxt
+                    boundary["games"] += games
+                    boundary["expand_s"] += time.perf_counter() - g1
+                loc += (2 if e.mirror else 1) * gather.rows_per_rank[gather.rank]
         if timed:
             m1.record()
             torch.cuda.synchronize()
@@ -355,7 +371,7 @@ def main():
     setup_s = time.perf_counter() - t_setup
 
     if gather is not None:  # one untimed exchange: communicator / channel set-up of the collective is not part of a move
-        gather.gather(e.leaf_input[:0].to(xdev), torch.empty((0, 2086), device=xdev), torch.empty((0,), device=xdev))
+        gather.gather(torch.empty((0, 880), dtype=torch.uint8, device=xdev))
     run(a.warmup, False)
     torch.cuda.synchronize()
     s0 = e.stats()
@@ -467,7 +483,8 @@ def main():
             "moves_per_sec": moves_per_sec,
             "move_boundary": {"in_window": boundary["n"], "ms_events": mb_ev, "ms_host": mb_host,
                               "games_finished": boundary["games"], "rows_harvested_rank0": boundary["rows_local"],
-                              "what": "k_finish_move + k_flip_half + status readback + k_harvest + restart" + (" + all-gather" if world > 1 else ""),
+                              "what": "k_finish_move + k_flip_half + status readback + " + ("k_harvest + restart" if world == 1 else
+                                      "k_harvest_records + restart + all-gather of the records + k_expand_records into the replay ring"),
                               "moves_per_sec_formula": "n_gpus * boards / (sims_per_move * (ms_per_step without the boundary) + ms_host)"},
             "roofline": {"bound": "hbm", "kernel": "k_step (fused expand+backup+select+movegen+encode)",
                          "achieved": (ach or 0) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": (ach or 0) / HBM_PEAK,
@@ -491,7 +508,12 @@ def main():
                                 "per_rank_sims_per_sec": per_rank, "exchanges_in_window": boundary["n"],
                                 "collectives_in_window": boundary["collectives"], "rows_gathered": boundary["rows"],
                                 "gather_ms": 1e3 * boundary["gather_s"] / max(1, boundary["n"]),
-                                "bytes_sent_per_rank_per_collective": gather.bytes_per_exchange(), "gather_capacity_rows": gather.cap}
+                                "expand_ms_host": 1e3 * boundary["expand_s"] / max(1, boundary["n"]),
+                                "wire_format": "compact ply records, 880 B per ply = 2 dense rows of 29,768 B (ccz_harvest_records -> "
+                                               "all_gather_into_tensor -> ccz_expand_records into every rank's replay ring)",
+                                "bytes_sent_per_rank_per_collective": gather.bytes_per_exchange(), "gather_capacity_plies": gather.cap,
+                                "payload_bytes_rank0_per_exchange": 880 * boundary["rows_local"] // (2 if e.mirror else 1) // max(1, boundary["n"]),
+                                "replay_ring_rows": rb.cap, "replay_rows_total": rb.total, "bad_records": int(bad_records.item())}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_seconds, a.blocks, a.channels)
         print(json.dumps(out), flush=True)

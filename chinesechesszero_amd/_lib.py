@@ -20,6 +20,7 @@ NMOVES = 2086
 MAX_LEGAL = 128
 MASK_WORDS = 66
 PLANES = 10710
+REC_BYTES, REC_HDR, REC_IDS, REC_PI = 880, 96, 112, 368  # compact ply record (include/cczero.h CCZ_REC_*)
 
 ABI_VERSION = 2
 RULE_PERPETUAL_CHECK = 1
@@ -86,6 +87,8 @@ PROTOTYPES = {
     "ccz_leaf_info": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "ccz_harvest_rows": (C.c_int, [_P, _P, C.POINTER(C.c_int64)]),
     "ccz_harvest": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "ccz_harvest_records": (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "ccz_expand_records": (C.c_int, [_P, _P, C.c_int64, C.c_uint32, _P, _P, _P, _P, C.c_int64, C.c_int64, _P]),
     "ccz_get_stats": (C.c_int, [_P, _P, C.POINTER(Stats)]),
     "ccz_legal_moves": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "ccz_apply_moves": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P]),

@@ -261,11 +261,25 @@ class CollectPipeline:
                     for chunk in self.selfplay.harvest_chunks(1 << 19):
                         self.sink.append(*chunk, games=done if first else 0)
                         first = False
+            elif hasattr(gatherer, "_payload"):
+                # compact exchange (replay.RecordGatherer): finished games travel as 880-byte ply records, ONE collective per
+                # move at the benchmark workload; rank 0 rebuilds the dense rows (ccz_expand_records) and stores the union
+                from .engine import expand_records, game_aligned_chunks
+                from .replay import exchange_finished_games
+                e = self.selfplay.engine
+                for union, games in exchange_finished_games(self.selfplay, gatherer, done):
+                    if gatherer.rank == 0:  # the union of the shards goes to ONE store, as N collectors -> one data file
+                        first = True
+                        for part in game_aligned_chunks(union.to(e.device), 1 << 14):  # bounds the dense temporary (2^15 rows = 1 GB)
+                            self.sink.append(*expand_records(part.contiguous(), e.record_flags(), e.plane_of_type), games=games if first else 0)
+                            first = False
+                        if first:
+                            self.sink.append(e.leaf_input[:0], torch.empty((0, 2086)), torch.empty((0,)), games=games)
+                    else:
+                        self.sink.games += games
             else:
-                # Every rank calls gather() the same number of times: once per move at least (possibly with zero rows), and
-                # again while ANY rank still holds harvest chunks. The "more" flag and the finished-game count ride in the
-                # header of the same collective (no extra all-reduce). Chunks are sized to the gatherer's capacity, so one
-                # chunk is one collective.
+                # Dense exchange (replay.TupleGatherer, round 2's wire format). Every rank calls gather() the same number of
+                # times: once per move at least (possibly with zero rows), and again while ANY rank still holds harvest chunks.
                 e = self.selfplay.engine
                 it = iter(self.selfplay.harvest_chunks(gatherer.cap)) if done else iter(())
                 chunk = next(it, None)

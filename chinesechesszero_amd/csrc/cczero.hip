@@ -146,7 +146,6 @@ int ccz_create(const ccz_config *cfg, ccz_engine **out)
     d.seed = cfg->seed;
     d.board_id_base = cfg->board_id_base;
     // ---- run-time rule tables (ABI 2)
-    if (cfg->rule_flags & CCZ_RULE_PERPETUAL_CHECK) { delete e; return fail(-6, "ccz_create: CCZ_RULE_PERPETUAL_CHECK is reserved and not implemented"); }
     if (cfg->rule_flags & ~(CCZ_RULE_PERPETUAL_CHECK | CCZ_RULE_PAWN_MOVE_RESETS_CLOCK)) { delete e; return fail(-1, "ccz_create: unknown rule_flags 0x%x", cfg->rule_flags); }
     d.rule_flags = cfg->rule_flags;
     {
@@ -191,6 +190,7 @@ int ccz_create(const ccz_config *cfg, ccz_engine **out)
     ALLOC(d.meta, B);
     ALLOC(d.root_sq, B * 96);
     ALLOC(d.chain, B * kChainCap);
+    ALLOC(d.chain_chk, B * 2);
     ALLOC(d.path, B * d.maxd);
     ALLOC(d.path_len, B);
     ALLOC(d.leaf_ids, B * kMaxLegal);
@@ -521,6 +521,79 @@ int ccz_harvest(ccz_engine *e, void *stream, void *states_f16_dev, float *pi_dev
     hipLaunchKernelGGL(k_reset, dim3(B), dim3(64), 0, s, e->d, (const uint8_t *)e->st_mask);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+int ccz_harvest_records(ccz_engine *e, void *stream, void *records_dev, int64_t capacity_plies, int64_t *plies_host)
+{
+    NEED(e);
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = fetch_meta(e, s);
+    if (rc) return rc;
+    const int B = e->d.B;
+    std::vector<long long> base((size_t)B, -1);
+    std::vector<uint8_t> mask((size_t)B, 0);
+    int64_t plies = 0;
+    bool any = false;
+    // as ccz_harvest: finished boards in index order while their plies fit; the rest stay finished for the next call
+    for (int b = 0; b < B; ++b)
+        if (e->h_meta[b].over) {
+            const int64_t add = (int64_t)e->h_meta[b].ply;
+            if (plies + add > capacity_plies) {
+                if (!any) return fail(-5, "ccz_harvest_records: the first finished game has %lld plies, capacity %lld", (long long)add, (long long)capacity_plies);
+                break;
+            }
+            base[b] = plies;
+            mask[b] = 1;
+            any = true;
+            plies += add;
+        }
+    if (plies_host) *plies_host = plies;
+    if (!any) return 0;
+    if (plies > 0 && !records_dev) return fail(-1, "ccz_harvest_records: null output buffer");
+    if (plies > 0) {
+        HIP_TRY(hipMemcpyAsync(e->st_rowbase, base.data(), (size_t)B * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_harvest_records, dim3(B, kHarvestSlices), dim3(256), 0, s, e->d, (const long long *)e->st_rowbase, (uint8_t *)records_dev);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemcpyAsync(e->st_mask, mask.data(), (size_t)B, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_reset, dim3(B), dim3(64), 0, s, e->d, (const uint8_t *)e->st_mask);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+int ccz_expand_records(void *stream, const void *records_dev, int64_t n_plies, uint32_t flags, const uint8_t *plane_of_type_host,
+                       void *states_f16_dev, float *pi_dev, float *z_dev, int64_t ring_rows, int64_t head_row, int32_t *bad_records_dev)
+{
+    if (n_plies < 0 || ring_rows < 0 || head_row < 0) return fail(-1, "ccz_expand_records: negative size");
+    if (n_plies == 0) return 0;
+    if (!records_dev || !states_f16_dev || !pi_dev || !z_dev) return fail(-1, "ccz_expand_records: null buffer");
+    if (((uintptr_t)records_dev | (uintptr_t)states_f16_dev) & 3) return fail(-1, "ccz_expand_records: buffers must be 4-byte aligned");
+    if (n_plies > (int64_t)INT32_MAX) return fail(-1, "ccz_expand_records: too many records for one launch");
+    const int64_t rows = n_plies * ((flags & CCZ_FLAG_NO_MIRROR) ? 1 : 2);
+    if (ring_rows > 0 && rows > ring_rows) return fail(-1, "ccz_expand_records: %lld rows do not fit a ring of %lld", (long long)rows, (long long)ring_rows);
+    if (ring_rows == 0 && head_row != 0) return fail(-1, "ccz_expand_records: head_row needs ring_rows");
+    uint8_t pot[8] = {0, 0, 1, 2, 3, 4, 5, 6};
+    if (plane_of_type_host) {
+        bool all_zero = true;
+        for (int t = 0; t < 8; ++t) all_zero = all_zero && plane_of_type_host[t] == 0;
+        if (!all_zero) {
+            unsigned seen = 0;
+            for (int t = 1; t <= 7; ++t) {
+                const int c = plane_of_type_host[t];
+                if (c > 6 || (seen >> c & 1u)) return fail(-1, "ccz_expand_records: plane_of_type[1..7] must be a permutation of 0..6");
+                seen |= 1u << c;
+                pot[t] = (uint8_t)c;
+            }
+        }
+    }
+    uint32_t typepack = 0;
+    for (int t = 1; t <= 7; ++t) typepack |= (uint32_t)(t - 1) << (3 * pot[t]);
+    hipLaunchKernelGGL(k_expand_records, dim3((unsigned)n_plies), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)records_dev, (long long)n_plies,
+                       flags & (CCZ_FLAG_REFERENCE_QUIRKS | CCZ_FLAG_NO_MIRROR), typepack, (uint16_t *)states_f16_dev, pi_dev, z_dev,
+                       (long long)ring_rows, (long long)head_row, bad_records_dev);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

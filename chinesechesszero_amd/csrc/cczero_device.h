@@ -63,6 +63,7 @@ struct Dev {
     BoardMeta *meta;   // [B]
     uint8_t *root_sq;  // [B][96]
     uint64_t *chain;   // [B][128]
+    uint64_t *chain_chk; // [B][2] bit i: the side to move is in check in chain position i (CCZ_RULE_PERPETUAL_CHECK)
     int32_t *path;     // [B][maxd] selection path: {node, N, Q bits, -} as seen by the select phase, so
                        // that the backup needs no dependent load of the node records
     int32_t *path_len; // [B] depth of the leaf (path holds depth+1 nodes)
@@ -87,7 +88,8 @@ struct Dev {
     uint32_t chanpack;      // 3 bits per piece type t (bits 3t..3t+2): plane channel of type t (tools.py:100)
     uint32_t typepack;      // 3 bits per channel c (bits 3c..3c+2): piece type - 1 encoded in channel c
     uint32_t trankpack;     // 3 bits per piece type: major key of `legal_moves` order by the mover's type; 0 = none
-    uint32_t rule_flags;    // CCZ_RULE_*: bit 1 = pawn moves restart the sixty-move clock and the history chain like captures
+    uint32_t rule_flags;    // CCZ_RULE_*: bit 0 = perpetual check loses (game end only), bit 1 = pawn moves restart the
+                            // sixty-move clock and the history chain like captures
 };
 __device__ __forceinline__ int plane_of(const Dev &D, int type) { return (int)((D.chanpack >> (3 * type)) & 7u); }
 __device__ __forceinline__ int type_in_plane(const Dev &D, int chan) { return (int)((D.typepack >> (3 * chan)) & 7u) + 1; }

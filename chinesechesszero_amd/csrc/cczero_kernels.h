@@ -28,6 +28,17 @@ __device__ __forceinline__ int start_piece(int s)
     return t ? t + add : 0;
 }
 
+// Node(None, 1.0) (mcts.py:94) as the only node of board b's tree in pool half `half`, no pending leaf: what a new game
+// (init_board) and MCTS.update_with_move(-1) (k_reset_tree) share. One lane.
+__device__ __forceinline__ void fresh_root(const Dev &D, int b, int half)
+{
+    const size_t base = ((size_t)b * 2 + half) * (size_t)D.cap;
+    D.nodeA[base] = NodeA{0, 0.0f, 1.0f, -1};
+    D.nodeB[base] = 0u;
+    D.path_len[b] = 0;
+    D.leaf_status[b] = CCZ_LEAF_SKIP;
+}
+
 // (re)initialise board b from D.root_sq[b] / the given turn+halfmove: key, chain, fresh tree, empty record
 __device__ inline void init_board(const Dev &D, int b, int lane, int turn, int halfmove, bool new_game_no)
 {
@@ -55,11 +66,9 @@ __device__ inline void init_board(const Dev &D, int b, int lane, int turn, int h
         m.half = (uint8_t)*D.half;
         D.meta[b] = m;
         D.chain[(size_t)b * kChainCap] = k;
-        const size_t base = ((size_t)b * 2 + m.half) * (size_t)D.cap;
-        D.nodeA[base] = NodeA{0, 0.0f, 1.0f, -1}; // Node(None, 1.0)  mcts.py:94
-        D.nodeB[base] = 0u;
-        D.path_len[b] = 0;
-        D.leaf_status[b] = CCZ_LEAF_SKIP;
+        D.chain_chk[(size_t)b * 2] = 0ull; // (the first position of a chain never lies inside a repetition window)
+        D.chain_chk[(size_t)b * 2 + 1] = 0ull;
+        fresh_root(D, b, m.half);
     }
 }
 
@@ -78,12 +87,10 @@ __global__ void k_reset_tree(Dev D, const uint8_t *mask)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= D.B || (mask && !mask[b])) return;
-    const size_t base = ((size_t)b * 2 + *D.half) * (size_t)D.cap;
-    D.nodeA[base] = NodeA{0, 0.0f, 1.0f, -1};
-    D.nodeB[base] = 0u;
+    const int half = *D.half;
+    fresh_root(D, b, half);
     D.meta[b].n_nodes = 1;
-    D.path_len[b] = 0;
-    D.leaf_status[b] = CCZ_LEAF_SKIP;
+    D.meta[b].half = (uint8_t)half;
 }
 
 __global__ __launch_bounds__(64) void k_set_position(Dev D, int b, const uint8_t *sq_in, int turn, int halfmove)
@@ -100,6 +107,10 @@ struct LeafEval {
     int n_legal;
     int status; // CCZ_LEAF_*
     bool tie;
+    bool insufficient;
+    int rep;       // occurrences of the current position in the history chain (incl. itself)
+    int first_occ; // chain index of its earliest occurrence
+    int ksq;       // king square of the side to move
 };
 
 // s_chain[0..chain_len) holds the keys since the last capture incl. the current position (last)
@@ -110,15 +121,21 @@ __device__ inline LeafEval eval_position(const uint8_t *s_sq, int turn, int half
 {
     const GenResult g = gen_legal(s_sq, turn, S, ids_out, lane, sp, rank, unrank, trankpack);
     overflow = g.overflow;
-    int rep = 0;
+    int rep = 0, first_occ = -1;
     for (int i0 = 0; i0 < chain_len; i0 += 64) {
         const int i = i0 + lane;
-        rep += __popcll(__ballot(i < chain_len && s_chain[i] == key));
+        const uint64_t hit = __ballot(i < chain_len && s_chain[i] == key);
+        if (hit && first_occ < 0) first_occ = i0 + __ffsll((long long)hit) - 1;
+        rep += __popcll(hit);
     }
     // tools.py:109-123 is_tie = insufficient material or fourfold repetition or sixty moves
     const bool sixty = halfmove >= 120 && g.n_legal > 0;
     LeafEval L;
     L.n_legal = g.n_legal;
+    L.insufficient = g.insufficient;
+    L.rep = rep;
+    L.first_occ = first_occ;
+    L.ksq = g.ksq;
     L.tie = g.insufficient || rep >= 4 || sixty;
     // mcts.py:116-126: not end and not tie -> expand ; end and tie -> 0.0 ; else side to move lost
     if (g.n_legal == 0) L.status = L.tie ? CCZ_LEAF_DRAW : CCZ_LEAF_LOSS;
@@ -803,7 +820,38 @@ __global__ __launch_bounds__(64) void k_finish_move(Dev D, const int32_t *forced
     bool overflow;
     const LeafEval L = eval_position(s_sq, turn, halfmove, key, s_chain, chain_len, S, nullptr, lane, overflow);
     if (overflow) set_err(D, 4);
+    // one bit per chain position: the side to move stands in check there (the move that led to it gave check)
+    uint64_t chk0 = zeroing ? 0ull : D.chain_chk[(size_t)b * 2], chk1 = zeroing ? 0ull : D.chain_chk[(size_t)b * 2 + 1];
+    {
+        const bool in_check = L.ksq >= 0 && king_attacked(s_sq, S, L.ksq, -1, -1, 0, turn);
+        const int ci = chain_len - 1;
+        if (in_check) { if (ci < 64) chk0 |= 1ull << ci; else chk1 |= 1ull << (ci - 64); }
+    }
+    // CCZ_RULE_PERPETUAL_CHECK: the game ends by fourfold repetition; inside the repetition window --
+    // the positions after the earliest occurrence of the repeated position -- a side whose EVERY move gave check while the
+    // other side's did not loses. Only outcome().winner changes (game.py:210-216): in the search the same leaf is
+    // "end and is_tie" -> 0.0 either way (mcts.py:120-122), so visit counts do not depend on this flag.
+    int perpetual_winner = -1;
+    if ((D.rule_flags & 1u) && L.n_legal > 0 && !L.insufficient && L.rep >= 4) {
+        const int last = chain_len - 1;
+        bool miss_mover = false, miss_other = false, any_other = false; // mover = the side that just moved (turn ^ 1)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = h * 64 + lane;
+            const bool in = i > L.first_occ && i <= last;
+            const bool bit = ((h ? chk1 : chk0) >> lane) & 1ull;
+            const bool by_mover = ((last - i) & 1) == 0;
+            miss_mover |= __ballot(in && by_mover && !bit) != 0ull;
+            miss_other |= __ballot(in && !by_mover && !bit) != 0ull;
+            any_other |= __ballot(in && !by_mover) != 0ull;
+        }
+        const bool mover_all = !miss_mover, other_all = any_other && !miss_other;
+        if (mover_all && !other_all) perpetual_winner = turn;          // the side that kept checking loses
+        else if (other_all && !mover_all) perpetual_winner = turn ^ 1;
+    }
     if (lane == 0) {
+        D.chain_chk[(size_t)b * 2] = chk0;
+        D.chain_chk[(size_t)b * 2 + 1] = chk1;
         m.key = key;
         m.halfmove = halfmove;
         m.chain_len = chain_len;
@@ -817,7 +865,7 @@ __global__ __launch_bounds__(64) void k_finish_move(Dev D, const int32_t *forced
         st.moves += 1;
         if (L.status != CCZ_LEAF_EXPAND) {
             m.over = 1;
-            m.winner = L.n_legal == 0 ? (int8_t)(turn ^ 1) : (int8_t)-1; // no legal move: side to move loses
+            m.winner = L.n_legal == 0 ? (int8_t)(turn ^ 1) : (int8_t)perpetual_winner; // no legal move: side to move loses
             st.games += 1;
         }
         D.meta[b] = m;
@@ -881,6 +929,126 @@ __global__ __launch_bounds__(256) void k_harvest(Dev D, const long long *row_bas
                 z[row] = m.winner < 0 ? 0.0f : (D.rec_turn[r] == (uint8_t)m.winner ? 1.0f : -1.0f);
             __syncthreads();
         }
+    }
+}
+
+// ------------------------------------------------------------------ compact game records (the multi-GPU wire format)
+// One fixed-size record per PLY of a finished game (include/cczero.h: CCZ_REC_*): position before the move, 16-byte
+// header, sparse pi (ids + float32, zero-padded to 128). The plies of a game are contiguous and in order, so a record
+// finds its game's first record at (index - t) and the two dense rows it stands for (the sample and its mirror image)
+// at 2 * first + t and 2 * first + T + t: expansion needs no prefix sum and no engine state. 880 B per ply against
+// 2 x 29,768 B of dense rows: what the all-gather moves (k_expand_records rebuilds the rows on the receiving side).
+constexpr int kRecBytes = 880, kRecHdr = 96, kRecIds = 112, kRecPi = 368;
+struct __align__(4) PlyHeader {
+    uint16_t t, T;      // ply index inside its game, plies of the game
+    int8_t winner;      // 1 RED, 0 BLACK, -1 draw
+    uint8_t turn, k, flags;
+    uint32_t board_id;  // global board id (low 32 bits)
+    uint32_t game_no;
+};
+static_assert(sizeof(PlyHeader) == 16, "ply header is 16 bytes");
+
+// rec_base[b]: index of the first record of board b's game in `out` (< 0: board not harvested)
+__global__ __launch_bounds__(256) void k_harvest_records(Dev D, const long long *rec_base, uint8_t *out)
+{
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const long long rb = rec_base[b];
+    if (rb < 0) return;
+    const BoardMeta m = D.meta[b];
+    const int T = m.ply;
+    for (int t = blockIdx.y; t < T; t += gridDim.y) {
+        const size_t r = (size_t)b * D.max_plies + t;
+        uint32_t *rec = (uint32_t *)(out + (size_t)(rb + t) * kRecBytes);
+        const int k = D.rec_k[r];
+        const size_t po = (size_t)b * D.pi_cap + D.rec_off[r];
+        if (tid < 24) {
+            uint32_t v = ((const uint32_t *)(D.rec_sq + r * 96))[tid];
+            if (tid == 22) v &= 0x0000ffffu;
+            if (tid == 23) v = 0u;
+            rec[tid] = v;
+        } else if (tid == 24) {
+            PlyHeader h;
+            h.t = (uint16_t)t; h.T = (uint16_t)T; h.winner = m.winner; h.turn = D.rec_turn[r]; h.k = (uint8_t)k; h.flags = 0;
+            h.board_id = (uint32_t)(D.board_id_base + (uint64_t)b); h.game_no = m.game_no;
+            *(PlyHeader *)(rec + kRecHdr / 4) = h;
+        }
+        if (tid < 64) { // ids: 128 x u16 = 64 dwords
+            const int i0 = 2 * tid, i1 = 2 * tid + 1;
+            const uint32_t lo = i0 < k ? D.rec_ids[po + i0] : 0u, hi = i1 < k ? D.rec_ids[po + i1] : 0u;
+            rec[kRecIds / 4 + tid] = lo | (hi << 16);
+        } else if (tid < 192) {
+            const int i = tid - 64;
+            ((float *)rec)[kRecPi / 4 + i] = i < k ? D.rec_pi[po + i] : 0.0f;
+        }
+    }
+}
+
+// Records -> dense training rows, exactly what k_harvest writes for the same games (game.py:213-237 z and history,
+// collect.py:64-131 preprocess + flip_data). One block per ply record; rows go to a ring of ring_rows rows starting at
+// row `head` (head = 0 and ring_rows >= rows: a plain array). flags: CCZ_FLAG_REFERENCE_QUIRKS / CCZ_FLAG_NO_MIRROR;
+// typepack: 3 bits per plane channel = piece type - 1 encoded there (ccz_config.plane_of_type inverted).
+__global__ __launch_bounds__(256) void k_expand_records(const uint8_t *recs, long long n_plies, uint32_t flags, uint32_t typepack,
+                                                          uint16_t *states, float *pi, float *z, long long ring_rows, long long head,
+                                                          int32_t *bad)
+{
+    const long long p = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (p >= n_plies) return;
+    __shared__ __align__(16) uint8_t hist[8][96];
+    __shared__ PlyHeader sh;
+    const uint8_t *rec = recs + (size_t)p * kRecBytes;
+    if (tid == 0) sh = *(const PlyHeader *)(rec + kRecHdr);
+    __syncthreads();
+    const PlyHeader h = sh;
+    const bool quirks = (flags & 1u) != 0, mirror = (flags & 2u) == 0;
+    const int t = h.t, T = h.T;
+    const long long first = p - t;
+    if (first < 0 || t >= T || first + T > n_plies || h.k > kMaxLegal) { // not a whole game in this buffer: nothing is read out of bounds
+        if (tid == 0 && bad) atomicAdd(bad, 1);
+        return;
+    }
+    const int te = quirks ? T - 1 : t; // game.py:234-237: every sample aliases the history at the LAST recorded ply
+    if (tid < 192) { // the 8-deep history of game.py:23-44: index i = the position i plies back, the first one before that
+        const int i = tid / 24, w = tid - 24 * i;
+        int tp = te - i;
+        if (tp < 0) tp = 0;
+        ((uint32_t *)hist[i])[w] = ((const uint32_t *)(recs + (size_t)(first + tp) * kRecBytes))[w];
+    }
+    __syncthreads();
+    const int turn_plane = quirks ? 1 : h.turn; // collect.py:78 reads a board that never advances
+    const long long mul = mirror ? 2 : 1;
+    for (int pass = 0; pass < (mirror ? 2 : 1); ++pass) {
+        long long row = head + mul * first + (pass ? T : 0) + t;
+        row = ring_rows > 0 ? row % ring_rows : row;
+        uint32_t *srow = (uint32_t *)(states + (size_t)row * 10710);
+        for (int i = tid; i < 5355; i += 256) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int e = 2 * i + hh;
+                const int g = e / 630, w = e - g * 630;
+                bool on;
+                if (g == 16) on = turn_plane != 0;
+                else {
+                    const int ch = w / 90, s = w - 90 * ch;
+                    const int ss = pass ? (s - s % 9) + (8 - s % 9) : s; // np.flip(axis=2): file mirror
+                    on = hist[g & 7][ss] == (int)((typepack >> (3 * ch)) & 7u) + 1 + (g >= 8 ? 8 : 0);
+                }
+                if (on) v |= (uint32_t)kHalfOne << (16 * hh);
+            }
+            srow[i] = v;
+        }
+        float *prow = pi + (size_t)row * kNMoves;
+        for (int i = tid; i < kNMoves; i += 256) prow[i] = 0.0f;
+        __syncthreads();
+        const uint16_t *ids = (const uint16_t *)(rec + kRecIds);
+        const float *pv = (const float *)(rec + kRecPi);
+        for (int i = tid; i < h.k; i += 256) {
+            const int id = ids[i];
+            if (id < kNMoves) prow[pass ? c_tab.flip[id] : id] = pv[i]; // mcts_prob[flip_map]
+        }
+        if (tid == 0) z[row] = h.winner < 0 ? 0.0f : (h.turn == (uint8_t)h.winner ? 1.0f : -1.0f); // game.py:213-219
+        __syncthreads();
     }
 }
 

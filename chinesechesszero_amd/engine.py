@@ -32,7 +32,7 @@ class SelfPlayEngine:
                  device: int = 0, max_nodes: int = 0, max_depth: int = 0, max_plies: int = 0,
                  reference_quirks: bool = False, mirror: bool = True, reserve_nodes: int = 0,
                  move_rank="tools", plane_of_type="tools", value_f16: bool = False, type_rank="tools",
-                 pawn_move_resets_clock="tools"):
+                 pawn_move_resets_clock="tools", perpetual_check="tools"):
         """``move_rank`` (uint16[2086] permutation, None = ascending id) and ``plane_of_type`` (8 entries, None = type-1)
         are the run-time rule tables of ``ccz_config`` (ABI 2); the default "tools" takes the process-wide choice of
         :func:`chinesechesszero_amd.tools.set_rules`."""
@@ -45,6 +45,8 @@ class SelfPlayEngine:
         flags = (_lib.FLAG_REFERENCE_QUIRKS if reference_quirks else 0) | (0 if mirror else _lib.FLAG_NO_MIRROR) \
             | (_lib.FLAG_VALUE_F16 if value_f16 else 0)  # value_f16: Q accumulated in float16 as on the reference's CUDA path
         self.mirror = mirror
+        self.reference_quirks = bool(reference_quirks)
+        self.max_plies = int(max_plies) if int(max_plies) > 0 else 2048  # recorded plies per game (ccz_config.max_plies)
         from . import tools
         if isinstance(move_rank, str):
             move_rank = tools.MOVE_RANK
@@ -67,8 +69,11 @@ class SelfPlayEngine:
         if isinstance(pawn_move_resets_clock, str):
             pawn_move_resets_clock = tools.PAWN_MOVE_RESETS_CLOCK
         self.pawn_move_resets_clock = bool(pawn_move_resets_clock)
-        if self.pawn_move_resets_clock:
-            cfg.rule_flags = _lib.RULE_PAWN_MOVE_RESETS_CLOCK
+        if isinstance(perpetual_check, str):
+            perpetual_check = tools.PERPETUAL_CHECK
+        self.perpetual_check = bool(perpetual_check)
+        cfg.rule_flags = (_lib.RULE_PAWN_MOVE_RESETS_CLOCK if self.pawn_move_resets_clock else 0) \
+            | (_lib.RULE_PERPETUAL_CHECK if self.perpetual_check else 0)
         self.type_rank = None if type_rank is None else tuple(int(x) for x in type_rank)
         if self.type_rank is not None:
             if len(self.type_rank) != 8:
@@ -275,6 +280,87 @@ class SelfPlayEngine:
         if len(chunks) == 1:
             return chunks[0]
         return tuple(torch.cat([c[i] for c in chunks]) for i in range(3))
+
+
+    def harvest_record_chunks(self, max_plies: int = 1 << 16):
+        """Yield uint8 [P, 880] tensors of compact ply records (``include/cczero.h`` CCZ_REC_*: whole finished games, plies in
+        order) of at most ``max_plies`` records until no finished game is left; harvested boards restart. The wire format of
+        the multi-GPU exchange: :func:`expand_records` rebuilds from them, byte for byte, the rows :meth:`harvest_chunks` yields."""
+        mul = 2 if self.mirror else 1
+        while True:
+            rows = C.c_int64(0)
+            check(self.L.ccz_harvest_rows(self.h, self._stream(), C.byref(rows)))
+            total = int(rows.value) // mul
+            if total == 0:
+                return
+            cap = min(total, int(max_plies))
+            while True:
+                rec = torch.empty((cap, _lib.REC_BYTES), dtype=torch.uint8, device=self.device)
+                got = C.c_int64(0)
+                rc = self.L.ccz_harvest_records(self.h, self._stream(), _ptr(rec), cap, C.byref(got))
+                if rc == -5 and cap < total:  # one single game is longer than the chunk: grow to fit it
+                    cap = min(total, cap * 2)
+                    continue
+                check(rc)
+                break
+            yield rec[:int(got.value)]
+
+    def record_flags(self) -> int:
+        """The ``flags`` :func:`expand_records` needs to reproduce this engine's :meth:`harvest` (quirk mode, mirror)."""
+        return (_lib.FLAG_REFERENCE_QUIRKS if self.reference_quirks else 0) | (0 if self.mirror else _lib.FLAG_NO_MIRROR)
+
+
+def rows_of_records(n_plies: int, flags: int = 0) -> int:
+    return int(n_plies) * (1 if flags & _lib.FLAG_NO_MIRROR else 2)
+
+
+def game_aligned_chunks(records: torch.Tensor, max_plies: int):
+    """Split records uint8 [P, 880] (whole games) into views of at most ``max_plies`` records that hold whole games each
+    (a single longer game becomes its own chunk). Reads one 2-byte header word per cut."""
+    P, lo = int(records.shape[0]), 0
+    while lo < P:
+        hi = min(P, lo + int(max_plies))
+        if hi < P:
+            t = int(records[hi, _lib.REC_HDR:_lib.REC_HDR + 2].cpu().view(torch.int16).item()) & 0xffff  # ply index of record hi
+            if hi - t > lo:
+                hi -= t       # cut in front of the game that holds record hi
+            else:             # the game starting at lo is longer than max_plies: take it whole (T at header bytes 2..3)
+                T = int(records[lo, _lib.REC_HDR + 2:_lib.REC_HDR + 4].cpu().view(torch.int16).item()) & 0xffff
+                hi = min(P, lo + max(T, 1))
+        yield records[lo:hi]
+        lo = hi
+
+
+def expand_records(records: torch.Tensor, flags: int = 0, plane_of_type=None, out=None, head_row: int = 0, bad=None):
+    """Compact ply records (uint8 [P, 880] on the GPU, whole games) -> the dense training rows ``ccz_harvest`` would have
+    written for those games: (states fp16 [R,17,7,10,9], pi f32 [R,2086], z f32 [R]), R = P x (1 or 2 with mirror images).
+    Stateless (no engine: the records may come from another rank). ``out=(states, pi, z)`` writes into existing arrays as a
+    ring: row i goes to (head_row + i) % len(z). ``bad``: int32 device tensor [1] counting records of cut games (skipped).
+    Asynchronous on the current stream. reference game.py:213-237 + collect.py:64-131 (preprocess, flip_data)."""
+    L = _lib.lib()
+    if not (records.is_cuda and records.dtype == torch.uint8 and records.is_contiguous()):
+        raise ValueError("records must be a contiguous uint8 device tensor")
+    if records.numel() % _lib.REC_BYTES:
+        raise ValueError("records must hold whole 880-byte ply records")
+    P = records.numel() // _lib.REC_BYTES
+    R = rows_of_records(P, flags)
+    dev = records.device
+    if out is None:
+        states = torch.empty((R, 17, 7, 10, 9), dtype=torch.float16, device=dev)
+        pi = torch.empty((R, NMOVES), dtype=torch.float32, device=dev)
+        z = torch.empty((R,), dtype=torch.float32, device=dev)
+        ring = 0
+    else:
+        states, pi, z = out
+        ring = int(z.shape[0])
+        if not (states.is_contiguous() and pi.is_contiguous() and z.is_contiguous() and states.shape[0] == ring and pi.shape[0] == ring
+                and states.dtype == torch.float16 and pi.dtype == torch.float32 and z.dtype == torch.float32):
+            raise ValueError("out must be contiguous (states fp16 [N,17,7,10,9], pi f32 [N,2086], z f32 [N])")
+    pot = None if plane_of_type is None else (C.c_uint8 * 8)(*[int(x) for x in plane_of_type])
+    with torch.cuda.device(dev):
+        check(L.ccz_expand_records(C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), _ptr(records), P, int(flags), pot,
+                                   _ptr(states), _ptr(pi), _ptr(z), ring, int(head_row) if ring else 0, _ptr(bad)))
+    return states, pi, z
 
 
 # ---------------------------------------------------------------------- stateless batch rules

@@ -213,7 +213,31 @@ class Board:
         if self.is_sixty_moves():
             return Outcome(None, "sixty_moves")
         if self.is_fourfold_repetition():
-            return Outcome(None, "fourfold_repetition")
+            w = self.perpetual_check_winner() if tools.PERPETUAL_CHECK else None
+            return Outcome(w, "fourfold_repetition" if w is None else "perpetual_check")
+        return None
+
+    def perpetual_check_winner(self):
+        """CCZ_RULE_PERPETUAL_CHECK on the host view: in a fourfold repetition, inside the window of
+        positions after the EARLIEST occurrence of the repeated position, a side whose every move gave check while not every
+        move of the other side did loses. Returns the winner (RED / BLACK) or None. The check flags of the window's positions
+        come from ONE batched ``ccz_legal_moves`` call."""
+        cur = self._chain[-1]
+        if sum(1 for p in self._chain if p == cur) < 4:
+            return None
+        first = next(i for i, p in enumerate(self._chain) if p == cur)
+        window = self._chain[first + 1:]
+        from .engine import legal_moves
+        sq = np.stack([np.frombuffer(p[0], np.uint8) for p in window])
+        _, _, flags = legal_moves(sq, np.array([1 if p[1] else 0 for p in window], np.uint8), None, device=self._device)
+        checked = [bool(f & 1) for f in flags]
+        mover = [c for p, c in zip(window, checked) if p[1] == self.turn]        # positions the side that just moved created
+        other = [c for p, c in zip(window, checked) if p[1] != self.turn]
+        mover_all, other_all = all(mover), bool(other) and all(other)
+        if mover_all and not other_all:
+            return self.turn            # the side that kept checking (it just moved) loses
+        if other_all and not mover_all:
+            return not self.turn
         return None
 
 

@@ -173,3 +173,7 @@ class BatchedSelfPlay:
 
     def harvest_chunks(self, max_rows: int = 1 << 19):
         return self.engine.harvest_chunks(max_rows)
+
+    def harvest_record_chunks(self, max_plies: int = 1 << 16):
+        """Finished games as compact ply records (the exchange format, ``replay.RecordGatherer``)."""
+        return self.engine.harvest_record_chunks(max_plies)

@@ -54,13 +54,56 @@ MOVE_RANK: np.ndarray | None = None
 PLANE_OF_TYPE: tuple = (0, 0, 1, 2, 3, 4, 5, 6)
 TYPE_RANK: tuple | None = None   # major key of the order by the mover's piece type (index 1..7), None = no major key
 PAWN_MOVE_RESETS_CLOCK = False   # sixty-move clock / repetition history restart on pawn moves too (python-chess `is_zeroing`)
+PERPETUAL_CHECK = False          # a fourfold repetition in which one side checked throughout is lost by that side
+PRESET = "canonical"             # name of the installed preset ("custom" after a set_rules call with explicit tables)
 
 
-def set_rules(move_rank=None, plane_of_type=None, type_rank=None, pawn_move_resets_clock=False):
-    """Install the rule profile of the process. Every call sets ALL four choices: what is omitted returns to this build's
-    default (``set_rules()`` restores them all). Boards cache their legal-move list: change the profile between games."""
-    global MOVE_RANK, PLANE_OF_TYPE, TYPE_RANK, PAWN_MOVE_RESETS_CLOCK
+def _scan_desc_rank() -> np.ndarray:
+    """move_rank of "from-square descending, then to-square descending" (the square scan of python-chess-style bitboards)."""
+    order = np.lexsort((-MOVE_TO.astype(np.int64), -MOVE_FROM.astype(np.int64)))
+    rank = np.empty(_lib.NMOVES, np.uint16)
+    rank[order] = np.arange(_lib.NMOVES, dtype=np.uint16)
+    return rank
+
+
+def rule_presets() -> dict:
+    """Named rule profiles for :func:`set_rules` -- every entry is a GUESS at the absent ``cchess`` module except "canonical",
+    which is this build's own choice; none can be verified in this image.
+
+    * ``"canonical"`` (default): ``legal_moves`` in ascending move id; PIECE_TYPES numbering PAWN 1, CANNON 2, ROOK 3, KNIGHT 4,
+      BISHOP 5, ADVISOR 6, KING 7 (plane channel = type - 1, tools.py:100); captures alone reset the clock; no perpetual-check
+      adjudication. What every golden trace without an ``order`` and the benchmark use.
+    * ``"python-chess-lineage"`` [unverified recollection of python-chinese-chess as a python-chess port]: PIECE_TYPES PAWN 1,
+      ROOK 2, KNIGHT 3, BISHOP 4, ADVISOR 5, KING 6, CANNON 7 (so the plane channels are P,R,N,B,A,K,C); ``legal_moves``
+      iterates piece sets: non-pawn moves by from-square then to-square in DESCENDING square order, pawn moves after them;
+      perpetual check loses. The profile to try FIRST with reference-trained weights: with the wrong numbering the net sees
+      permuted planes."""
+    return {
+        "canonical": dict(),
+        "python-chess-lineage": dict(move_rank=_scan_desc_rank(), type_rank=(0, 1, 0, 0, 0, 0, 0, 0),
+                                     plane_of_type=(0, 0, 6, 1, 2, 3, 4, 5), perpetual_check=True),
+    }
+
+
+def set_rules(move_rank=None, plane_of_type=None, type_rank=None, pawn_move_resets_clock=False, perpetual_check=False, preset=None):
+    """Install the rule profile of the process. Every call sets ALL choices: what is omitted returns to this build's
+    default (``set_rules()`` restores them all). ``preset``: a name from :func:`rule_presets` (explicit arguments override its
+    entries). Boards cache their legal-move list: change the profile between games."""
+    global MOVE_RANK, PLANE_OF_TYPE, TYPE_RANK, PAWN_MOVE_RESETS_CLOCK, PERPETUAL_CHECK, PRESET
+    explicit = any(x is not None for x in (move_rank, plane_of_type, type_rank)) or pawn_move_resets_clock or perpetual_check
+    if preset is not None:
+        table = rule_presets()
+        if preset not in table:
+            raise ValueError(f"unknown rule preset {preset!r}: one of {sorted(table)}")
+        p = table[preset]
+        move_rank = p.get("move_rank") if move_rank is None else move_rank
+        plane_of_type = p.get("plane_of_type") if plane_of_type is None else plane_of_type
+        type_rank = p.get("type_rank") if type_rank is None else type_rank
+        pawn_move_resets_clock = pawn_move_resets_clock or p.get("pawn_move_resets_clock", False)
+        perpetual_check = perpetual_check or p.get("perpetual_check", False)
+    PRESET = (preset if not explicit else "custom") if (preset is not None or explicit) else "canonical"
     PAWN_MOVE_RESETS_CLOCK = bool(pawn_move_resets_clock)
+    PERPETUAL_CHECK = bool(perpetual_check)
     if type_rank is not None:
         tr = tuple(int(x) for x in type_rank)
         if len(tr) != 8 or max(tr) > 7 or min(tr) < 0:
@@ -82,6 +125,12 @@ def set_rules(move_rank=None, plane_of_type=None, type_rank=None, pawn_move_rese
         PLANE_OF_TYPE = (0,) + pt[1:]
     else:
         PLANE_OF_TYPE = (0, 0, 1, 2, 3, 4, 5, 6)
+
+
+def current_rules() -> dict:
+    """The installed profile as keyword arguments (what ``oracle.set_rules`` takes too: the checker's twin of this module)."""
+    return dict(move_rank=MOVE_RANK, plane_of_type=PLANE_OF_TYPE, type_rank=TYPE_RANK,
+                pawn_move_resets_clock=PAWN_MOVE_RESETS_CLOCK, perpetual_check=PERPETUAL_CHECK)
 
 
 def order_ids(ids, squares=None):

@@ -52,9 +52,14 @@ extern "C" {
 #define CCZ_RULE_PAWN_MOVE_RESETS_CLOCK 2u /* the sixty-move clock (and the repetition history with it) restarts on pawn
                                        moves as well as on captures -- python-chess's `is_zeroing`, which a port may have kept;
                                        default: captures only. A pawn never moves backwards, so no earlier position can recur */
-#define CCZ_RULE_PERPETUAL_CHECK 1u /* reserved: adjudicate perpetual check / chase. NOT implemented -- ccz_create
-                                       refuses it (-6); python-chinese-chess may or may not apply such a rule
-                                       [unverified]; the default engine has none                                */
+#define CCZ_RULE_PERPETUAL_CHECK 1u /* a game that ends by fourfold repetition is examined for perpetual check: inside the
+                                       repetition window (the positions after the EARLIEST occurrence of the repeated position,
+                                       up to the current one) a side whose every move gave check, while not every move of the
+                                       other side did, LOSES (winner = the other side); both or neither: draw, as without the
+                                       flag. Changes outcome().winner only (game.py:210-216, z of the tuples): in the search
+                                       the same leaf is `end and is_tie` -> 0.0 either way (mcts.py:120-122), visit counts do
+                                       not depend on it. This build's statement of the rule: python-chinese-chess may apply
+                                       one [unverified]; default off                                                    */
 
 /* flags for ccz_config.flags */
 #define CCZ_FLAG_REFERENCE_QUIRKS 1u /* harvest(): reproduce game.py:234-237 (all samples carry the
@@ -244,6 +249,35 @@ int ccz_harvest_rows(ccz_engine *e, void *stream, int64_t *rows_host);
  * the others stay finished for the next call (loop until ccz_harvest_rows reports 0). Syncs. */
 int ccz_harvest(ccz_engine *e, void *stream, void *states_f16_dev, float *pi_dev, float *z_dev,
                 int64_t capacity_rows, int64_t *rows_host);
+
+/* ---- compact game records: the wire format of the multi-GPU exchange ------------------------------ */
+/* One fixed-size record per PLY of a finished game, plies of a game contiguous and in order:
+ *   bytes   0..89   position before the move (piece codes, square = file + 9*rank), 90..95 zero
+ *   bytes  96..111  header: uint16 t (ply index), uint16 T (plies of the game), int8 winner (1 RED, 0 BLACK, -1 draw),
+ *                   uint8 turn (side to move), uint8 k (entries of pi), uint8 flags (0), uint32 board_id (global),
+ *                   uint32 game_no
+ *   bytes 112..367  uint16 ids[128]   move ids of the root's children (mcts.py:162), zero-padded
+ *   bytes 368..879  float  pi[128]    visit distribution of the move (mcts.py:163-166), zero-padded
+ * 880 B per ply stand for the TWO dense rows of 29,768 B (sample + mirror image) that ccz_harvest writes, so the
+ * all-gather of finished games (replay.RecordGatherer) moves 1/67 of the bytes; ccz_expand_records rebuilds the rows
+ * on the receiving side. What N reference collectors would append to data.h5 (collect.py:146-167). */
+#define CCZ_REC_BYTES 880
+#define CCZ_REC_HDR 96
+#define CCZ_REC_IDS 112
+#define CCZ_REC_PI 368
+/* ccz_harvest with records as output: the finished boards (index order, while their plies fit capacity_plies; loop
+ * until ccz_harvest_rows reports 0) are written to records_dev [capacity_plies x 880 B] and restarted. Syncs. */
+int ccz_harvest_records(ccz_engine *e, void *stream, void *records_dev, int64_t capacity_plies, int64_t *plies_host);
+/* Records -> dense rows, byte for byte what ccz_harvest writes for the same games (game.py:213-237, collect.py:64-131):
+ * state fp16 [17,7,10,9], pi float32 [2086], z float32; per game T samples then (unless CCZ_FLAG_NO_MIRROR) their T mirror
+ * images. Stateless: needs no engine (the receiving rank may never have played these games). records_dev must hold WHOLE
+ * games (a record whose game is cut is skipped and counted in *bad_records_dev, int32 on the device, may be NULL).
+ * flags: CCZ_FLAG_REFERENCE_QUIRKS | CCZ_FLAG_NO_MIRROR; plane_of_type_host: as ccz_config.plane_of_type or NULL.
+ * Rows are written to row (head_row + i) % ring_rows of the output arrays (a replay ring resident in HBM);
+ * ring_rows = 0: a plain array, row i. Asynchronous on `stream`. */
+int ccz_expand_records(void *stream, const void *records_dev, int64_t n_plies, uint32_t flags,
+                       const uint8_t *plane_of_type_host, void *states_f16_dev, float *pi_dev, float *z_dev,
+                       int64_t ring_rows, int64_t head_row, int32_t *bad_records_dev);
 
 int ccz_get_stats(ccz_engine *e, void *stream, ccz_stats *out); /* syncs */
 

@@ -83,6 +83,9 @@ void xq_set_move_order(const uint16_t *rank);
 void xq_set_type_order(const uint8_t *type_rank);
 /* the sixty-move clock and the repetition history restart on pawn moves as well as on captures (default: captures only) */
 void xq_set_pawn_move_resets_clock(int on);
+/* perpetual check loses (twin of CCZ_RULE_PERPETUAL_CHECK; changes xq_outcome_winner of a fourfold repetition only) */
+void xq_set_perpetual_check(int on);
+int xq_perpetual_check_winner(const xq_board *b);
 /* channel (0..6) of piece type t = 1..7 in decode_board (tools.py:100); NULL = type-1 */
 void xq_set_plane_map(const uint8_t *plane_of_type);
 int xq_insufficient_material(const xq_board *b);

@@ -73,6 +73,102 @@ def test_all_gather_of_tuples_world2():
     assert res[0][2] == res[1][2] == sum(sum(c) for c in rounds)  # every rank holds the union of the shards
 
 
+def _records(rank, game_lengths):
+    """Synthetic compact ply records (include/cczero.h CCZ_REC_*): whole games, valid headers, random payload."""
+    g = torch.Generator().manual_seed(500 + rank)
+    P = sum(game_lengths)
+    rec = torch.randint(0, 256, (P, 880), dtype=torch.uint8, generator=g)
+    hdr = np.zeros((P, 4), np.uint16)
+    p = 0
+    for T in game_lengths:
+        for t in range(T):
+            hdr[p] = (t, T, 0, 0)
+            p += 1
+    rec[:, 96:104] = torch.from_numpy(hdr.view(np.uint8).reshape(P, 8))
+    return rec
+
+
+def _chunks(rank, lengths, max_plies):
+    """What an engine's harvest_record_chunks(max_plies) hands over: chunks of whole games, in order."""
+    rec, out, lo = _records(rank, lengths), [], 0
+    bounds = np.cumsum([0] + list(lengths))
+    while lo < len(lengths):
+        hi = lo + 1
+        while hi < len(lengths) and bounds[hi + 1] - bounds[lo] <= max_plies:
+            hi += 1
+        out.append(rec[bounds[lo]:bounds[hi]])
+        lo = hi
+    return out
+
+
+class _RecordSource:
+    def __init__(self, rank, lengths):
+        self.rank, self.lengths = rank, lengths
+
+    def harvest_record_chunks(self, max_plies):
+        return iter(_chunks(self.rank, self.lengths, max_plies))
+
+
+def _record_worker(rank, world, port, rounds, cap, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from chinesechesszero_amd.replay import RecordGatherer, exchange_finished_games
+        g = RecordGatherer(cap, "cpu")
+        bad, total = [], 0
+        assert g.bytes_per_exchange() == -(-(64 + cap * 880) // 64) * 64
+        for x, lengths in enumerate(rounds):
+            parts = []
+            for union, games in exchange_finished_games(_RecordSource(rank, lengths[rank]), g, len(lengths[rank])):
+                parts.append((union.clone(), games, g.collectives))
+            chunks = [_chunks(r, lengths[r], cap) for r in range(world)]
+            want_rounds = max(1, max(len(c) for c in chunks))
+            if len(parts) != want_rounds:
+                bad.append((x, "rounds", len(parts), want_rounds))
+            if sum(p[1] for p in parts) != sum(len(l) for l in lengths):
+                bad.append((x, "games"))
+            if any(p[2] != 1 for p in parts):           # every iteration of the exchange is exactly ONE collective
+                bad.append((x, "collectives", [p[2] for p in parts]))
+            # the union: round-major, rank-major inside a round, bytes untouched
+            exp = [chunks[r][i] for i in range(want_rounds) for r in range(world) if i < len(chunks[r])]
+            exp = torch.cat(exp) if exp else torch.empty((0, 880), dtype=torch.uint8)
+            union = torch.cat([p[0] for p in parts])
+            if not torch.equal(union, exp):
+                bad.append((x, "bytes", tuple(union.shape), tuple(exp.shape)))
+            for part, _, _ in parts:                    # every part holds whole games only: it expands on its own
+                if part.shape[0]:
+                    t = part[:, 96:98].contiguous().view(torch.int16).view(-1)
+                    T = part[:, 98:100].contiguous().view(torch.int16).view(-1)
+                    if int(t[0]) != 0 or int(t[-1]) != int(T[-1]) - 1:
+                        bad.append((x, "cut game"))
+            total += int(union.shape[0])
+        q.put((rank, not bad, total if not bad else bad))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, False, traceback.format_exc()[-1500:]))
+
+
+def test_all_gather_of_compact_records_world2():
+    """The exchange format of round 3: 880-byte ply records, one collective per exchange while every rank's finished plies fit
+    the slot; further rounds are cut BETWEEN games. The gathered bytes are the ranks' records, untouched."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    # per exchange: game lengths per rank. Uneven, an empty rank, nobody, and a rank that needs three rounds (cap 16)
+    rounds = [((5, 3), (7,)), ((), (4, 4)), ((), ()), ((9, 6, 2, 11, 5), (16,))]
+    procs = [ctx.Process(target=_record_worker, args=(r, world, port, rounds, 16, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert [r[1] for r in res] == [True, True], res
+    assert res[0][2] == res[1][2] == sum(sum(l) for rr in rounds for l in rr)  # every rank holds the union
+
+
 def test_board_id_streams_independent_of_gpu_count():
     """RNG streams are keyed by the GLOBAL board id: rank r's board b uses id r*B+b (oracle twin of the device sampler)."""
     import oracle

@@ -40,12 +40,15 @@ def _env():
     return env
 
 
-def test_bench_two_ranks_exchange_inside_the_timed_window():
-    port = _free_port()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2",
-           "--backend", "gloo", "--share-gpu", "--gather-rows", "1024", "--playout", "16"] + SMALL
-    r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
+def test_bench_starts_its_own_ranks_and_exchanges_inside_the_timed_window():
+    """`python bench.py --gpus 2 ...` with NO launcher (the driver's N = 1 command shape with another N): bench.py starts its
+    own two ranks as a child `torch.distributed.run` before touching the GPU and relays rank 0's line and the exit code."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2",
+           "--backend", "gloo", "--share-gpu", "--gather-plies", "1024", "--playout", "16"] + SMALL
+    env = _env()
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     j = _json_line(r.stdout)
     assert j["n_gpus"] == 2 and j["steps"] == 12 and j["warmup"] == 2 and j["scaling"] == "weak" and j["unit"] == "sims/s"
@@ -55,12 +58,22 @@ def test_bench_two_ranks_exchange_inside_the_timed_window():
     assert m["exchanges_in_window"] == 1 and m["collectives_in_window"] == 1
     # boards 0, 12, 24, ... of each rank stand at the 12-ply cap: 22 games x 12 plies x 2 (mirror images) per rank at least
     assert m["rows_gathered"] >= 2 * 22 * 12 * 2 and j["move_boundary"]["games_finished"] >= 44
-    assert m["gather_ms"] > 0 and m["bytes_sent_per_rank_per_collective"] == 64 + 1024 * 29768
+    # the wire carries compact ply records: 880 B per ply (= two dense rows of 29,768 B), one fixed-size slot per rank
+    assert m["gather_ms"] > 0 and m["bytes_sent_per_rank_per_collective"] == 64 + 1024 * 880 and m["gather_capacity_plies"] == 1024
+    assert m["payload_bytes_rank0_per_exchange"] == 880 * j["move_boundary"]["rows_harvested_rank0"] // 2
+    assert m["bad_records"] == 0 and m["replay_rows_total"] == m["rows_gathered"]   # every rank's ring received the union
     assert len(m["per_rank_sims_per_sec"]) == 2 and all(v > 0 for v in m["per_rank_sims_per_sec"])
     # whole-job value = all ranks' simulations over the slowest rank's time: never above the sum of the per-rank rates
     assert 0 < j["value"] <= sum(m["per_rank_sims_per_sec"]) * 1.001
     assert j["move_boundary"]["in_window"] == 1 and j["move_boundary"]["ms_host"] > 0
     assert abs(j["ms_per_step"] * 12 * 1e-3 * j["value"] - 2 * 256 * 12) < 1e-3 * 2 * 256 * 12
+
+
+def test_bench_refuses_a_gpu_count_that_contradicts_the_launcher():
+    env = _env()
+    env.update({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stdout + r.stderr)
 
 
 def test_bench_two_ranks_with_concurrent_trainer_on_rank0():
@@ -69,7 +82,7 @@ def test_bench_two_ranks_with_concurrent_trainer_on_rank0():
     port = _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "16", "--warmup", "2",
-           "--backend", "gloo", "--share-gpu", "--gather-rows", "1024", "--playout", "16", "--train-every", "4"] + SMALL
+           "--backend", "gloo", "--share-gpu", "--gather-plies", "1024", "--playout", "16", "--train-every", "4"] + SMALL
     r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     j = _json_line(r.stdout)
@@ -111,15 +124,21 @@ os.environ.setdefault("MASTER_PORT", sys.argv[1])
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-from chinesechesszero_amd.replay import TupleGatherer
+from chinesechesszero_amd.replay import RecordGatherer, ReplayBuffer, TupleGatherer, exchange_finished_games
 from chinesechesszero_amd.selfplay import BatchedSelfPlay
+from chinesechesszero_amd.engine import expand_records
 from chinesechesszero_amd.net import uniform_evaluator
+def play(seed):
+    sp = BatchedSelfPlay(uniform_evaluator, 16, n_playout=3, seed=seed, max_plies=4)
+    for _ in range(5):
+        sp.run_move()
+    assert sp.engine.game_status()["over"].all()
+    return sp
+# dense rows through the fused buffer (round 2's wire format)
 g = TupleGatherer(96, dev, always_collective=True)
-sp = BatchedSelfPlay(uniform_evaluator, 16, n_playout=3, seed=1, max_plies=4)
-for _ in range(5):
-    sp.run_move()
-assert sp.engine.game_status()["over"].all()
+sp = play(1)
 rows = 0
+dense = []
 it = iter(sp.harvest_chunks(g.cap))
 chunk = next(it)
 while chunk is not None:
@@ -127,12 +146,26 @@ while chunk is not None:
     s, p, z = g.gather(*chunk, more=nxt is not None, user=16 if rows == 0 else 0)
     assert g.collectives == 1 and g.rows_per_rank == [int(chunk[2].shape[0])] and g.any_more == (nxt is not None)
     assert torch.equal(s, chunk[0]) and torch.equal(p, chunk[1]) and torch.equal(z, chunk[2])   # bytes survive the fused buffer
+    dense.append((s.clone(), p.clone(), z.clone()))
     rows += int(z.shape[0])
     chunk = nxt
 assert rows == 16 * 4 * 2, rows
 big = torch.rand((250, 2086), device=dev)
 S, P, Z = g.gather(torch.zeros((250, 17, 7, 10, 9), dtype=torch.float16, device=dev), big, torch.arange(250, device=dev).float())
 assert g.collectives == 3 and torch.equal(P, big) and torch.equal(Z, torch.arange(250, device=dev).float())   # 250 rows through 96-row rounds
+# the same games as COMPACT RECORDS through RCCL, 24 plies per round (whole games only), expanded into a replay ring:
+# byte for byte the dense rows above
+rg = RecordGatherer(24, dev, always_collective=True)
+sp2 = play(1)
+rb = ReplayBuffer(200, dev)
+n = colls = 0
+for union, games in exchange_finished_games(sp2, rg, 16):
+    assert union.shape[0] <= 24 and union.shape[0] % 4 == 0 and rg.collectives == 1
+    n += rb.append_records(union, sp2.engine.record_flags(), sp2.engine.plane_of_type)
+    colls += 1
+assert n == 128 and colls == 3 and rb.total == 128     # 64 plies in rounds of 24, 24, 16
+D = [torch.cat([d[i] for d in dense]) for i in range(3)]
+assert torch.equal(rb.states[:128], D[0]) and torch.equal(rb.pi[:128], D[1]) and torch.equal(rb.z[:128], D[2])
 t = torch.ones(1, dtype=torch.float64, device=dev)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
 dist.barrier()

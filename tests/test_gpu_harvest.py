@@ -170,3 +170,78 @@ def test_harvest_in_chunks_bounded_by_capacity():
     got = sum(s.shape[0] for s, _, _ in sp.harvest_chunks(max_rows=5))
     assert got == B * cap * 2
     sp.engine.check_healthy()
+
+
+def _play_out(B, seed, quirks, mirror, plane_of_type=None):
+    """Self-play with the stub evaluator until every board has finished at least one game; games end at different plies
+    (captures to bare kings, repetition, the 14-ply cap)."""
+    from chinesechesszero_amd.selfplay import BatchedSelfPlay
+    from chinesechesszero_amd.net import uniform_evaluator
+    sp = BatchedSelfPlay(uniform_evaluator, B, n_playout=4, seed=seed, max_plies=14, reference_quirks=quirks, mirror=mirror,
+                         plane_of_type=plane_of_type)
+    e = sp.engine
+    e.set_position(1, STARTS["capture_to_bare"], 1, 3)
+    e.set_position(2, STARTS["two_rooks"], 1, 0)
+    e.set_position(3, STARTS["rook_knight"], 0, 100)
+    for _ in range(16):
+        sp.run_move()
+    assert sp.engine.game_status()["over"].all()
+    return sp
+
+
+@pytest.mark.parametrize("quirks,mirror,pot", [(False, True, None), (True, True, None), (False, False, (0, 6, 5, 4, 3, 2, 1, 0))])
+def test_compact_records_expand_to_the_dense_harvest_byte_for_byte(quirks, mirror, pot):
+    """The multi-GPU wire format: ccz_harvest_records + ccz_expand_records == ccz_harvest, bit for bit, for the same games
+    (two engines with the same seed play the same games); headers agree with the game status."""
+    from chinesechesszero_amd.engine import expand_records, game_aligned_chunks
+    B = 12
+    a, b = _play_out(B, 21, quirks, mirror, pot), _play_out(B, 21, quirks, mirror, pot)
+    st = a.engine.game_status()
+    S, P, Z = a.engine.harvest()
+    recs = list(b.engine.harvest_record_chunks(40))          # several chunks, whole games each
+    assert len(recs) > 1 and all(r.shape[0] <= 40 or r.shape[0] == int(r[0, 98:100].view(torch.int16)) for r in recs)
+    rec = torch.cat(recs)
+    mul = 2 if mirror else 1
+    assert rec.shape == (int(st["plies"].sum()), 880) and S.shape[0] == mul * rec.shape[0]
+    hdr = rec[:, 96:112].cpu().numpy()
+    t = hdr[:, 0:2].copy().view(np.uint16).ravel()
+    T = hdr[:, 2:4].copy().view(np.uint16).ravel()
+    first = np.nonzero(t == 0)[0]
+    assert T[first].tolist() == st["plies"].tolist() and hdr[first, 4].view(np.int8).tolist() == st["winner"].tolist()
+    assert hdr[:, 8:12].copy().view(np.uint32).ravel()[first].tolist() == list(range(B))       # global board ids, board order
+    assert (rec[:, 90:96] == 0).all() and (hdr[:, 7] == 0).all()
+    flags = b.engine.record_flags()
+    # whole buffer at once, and chunk by chunk: the same rows
+    s1, p1, z1 = expand_records(rec, flags, pot)
+    assert torch.equal(s1, S) and torch.equal(p1, P) and torch.equal(z1, Z)
+    parts = [expand_records(c.contiguous(), flags, pot) for c in game_aligned_chunks(rec, 25)]
+    assert len(parts) > 2 and all(torch.equal(torch.cat([q[i] for q in parts]), (S, P, Z)[i]) for i in range(3))
+    st2 = b.engine.game_status()
+    assert st2["over"].sum() == 0 and st2["plies"].sum() == 0       # harvested boards restarted
+    a.engine.check_healthy()
+    b.engine.check_healthy()
+
+
+def test_records_expand_into_a_replay_ring_and_cut_games_are_refused():
+    from chinesechesszero_amd.engine import expand_records
+    from chinesechesszero_amd.replay import ReplayBuffer
+    a, b = _play_out(8, 4, False, True), _play_out(8, 4, False, True)
+    S, P, Z = a.engine.harvest()
+    rec = torch.cat(list(b.engine.harvest_record_chunks(1 << 16)))
+    R = S.shape[0]
+    rb = ReplayBuffer(R + 10, "cuda")          # the ring wraps: the rows land at (head + i) % capacity
+    rb.head = R - 3
+    bad = torch.zeros(1, dtype=torch.int32, device="cuda")
+    assert rb.append_records(rec, 0, None, bad=bad) == R and rb.head == (R - 3 + R) % (R + 10) and int(bad.item()) == 0
+    idx = (torch.arange(R, device="cuda") + (R - 3)) % (R + 10)
+    assert torch.equal(rb.states[idx], S) and torch.equal(rb.pi[idx], P) and torch.equal(rb.z[idx], Z)
+    small = ReplayBuffer(64, "cuda")           # smaller than one exchange: game by game, the newest rows survive
+    assert small.append_records(rec, 0) == R and small.total == R and small.size == 64
+    # a buffer that starts in the middle of a game: those records are skipped and counted, nothing is read out of bounds
+    T0 = int(rec[0, 98:100].view(torch.int16))
+    s, p, z = expand_records(rec[1:].contiguous(), 0, None, bad=bad)
+    torch.cuda.synchronize()
+    assert int(bad.item()) == T0 - 1
+    assert torch.equal(s[2 * (T0 - 1):], S[2 * T0:]) and torch.equal(z[2 * (T0 - 1):], Z[2 * T0:])
+    with pytest.raises(ValueError):
+        expand_records(rec.view(-1)[:-1], 0)

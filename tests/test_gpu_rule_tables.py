@@ -299,3 +299,118 @@ def test_pawn_move_clock_rule_is_switchable():
             tools.set_rules()
     assert results[False] == [False, True]     # 118 + 2 quiet plies: the sixty-move rule ends the game
     assert results[True] == [False, False, False]   # the pawn move restarted the clock
+
+
+def _perpetual_case(checker_is_red: bool):
+    """A rook that checks a bare king back and forth (a9+ Ke8, a8+ Ke9, ...): (squares, side to move, the 4-ply cycle)."""
+    from golden_cases import sq as S
+    pos = np.zeros(90, np.uint8)
+    if checker_is_red:
+        pos[S("d0")] = 7            # red king
+        pos[S("a8")] = 3            # red rook
+        pos[S("e9")] = 7 + 8        # black king
+        return pos, 1, ["a8a9", "e9e8", "a9a8", "e8e9"]
+    pos[S("d9")] = 7 + 8
+    pos[S("a1")] = 3 + 8            # black rook
+    pos[S("e0")] = 7
+    return pos, 0, ["a1a0", "e0e1", "a0a1", "e1e0"]
+
+
+@pytest.mark.parametrize("checker_is_red", [True, False])
+def test_perpetual_check_rule_decides_a_fourfold_repetition(checker_is_red):
+    """CCZ_RULE_PERPETUAL_CHECK: the side that checked with every move of a repetition cycle loses.
+    Engine (k_finish_move), oracle (xq_outcome_winner) and host Board flip together; without the flag the same game is a draw;
+    a repetition without checks stays a draw under the flag; the search below such a root is unchanged (leaf value 0.0)."""
+    import oracle
+    from gpu_harness import Lockstep
+    from golden_cases import sq as S
+    from oracle import OracleBoard
+    from chinesechesszero_amd import tools
+    from chinesechesszero_amd.game import Board
+    L = oracle.lib()
+    uid = lambda u: L.xq_move_id(S(u[:2]), S(u[2:]))
+    pos, turn, cycle = _perpetual_case(checker_is_red)
+    quiet = ["a8a7", "e9f9", "a7a8", "f9e9"] if checker_is_red else ["a1a2", "e0f0", "a2a1", "f0e0"]   # the rook shuffles, no check
+    results = {}
+    for flag, seq, name in ((True, cycle, "perpetual"), (False, cycle, "flag off"), (True, quiet, "no checks")):
+        try:
+            oracle.set_rules(perpetual_check=flag)
+            tools.set_rules(perpetual_check=flag)
+            e = _engine(1, 24, seed=3)          # picks the rule up from tools.set_rules
+            assert e.perpetual_check is flag
+            e.set_position(0, pos, turn, 0)
+            ob, hb = OracleBoard.from_array(pos, turn, 0), Board(pos, bool(turn), 0)
+            for ply in range(12):
+                if ply == 8:
+                    # two cycles played, the position has occurred three times: a search from here meets the fourth
+                    # occurrence as a LEAF -- value 0.0 with or without the flag (mcts.py:120-122 `end and is_tie`), visit
+                    # counts bit-exact with the oracle's sequential search
+                    ls = Lockstep(e, [ob], kind="hash_sharp", salts=[5])
+                    ls.run_fused(24, check_leaf=True)
+                    ls.compare_roots()
+                u = seq[ply % 4]
+                e.finish_move(forced_moves=np.array([uid(u)], np.int32), keep_tree=False)
+                ob.push(u)
+                hb.push(u)
+                st = e.game_status()
+                assert bool(st["over"][0]) == ob.is_game_over() == hb.is_game_over() == (ply == 11), (name, ply)
+            w = int(st["winner"][0])
+            o, h = ob.outcome(), hb.outcome()
+            ow = -1 if o.winner is None else int(o.winner)
+            hw = -1 if h.winner is None else int(h.winner)
+            assert w == ow == hw, (name, w, ow, hw)
+            assert h.termination == ("perpetual_check" if w >= 0 else "fourfold_repetition")
+            results[name] = w
+            # z of the harvested tuples follows the adjudicated winner (game.py:213-219)
+            _, _, z = e.harvest()
+            zz = z.cpu().numpy()[:12]
+            want = [0.0] * 12 if w < 0 else [1.0 if ((turn if t % 2 == 0 else 1 - turn) == w) else -1.0 for t in range(12)]
+            assert zz.tolist() == want, (name, zz.tolist())
+            e.check_healthy()
+        finally:
+            oracle.set_rules()
+            tools.set_rules()
+    loser_is_red = checker_is_red
+    assert results == {"perpetual": 0 if loser_is_red else 1, "flag off": -1, "no checks": -1}
+
+
+def test_rule_presets_install_tables_in_every_layer():
+    """tools.set_rules(preset=...): "canonical" and the unverified "python-chess-lineage" guess (planes P,R,N,B,A,K,C; piece-set
+    scan order with pawns last; perpetual check). The engine, the host Board and -- given the same tables -- the oracle agree
+    on move order and planes leaf by leaf under the preset."""
+    import oracle
+    from gpu_harness import Lockstep
+    from oracle import OracleBoard
+    from chinesechesszero_amd import tools
+    from chinesechesszero_amd.game import Board
+    try:
+        with pytest.raises(ValueError):
+            tools.set_rules(preset="no such preset")
+        tools.set_rules(preset="python-chess-lineage")
+        assert tools.PRESET == "python-chess-lineage" and tools.PERPETUAL_CHECK and tools.PLANE_OF_TYPE == (0, 0, 6, 1, 2, 3, 4, 5)
+        oracle.set_rules(**tools.current_rules())
+        e = _engine(2, 48, seed=2)
+        assert e.perpetual_check and e.plane_of_type == (0, 0, 6, 1, 2, 3, 4, 5)
+        ob = [OracleBoard(), OracleBoard()]
+        hb = Board()
+        ids = hb.legal_ids()
+        assert ids == ob[0].legal_ids() and len(ids) == 44
+        fr = [int(tools.MOVE_FROM[i]) for i in ids]
+        pawn = [(int(hb.squares()[f]) & 7) == 1 for f in fr]
+        assert pawn == sorted(pawn) and sum(pawn) == 5                          # the five pawn moves come last
+        nonp = [f for f, p in zip(fr, pawn) if not p]
+        assert nonp == sorted(nonp, reverse=True)                              # from-squares in descending scan order
+        red, black = tools.decode_board(hb)
+        assert red[0].sum() == 5 and red[6].sum() == 2 and red[1].sum() == 2 and red[5].sum() == 1   # P, C, R, K planes
+        ls = Lockstep(e, ob, kind="hash_sharp", salts=[1, 2])
+        ls.run_fused(48, check_leaf=True)                                      # leaf ids AND planes vs the oracle every step
+        ls.compare_roots()
+        e.check_healthy()
+        tools.set_rules(preset="canonical")
+        assert tools.PRESET == "canonical" and tools.MOVE_RANK is None and not tools.PERPETUAL_CHECK
+        assert Board().legal_ids() == sorted(Board().legal_ids())
+        tools.set_rules(preset="python-chess-lineage", perpetual_check=False, plane_of_type=(0, 0, 1, 2, 3, 4, 5, 6))
+        assert tools.PRESET == "custom" and tools.MOVE_RANK is not None
+    finally:
+        oracle.set_rules()
+        tools.set_rules()

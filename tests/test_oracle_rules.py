@@ -125,3 +125,31 @@ def test_leaf_planes_layout():
     assert red[6, 0, 4] == 1 and black[6, 9, 4] == 1 and red[0, 3, 0] == 1
     b.push("b0c2")
     assert np.all(b.leaf_planes()[16] == 0)
+
+
+def test_perpetual_check_rule_of_the_oracle():
+    """xq_set_perpetual_check (twin of CCZ_RULE_PERPETUAL_CHECK): in a fourfold repetition the side that
+    checked with every move of the cycle loses; off by default; a repetition without checks stays a draw; is_tie / is_game_over
+    (what the search consults, mcts.py:116-117) do not depend on the flag."""
+    import numpy as np
+
+    import oracle
+    from golden_cases import sq as S
+    from oracle import OracleBoard
+    pos = np.zeros(90, np.uint8)
+    pos[S("d0")], pos[S("a8")], pos[S("e9")] = 7, 3, 15
+    cycle, quiet = ["a8a9", "e9e8", "a9a8", "e8e9"], ["a8a7", "e9f9", "a7a8", "f9e9"]
+    got = {}
+    try:
+        for flag, seq, name in ((True, cycle, "perpetual"), (False, cycle, "off"), (True, quiet, "quiet")):
+            oracle.set_rules(perpetual_check=flag)
+            b = OracleBoard.from_array(pos, 1, 0)
+            for ply in range(12):
+                assert seq[ply % 4] in b.legal_moves
+                b.push(seq[ply % 4])
+                assert b.is_game_over() == b.is_tie() == (ply == 11)
+            assert b.is_fourfold_repetition()
+            got[name] = b.outcome().winner
+    finally:
+        oracle.set_rules()
+    assert got == {"perpetual": False, "off": None, "quiet": None}     # RED checked throughout: BLACK wins
