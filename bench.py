@@ -358,13 +358,14 @@ def main():
     if a.align_evaluator == "stub" and a.evaluator == "net":
         real, evaluator = evaluator, uniform_evaluator
         logits_in = False
-        run(phase, False)
-        if state["leaf"] is not None:   # the pending leaf of the stub phase is consumed through the dense entry point
+        run(max(phase - 1, 0), False)   # the pending leaf of the stub phase is consumed through the dense entry point, and that
+        if phase > 0:                   # IS simulation number `phase`: both evaluators start the timed window on the same index
+            if state["leaf"] is None:
+                state["leaf"] = e.select_leaves()
             e.expand_backup(*uniform_evaluator(state["leaf"]))
             state["leaf"] = None
             step_no[0] += 1
-            if step_no[0] % n == 0:
-                per_move(False)
+        assert step_no[0] == phase
         evaluator, logits_in = real, bool(getattr(real, "returns_logits", False))
     else:
         run(phase, False)

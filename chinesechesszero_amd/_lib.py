@@ -32,7 +32,8 @@ LEAF_EXPAND, LEAF_DRAW, LEAF_LOSS, LEAF_SKIP = 0, 1, 2, 3
 
 ERR_BITS = {1: "node pool exhausted (raise max_nodes)", 2: "selection path deeper than max_depth", 64: "history chain overflow (> 128 positions since the last capture)",
             4: "more than 128 legal moves or pseudo-move overflow", 8: "pi record arena overflow",
-            16: "forced move is not a child of the root / root not expanded", 32: "NaN priors"}
+            16: "forced move is not a child of the root / root not expanded", 32: "NaN priors",
+            128: "index out of bounds (bounds-checked diagnostic build)"}
 
 
 class CczError(RuntimeError):

@@ -37,8 +37,8 @@ class TupleSink:
     (``total_count, states_shape, states_dtype, mcts_shape, mcts_dtype, winners_shape, winners_dtype``; plus
     ``iters``, the game counter the reference keeps in ``data.h5`` attrs). ``mcts.npy`` is float64 by default, the
     dtype the reference stores (mcts.py:212 ``np.zeros(2086)`` kept as is by collect.py:157-160); ``pi_dtype=np.float32``
-    halves the file. Crash safety: shards are only deleted after ``meta.json`` is in place; a sink opened on a directory
-    that still holds shards adopts them, and ``finalize`` skips arrays that already have their merged length.
+    halves the file. One collector per directory (a pid lock file; a dead collector's lock is taken over and its shards
+    adopted). ``finalize`` is journaled: validated before the first write, idempotent after a crash at any point.
     """
 
     ARRAYS = {"states": ("_s.npy", np.float16, (17, 7, 10, 9)), "mcts": ("_p.npy", None, (2086,)), "winners": ("_z.npy", np.float32, ())}
@@ -50,23 +50,100 @@ class TupleSink:
         self._next = 0
         self.games = 0
         os.makedirs(out_dir, exist_ok=True)
-        self._merged_rows = 0
-        meta = os.path.join(out_dir, "meta.json")
-        if os.path.exists(meta):
-            with open(meta, encoding="utf-8") as f:
-                m = json.load(f)
-            self.games = int(m.get("iters", 0))
-            self._merged_rows = int(m.get("total_count", 0))
+        self._take_lock()
         state = os.path.join(out_dir, "collect_state.json")
         if os.path.exists(state):
             with open(state, encoding="utf-8") as f:
-                self.games = max(self.games, int(json.load(f).get("iters", 0)))
-        # shards a previous (crashed or still unmerged) collector left behind are part of the data set
+                self.games = int(json.load(f).get("iters", 0))
+        self._recover()  # a merge that a crash interrupted is completed from its journal before anything else is looked at
+        meta = os.path.join(out_dir, "meta.json")
+        m = {}
+        if os.path.exists(meta):
+            with open(meta, encoding="utf-8") as f:
+                m = json.load(f)
+            self.games = max(self.games, int(m.get("iters", 0)))
+        self._merged_rows = self._rows_on_disk(m.get("total_count"))
+        # shards a previous (crashed or still unmerged) collector left behind are part of the data set; a LIVE collector's
+        # directory is refused by the lock above
         for name in sorted(os.listdir(out_dir)):
             if name.startswith(".shard_") and name.endswith("_z.npy"):
                 base = os.path.join(out_dir, name[:-len("_z.npy")])
                 if all(os.path.exists(base + sfx) for sfx, _, _ in self.ARRAYS.values()):
                     self._shards.append((base, int(np.load(base + "_z.npy", mmap_mode="r").shape[0])))
+
+    # ---- one collector per directory ------------------------------------------------------------------
+    def _take_lock(self):
+        path = os.path.join(self.out_dir, ".collector.lock")
+        if os.path.exists(path):
+            try:
+                with open(path, encoding="utf-8") as f:
+                    pid = int(f.read().strip() or 0)
+            except (OSError, ValueError):
+                pid = 0
+            alive = False
+            if pid and pid != os.getpid():
+                try:
+                    os.kill(pid, 0)
+                    alive = True
+                except ProcessLookupError:
+                    alive = False
+                except PermissionError:
+                    alive = True
+            if alive:
+                raise RuntimeError(f"{self.out_dir} is in use by collector process {pid} (its shards would be adopted and deleted); "
+                                   "use another data_dir or stop that collector")
+        with open(path, "w", encoding="utf-8") as f:
+            f.write(str(os.getpid()))
+        self._lock = path
+
+    def close(self):
+        """Release the directory (shards that were not finalized stay on disk and are adopted by the next sink)."""
+        path = getattr(self, "_lock", None)
+        if path and os.path.exists(path):
+            try:
+                with open(path, encoding="utf-8") as f:
+                    mine = f.read().strip() == str(os.getpid())
+                if mine:
+                    os.remove(path)
+            except OSError:
+                pass
+        self._lock = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- what is on disk ------------------------------------------------------------------------------
+    def _journal(self) -> str:
+        return os.path.join(self.out_dir, "merge_journal.json")
+
+    def _paths(self) -> dict:
+        return {k: os.path.join(self.out_dir, k + ".npy") for k in self.ARRAYS}
+
+    def _rows_on_disk(self, meta_total=None) -> int:
+        """Rows of the merged arrays, taken from the FILES (all three must agree); ``meta_total`` (meta.json's
+        ``total_count``, if it has one) must agree with them too. A directory written by an older layout (no ``total_count``,
+        or no meta.json at all) is accepted on the evidence of its arrays."""
+        lens = {}
+        for k, path in self._paths().items():
+            if os.path.exists(path):
+                a = np.load(path, mmap_mode="r")
+                if a.dtype != self._dtype(k):
+                    raise ValueError(f"{path} holds {a.dtype}, this sink writes {self._dtype(k)}")
+                lens[k] = int(a.shape[0])
+                del a
+        if not lens:
+            if meta_total:
+                raise ValueError(f"{self.out_dir}: meta.json says {meta_total} rows but the arrays are missing")
+            return 0
+        if len(lens) != len(self.ARRAYS) or len(set(lens.values())) != 1:
+            raise ValueError(f"{self.out_dir}: the merged arrays disagree ({lens}); refusing to merge on top of them")
+        n = next(iter(lens.values()))
+        if meta_total is not None and int(meta_total) != n:
+            raise ValueError(f"{self.out_dir}: meta.json says {meta_total} rows, the arrays hold {n}")
+        return n
 
     def _dtype(self, key):
         return self.pi_dtype if key == "mcts" else np.dtype(self.ARRAYS[key][1])
@@ -96,35 +173,33 @@ class TupleSink:
         return int(sum(n for _, n in self._shards))
 
     def finalize(self) -> int:
-        """Merge what is on disk with the pending shards (the reference's converter step); returns the total row count."""
-        paths = {k: os.path.join(self.out_dir, k + ".npy") for k in self.ARRAYS}
-        n_old = self._merged_rows
+        """Merge what is on disk with the pending shards (the reference's converter step); returns the total row count.
+
+        Crash-safe and idempotent: (1) every array is validated (dtype, length) before anything is written; (2) a journal
+        naming ``n_old``, ``total`` and the shard files of THIS merge is written first and removed last, so a merge killed at
+        any point -- also between ``meta.json`` and the deletion of its shards -- is completed by the next sink exactly once
+        (:meth:`_recover`), never repeated; (3) ``meta.json`` changes after the arrays, the shards go after ``meta.json``."""
+        n_old = self._rows_on_disk()
+        if n_old != self._merged_rows:
+            raise ValueError(f"{self.out_dir}: the arrays hold {n_old} rows, this sink merged {self._merged_rows}: another writer?")
         total = n_old + self.rows()
         if total == 0:
             return 0
-        for k, (suffix, _, tail) in self.ARRAYS.items():
-            dtype = self._dtype(k)
-            have = os.path.exists(paths[k])
-            cur = np.load(paths[k], mmap_mode="r") if have else None
-            if have and cur.dtype != dtype:
-                raise ValueError(f"{paths[k]} holds {cur.dtype}, this sink writes {dtype}")
-            cur_n = int(cur.shape[0]) if have else 0
-            if cur_n == total:
-                continue  # merged by an interrupted finalize(): nothing to redo for this array
-            if cur_n < n_old:
-                raise ValueError(f"{paths[k]} has {cur_n} rows, meta.json says {n_old}")
-            tmp = paths[k] + ".tmp"
-            out = np.lib.format.open_memmap(tmp, mode="w+", dtype=dtype, shape=(total,) + tail)
-            if n_old:
-                out[:n_old] = cur[:n_old]
-            pos = n_old
-            del cur
-            for base, n in self._shards:
-                out[pos:pos + n] = np.load(base + suffix, mmap_mode="r")
-                pos += n
-            out.flush()
-            del out
-            os.replace(tmp, paths[k])
+        if not self._shards:
+            self._write_meta(total)
+            return total
+        journal = {"n_old": int(n_old), "total": int(total), "pi_dtype": str(self.pi_dtype),
+                   "shards": [[os.path.basename(b), int(n)] for b, n in self._shards]}
+        tmp = self._journal() + ".tmp"
+        with open(tmp, "w", encoding="utf-8") as f:
+            json.dump(journal, f)
+        os.replace(tmp, self._journal())
+        self._apply(journal)
+        self._shards = []
+        self._merged_rows = total
+        return total
+
+    def _write_meta(self, total: int):
         meta = {"total_count": int(total),
                 "states_shape": [int(total), 17, 7, 10, 9], "states_dtype": "float16",
                 "mcts_shape": [int(total), 2086], "mcts_dtype": str(self.pi_dtype),
@@ -134,12 +209,69 @@ class TupleSink:
         with open(tmp, "w", encoding="utf-8") as f:
             json.dump(meta, f, ensure_ascii=False, indent=2)  # convert.py:98-99
         os.replace(tmp, os.path.join(self.out_dir, "meta.json"))  # readers trust meta.json: it changes last
-        for base, _ in self._shards:
+
+    def _apply(self, journal: dict):
+        """Carry out (or complete) the merge a journal describes. Every step is skipped if already done."""
+        n_old, total = int(journal["n_old"]), int(journal["total"])
+        shards = [(os.path.join(self.out_dir, b), int(n)) for b, n in journal["shards"]]
+        paths = self._paths()
+        plan = {}
+        for k, (suffix, _, tail) in self.ARRAYS.items():   # validate EVERYTHING before the first byte is written
+            dtype = self._dtype(k)
+            cur_n = 0
+            if os.path.exists(paths[k]):
+                cur = np.load(paths[k], mmap_mode="r")
+                if cur.dtype != dtype:
+                    raise ValueError(f"{paths[k]} holds {cur.dtype}, this sink writes {dtype}")
+                cur_n = int(cur.shape[0])
+                del cur
+            if cur_n == total:
+                plan[k] = False      # merged before the interruption
+                continue
+            if cur_n != n_old:
+                raise ValueError(f"{paths[k]} has {cur_n} rows; the merge in progress expects {n_old} (before) or {total} (after)")
+            for base, n in shards:
+                if not os.path.exists(base + suffix):
+                    raise ValueError(f"{base + suffix} is missing but {paths[k]} still needs it")
+                a = np.load(base + suffix, mmap_mode="r")
+                if int(a.shape[0]) != n or a.dtype != dtype or tuple(a.shape[1:]) != tuple(tail):
+                    raise ValueError(f"{base + suffix}: {a.dtype}{a.shape}, expected {dtype}{(n,) + tuple(tail)}")
+                del a
+            plan[k] = True
+        for k, (suffix, _, tail) in self.ARRAYS.items():
+            if not plan[k]:
+                continue
+            tmp = paths[k] + ".tmp"
+            out = np.lib.format.open_memmap(tmp, mode="w+", dtype=self._dtype(k), shape=(total,) + tail)
+            if n_old:
+                cur = np.load(paths[k], mmap_mode="r")
+                out[:n_old] = cur[:n_old]
+                del cur
+            pos = n_old
+            for base, n in shards:
+                out[pos:pos + n] = np.load(base + suffix, mmap_mode="r")
+                pos += n
+            out.flush()
+            del out
+            os.replace(tmp, paths[k])
+        self._write_meta(total)
+        for base, _ in shards:
             for suffix, _, _ in self.ARRAYS.values():
-                os.remove(base + suffix)
-        self._shards = []
-        self._merged_rows = total
-        return total
+                if os.path.exists(base + suffix):
+                    os.remove(base + suffix)
+        os.remove(self._journal())
+
+    def _recover(self):
+        """A journal on disk = a merge that did not finish: complete it (its shards are then gone before they could be
+        adopted a second time)."""
+        if not os.path.exists(self._journal()):
+            return
+        with open(self._journal(), encoding="utf-8") as f:
+            journal = json.load(f)
+        if journal.get("pi_dtype", str(self.pi_dtype)) != str(self.pi_dtype):
+            raise ValueError(f"{self.out_dir}: an interrupted merge wrote mcts.npy as {journal['pi_dtype']}, this sink uses {self.pi_dtype}")
+        log(f"completing the interrupted merge of {len(journal['shards'])} shards in {self.out_dir}", "WARNING")
+        self._apply(journal)
 
     flush = finalize  # round-1 name
 

@@ -16,7 +16,7 @@
 #include "cczero_netops.h"
 #include "cczero_conv.h"
 #ifdef CCZ_CONV2 // experimental second form of the tower kernel: diagnostic / A-B builds only (make ab NAME=v2 ABFLAGS=-DCCZ_CONV2)
-#include "cczero_conv2.h"
+#include "../../profiles/experiments/cczero_conv2.h"
 #endif
 
 using namespace ccz;
@@ -603,9 +603,9 @@ int ccz_get_stats(ccz_engine *e, void *stream, ccz_stats *out)
     if (!out) return fail(-1, "ccz_get_stats: null output");
     hipStream_t s = (hipStream_t)stream;
     std::vector<BoardStats> st((size_t)e->d.B);
-    int32_t err = 0;
+    int32_t err[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(st.data(), e->d.stats, st.size() * sizeof(BoardStats), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&err, e->d.err, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(err, e->d.err, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     memset(out, 0, sizeof *out);
     for (const BoardStats &b : st) {
@@ -621,7 +621,8 @@ int ccz_get_stats(ccz_engine *e, void *stream, ccz_stats *out)
         if (b.nodes_peak > out->nodes_peak) out->nodes_peak = b.nodes_peak;
         if (b.depth_peak > out->depth_peak) out->depth_peak = b.depth_peak;
     }
-    out->error_flags = err;
+    out->error_flags = err[0];
+    out->reserved = err[1]; // bounds-checked diagnostic build: source line of the stray index (0 otherwise)
     out->hbm_bytes = (int64_t)e->bytes;
     return 0;
 }

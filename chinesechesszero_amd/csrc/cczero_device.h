@@ -120,6 +120,21 @@ __device__ __forceinline__ int type_in_plane(const Dev &D, int chan) { return (i
 
 #define CCZ_LEAF_SKIP 3
 
+// Bounds-checked diagnostic build (-DCCZ_BOUNDS: `make bounds` -> build/diag/libcczero_bounds.so, never shipped): every
+// index into the node pool, the selection path, the game record and the pi arena is range-checked; a stray index sets the
+// sticky error bit CCZ_ERR_BOUNDS, remembers its source line in err[1] and is redirected to element 0 (SURVEY section 5:
+// ROCm has no compute-sanitizer). The shipped build compiles the checks away.
+#ifdef CCZ_BOUNDS
+__device__ __forceinline__ long long ccz_checked(int32_t *err, long long i, long long n, int line)
+{
+    if (i < 0 || i >= n) { atomicOr(err, 128); atomicMax(err + 1, line); return 0; }
+    return i;
+}
+#define CCZ_IDX(D_, i_, n_) ccz_checked((D_).err, (long long)(i_), (long long)(n_), __LINE__)
+#else
+#define CCZ_IDX(D_, i_, n_) (i_)
+#endif
+
 // ------------------------------------------------------------------ small helpers
 constexpr uint64_t mix64(uint64_t z)
 {

@@ -265,8 +265,8 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
                         if (tp.kid_expanded) { c.fc = tp.n0; w = (w & 0xffffu) | ((uint32_t)tp.k << 16); }
                     }
                 } else {
-                    c = A[pa.fc + i];
-                    w = Bn[pa.fc + i];
+                    c = A[CCZ_IDX(D, pa.fc + i, D.cap)];
+                    w = Bn[CCZ_IDX(D, pa.fc + i, D.cap)];
                 }
                 // value + c_puct*prob*sqrt(N_parent)/(1+N): float32 product, float64 elsewhere; inf if unvisited
                 const double sc = c.N == 0 ? __builtin_huge_val()
@@ -293,7 +293,7 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
         if (lane == 0) sh.pm.mv[depth] = (uint16_t)mv;
         ++depth;
         if (depth >= D.maxd) { bad = true; set_err(D, 2); break; }
-        if (lane == 0) path[depth] = child;
+        if (lane == 0) path[CCZ_IDX(D, depth, D.maxd)] = child;
     }
     wave_sync();
     if (bad) {
@@ -345,7 +345,7 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
                 if (cp) dlt ^= zob(cp, to);
             }
             dlt = wave_incl_xor64(dlt) ^ carry;
-            if (j < depth && j >= first) s_chain[off + j] = dlt;
+            if (j < depth && j >= first) s_chain[CCZ_IDX(D, off + j, kChainCap)] = dlt;
             carry = wave_readlane64(dlt, 63);
         }
         key = carry;
@@ -454,12 +454,12 @@ __device__ inline TopPatch expand_backup_phase(const Dev &D, int b, int lane, co
         } else {
             const float *pr = prob + (size_t)b * kNMoves;
             if (lane < k) {
-                A[n0 + lane] = NodeA{0, 0.0f, COMPACT ? cp0 : pr[id0], -1};
-                Bn[n0 + lane] = (uint32_t)id0;
+                A[CCZ_IDX(D, n0 + lane, D.cap)] = NodeA{0, 0.0f, COMPACT ? cp0 : pr[COMPACT ? 0 : CCZ_IDX(D, id0, kNMoves)], -1};
+                Bn[CCZ_IDX(D, n0 + lane, D.cap)] = (uint32_t)id0;
             }
             if (64 + lane < k) {
-                A[n0 + 64 + lane] = NodeA{0, 0.0f, COMPACT ? cp1 : pr[id1], -1};
-                Bn[n0 + 64 + lane] = (uint32_t)id1;
+                A[CCZ_IDX(D, n0 + 64 + lane, D.cap)] = NodeA{0, 0.0f, COMPACT ? cp1 : pr[COMPACT ? 0 : CCZ_IDX(D, id1, kNMoves)], -1};
+                Bn[CCZ_IDX(D, n0 + 64 + lane, D.cap)] = (uint32_t)id1;
             }
             tp.root_expanded = d == 0;
             tp.kid_expanded = d == 1;
@@ -467,7 +467,7 @@ __device__ inline TopPatch expand_backup_phase(const Dev &D, int b, int lane, co
             tp.k = k;
             tp.first_id = __builtin_amdgcn_readlane(id0, 0);
             if (lane == 0) {
-                const int leaf0 = d < 64 ? leaf : path[d];
+                const int leaf0 = (int)CCZ_IDX(D, d < 64 ? leaf : path[CCZ_IDX(D, d, D.maxd)], D.cap);
                 A[leaf0].fc = n0;
                 Bn[leaf0] = (Bn[leaf0] & 0xffffu) | ((uint32_t)k << 16);
                 mp->n_nodes = n0 + k;
@@ -490,7 +490,7 @@ __device__ inline TopPatch expand_backup_phase(const Dev &D, int b, int lane, co
     int myN = 0;
     float myQ = 0.0f;
     for (int j = lane; j <= d; j += 64) {
-        const int node = j < 64 ? pj : path[j];
+        const int node = (int)CCZ_IDX(D, j < 64 ? pj : path[CCZ_IDX(D, j, D.maxd)], D.cap);
         const float val = ((d - j) & 1) ? v : -v;
         const int n = A[node].N + 1;
         const float q = A[node].Q;
@@ -683,8 +683,8 @@ __global__ __launch_bounds__(64) void k_finish_move(Dev D, const int32_t *forced
 
     load_board(s_sq, D.root_sq + (size_t)b * 96, lane);
     for (int i = lane; i < k; i += 64) {
-        s_vis[i] = A[root.fc + i].N;
-        s_act[i] = (uint16_t)(Bn[root.fc + i] & 0xffffu);
+        s_vis[i] = A[CCZ_IDX(D, root.fc + i, D.cap)].N;
+        s_act[i] = (uint16_t)(Bn[CCZ_IDX(D, root.fc + i, D.cap)] & 0xffffu);
     }
     __syncthreads();
 
@@ -702,11 +702,16 @@ __global__ __launch_bounds__(64) void k_finish_move(Dev D, const int32_t *forced
         return;
     }
     {
-        const size_t r = (size_t)b * D.max_plies + m.ply;
+        const size_t r = (size_t)b * D.max_plies + CCZ_IDX(D, m.ply, D.max_plies);
         if (lane < 24) ((uint32_t *)(D.rec_sq + r * 96))[lane] = ((const uint32_t *)s_sq)[lane];
         if (lane == 0) { D.rec_turn[r] = m.turn; D.rec_k[r] = (uint8_t)k; D.rec_off[r] = m.pi_used; }
         const size_t po = (size_t)b * D.pi_cap + m.pi_used;
-        for (int i = lane; i < k; i += 64) { D.rec_ids[po + i] = s_act[i]; D.rec_pi[po + i] = (float)s_pi[i]; }
+        for (int i = lane; i < k; i += 64) {
+            const size_t o = (size_t)b * D.pi_cap + CCZ_IDX(D, m.pi_used + (uint32_t)i, D.pi_cap);
+            D.rec_ids[o] = s_act[i];
+            D.rec_pi[o] = (float)s_pi[i];
+        }
+        (void)po;
     }
 
     // ---- move choice (mcts.py:216-229)
@@ -753,7 +758,7 @@ __global__ __launch_bounds__(64) void k_finish_move(Dev D, const int32_t *forced
     uint32_t *NB = D.nodeB + baseNew;
     int n_new = 1;
     if (keep_tree) {
-        if (lane == 0) { NA[0] = A[root.fc + ci]; NB[0] = Bn[root.fc + ci]; }
+        if (lane == 0) { NA[0] = A[CCZ_IDX(D, root.fc + ci, D.cap)]; NB[0] = Bn[CCZ_IDX(D, root.fc + ci, D.cap)]; }
         __syncthreads();
         int head = 0, pruned = 0;
         // The kept subtree may use the pool up to `budget`, leaving room for a whole move of new expansions.
@@ -767,7 +772,7 @@ __global__ __launch_bounds__(64) void k_finish_move(Dev D, const int32_t *forced
             const bool valid = i < n_new;
             NodeA rec = NodeA{0, 0.0f, 0.0f, -1};
             int nc = 0;
-            if (valid) { rec = NA[i]; nc = (int)(NB[i] >> 16); }
+            if (valid) { rec = NA[CCZ_IDX(D, i, D.cap)]; nc = (int)(NB[CCZ_IDX(D, i, D.cap)] >> 16); }
             const int incl = wave_incl_scan(nc, lane);
             const bool keep = nc > 0 && n_new + incl <= budget;   // a prefix of the lanes: incl is non-decreasing
             const bool drop = nc > 0 && !keep;
@@ -784,7 +789,10 @@ __global__ __launch_bounds__(64) void k_finish_move(Dev D, const int32_t *forced
                 const int L = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
                 const int src = s_src[L], dd = s_dst[L], cn = s_cnt[L];
-                for (int j = lane; j < cn; j += 64) { NA[dd + j] = A[src + j]; NB[dd + j] = Bn[src + j]; }
+                for (int j = lane; j < cn; j += 64) {
+                    NA[CCZ_IDX(D, dd + j, D.cap)] = A[CCZ_IDX(D, src + j, D.cap)];
+                    NB[CCZ_IDX(D, dd + j, D.cap)] = Bn[CCZ_IDX(D, src + j, D.cap)];
+                }
             }
             const int nbatch = n_new - head < 64 ? n_new - head : 64;
             head += nbatch;
@@ -811,7 +819,7 @@ __global__ __launch_bounds__(64) void k_finish_move(Dev D, const int32_t *forced
     int chain_len = zeroing ? 0 : m.chain_len;
     if (chain_len >= kChainCap) { chain_len = kChainCap - 1; set_err(D, 64); }
     for (int i = lane; i < chain_len; i += 64) s_chain[i] = D.chain[(size_t)b * kChainCap + i];
-    if (lane == 0) { s_chain[chain_len] = key; D.chain[(size_t)b * kChainCap + chain_len] = key; }
+    if (lane == 0) { s_chain[CCZ_IDX(D, chain_len, kChainCap)] = key; D.chain[(size_t)b * kChainCap + CCZ_IDX(D, chain_len, kChainCap)] = key; }
     ++chain_len;
     __syncthreads();
     if (lane < 24) ((uint32_t *)(D.root_sq + (size_t)b * 96))[lane] = ((const uint32_t *)s_sq)[lane];
@@ -910,7 +918,7 @@ __global__ __launch_bounds__(256) void k_harvest(Dev D, const long long *row_bas
                         const int ss = pass ? (s - s % 9) + (8 - s % 9) : s; // np.flip(axis=2): file mirror
                         int tp = te - (g & 7);
                         if (tp < 0) tp = 0;
-                        on = rsq[(size_t)tp * 96 + ss] == type_in_plane(D, ch) + (g >= 8 ? 8 : 0);
+                        on = rsq[(size_t)CCZ_IDX(D, tp, D.max_plies) * 96 + CCZ_IDX(D, ss, 90)] == type_in_plane(D, ch) + (g >= 8 ? 8 : 0);
                     }
                     if (on) v |= (uint32_t)kHalfOne << (16 * h);
                 }
@@ -922,7 +930,7 @@ __global__ __launch_bounds__(256) void k_harvest(Dev D, const long long *row_bas
             const int k = D.rec_k[r];
             const size_t po = (size_t)b * D.pi_cap + D.rec_off[r];
             for (int i = tid; i < k; i += 256) {
-                const int id = D.rec_ids[po + i];
+                const int id = (int)CCZ_IDX(D, D.rec_ids[(size_t)b * D.pi_cap + CCZ_IDX(D, D.rec_off[r] + (uint32_t)i, D.pi_cap)], kNMoves);
                 prow[pass ? c_tab.flip[id] : id] = D.rec_pi[po + i]; // mcts_prob[flip_map]
             }
             if (tid == 0) // game.py:213-219

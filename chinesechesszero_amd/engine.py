@@ -231,13 +231,15 @@ class SelfPlayEngine:
         s = Stats()
         check(self.L.ccz_get_stats(self.h, self._stream(), C.byref(s)))
         d = {f: getattr(s, f) for f, _ in Stats._fields_ if f != "reserved"}
+        if s.reserved:
+            d["bounds_line"] = int(s.reserved)  # bounds-checked diagnostic build: where cczero_kernels.h indexed out of range
         return d
 
     def check_healthy(self):
         e = self.stats()["error_flags"]
         if e:
             msgs = [m for bit, m in _lib.ERR_BITS.items() if e & bit]
-            raise CczError(f"engine error flags {e}: " + "; ".join(msgs))
+            raise CczError(f"engine error flags {e}: " + "; ".join(msgs) + (f" (cczero_kernels.h:{self.stats()['bounds_line']})" if e & 128 else ""))
 
     # ------------------------------------------------------------------ training tuples
     def harvest_chunks(self, max_rows: int = 1 << 19):

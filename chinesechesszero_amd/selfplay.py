@@ -23,17 +23,29 @@ class GraphedStep:
     allocator warm-up therefore run eagerly on a side stream first.
     """
 
-    def __init__(self, engine: SelfPlayEngine, evaluator, warmup: int = 3):
+    def __init__(self, engine: SelfPlayEngine, evaluator, warmup: int = 3, version_fn=None):
+        """``version_fn() -> hashable``: what tells this object that the evaluator's weights changed (a re-capture follows).
+        Default: the ``weights_version`` of the object the evaluator is a bound method of (``PolicyValueNet``). An evaluator
+        wrapped in a lambda / partial / closure has no such owner: pass ``version_fn`` (e.g. ``lambda: pvn.weights_version``),
+        otherwise the captured graph can never notice a weight change -- that case is logged once."""
         self.engine = engine
         self.evaluator = evaluator
         self.warmup = warmup
         self.captures = 0
+        self.version_fn = version_fn
+        if version_fn is None and not hasattr(getattr(evaluator, "__self__", None), "weights_version") \
+                and not getattr(evaluator, "stateless", False) and getattr(evaluator, "__name__", "") != "uniform_evaluator":
+            from .tools import log
+            log("GraphedStep: the evaluator exposes no weights_version and no version_fn was given: the captured hipGraph will "
+                "keep replaying the weights it was captured with (pass version_fn=... if they can change)", "WARNING")
         self._capture()
 
     def _weights_version(self):
         """The captured graph holds the device addresses of the evaluator's inference weights. ``PolicyValueNet`` bumps
         ``weights_version`` whenever that copy is rebuilt or invalidated (training step, hot reload): a replay against
         the old addresses would silently search with stale or freed weights."""
+        if self.version_fn is not None:
+            return self.version_fn()
         owner = getattr(self.evaluator, "__self__", None)
         return getattr(owner, "weights_version", None)
 

@@ -130,7 +130,7 @@ typedef struct ccz_stats {
     int64_t expansions;      /* leaves expanded                                                  */
     int64_t terminal_leaves; /* terminal leaves backed up                                        */
     int32_t error_flags;     /* sticky device error bits (CCZ_ERR_*), 0 = healthy                */
-    int32_t reserved;
+    int32_t reserved;        /* -DCCZ_BOUNDS diagnostic build: source line of the last stray index; 0 otherwise */
     int64_t hbm_bytes;       /* device memory held by the engine                                 */
     int64_t pruned_subtrees; /* nodes whose children were dropped at re-root time to keep the kept
                                 subtree within the pool budget (0 in normal runs)                 */
@@ -143,6 +143,7 @@ typedef struct ccz_stats {
 #define CCZ_ERR_RECORD 8      /* pi record arena overflow (game adjudicated)                     */
 #define CCZ_ERR_BAD_MOVE 16   /* forced move id invalid / nothing searched and nothing forced    */
 #define CCZ_ERR_NAN 32        /* NaN priors: no comparable child during selection                */
+#define CCZ_ERR_BOUNDS 128    /* bounds-checked diagnostic build only (-DCCZ_BOUNDS): an index left its array      */
 
 /* ---- library ---------------------------------------------------------------------------- */
 int ccz_abi_version(void);

@@ -21,6 +21,9 @@ def _ensure_built():
 
 def pytest_configure(config):
     _ensure_built()
+    if os.environ.get("CCZ_LIB"):  # run the suite against a diagnostic build (build/diag/libcczero_bounds.so: `make bounds`)
+        from chinesechesszero_amd import _lib
+        _lib.LIB_PATH = os.path.join(ROOT, "build", "diag", os.environ["CCZ_LIB"])
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long-running CPU check")
 

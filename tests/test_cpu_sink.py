@@ -75,7 +75,7 @@ def test_interrupted_finalize_is_repaired(tmp_path):
 
     def dying_replace(src, dst):
         calls["n"] += 1
-        if calls["n"] == 2:
+        if calls["n"] == 3:   # 1 = the merge journal, 2 = states.npy, 3 = mcts.npy
             raise KeyboardInterrupt("killed between two replacements")
         return real_replace(src, dst)
 
@@ -87,10 +87,94 @@ def test_interrupted_finalize_is_repaired(tmp_path):
         os.replace = real_replace
     assert json.load(open(tmp_path / "meta.json"))["total_count"] == 10            # still describes the valid prefix
     assert np.load(tmp_path / "states.npy", mmap_mode="r").shape[0] == 30 and np.load(tmp_path / "mcts.npy", mmap_mode="r").shape[0] == 10
-    b = TupleSink(str(tmp_path))
-    assert b.rows() == 20 and b.finalize() == 30
+    a.close()
+    b = TupleSink(str(tmp_path))       # opening the directory completes the journaled merge
+    assert b.rows() == 0 and b.finalize() == 30
     assert np.array_equal(np.load(tmp_path / "states.npy"), s) and np.array_equal(np.load(tmp_path / "mcts.npy"), p)
     assert np.array_equal(np.load(tmp_path / "winners.npy"), z)
+    assert json.load(open(tmp_path / "meta.json"))["total_count"] == 30 and not os.path.exists(tmp_path / "merge_journal.json")
+    assert not [f for f in os.listdir(tmp_path) if f.startswith(".shard_")]
+
+
+def test_crash_between_meta_and_shard_deletion_does_not_duplicate_rows(tmp_path):
+    """meta.json already carries the new total, the shards are still on disk. The journal names them as merged:
+    the next sink deletes them instead of adopting them, so nothing is appended twice."""
+    from chinesechesszero_amd.collect import TupleSink
+    s, p, z = _rows(24, 5)
+    a = TupleSink(str(tmp_path))
+    a.append(s[:8], p[:8], z[:8])
+    a.finalize()
+    a.append(s[8:], p[8:], z[8:])
+    real_remove = os.remove
+
+    def dying_remove(path):
+        if ".shard_" in str(path):
+            raise KeyboardInterrupt("killed before the first shard was deleted")
+        return real_remove(path)
+
+    os.remove = dying_remove
+    try:
+        with pytest.raises(KeyboardInterrupt):
+            a.finalize()
+    finally:
+        os.remove = real_remove
+    assert json.load(open(tmp_path / "meta.json"))["total_count"] == 24 and [f for f in os.listdir(tmp_path) if f.startswith(".shard_")]
+    a.close()
+    b = TupleSink(str(tmp_path))
+    assert b.rows() == 0 and not [f for f in os.listdir(tmp_path) if f.startswith(".shard_")]
+    b.append(s[:4], p[:4], z[:4])
+    assert b.finalize() == 28
+    assert np.array_equal(np.load(tmp_path / "winners.npy"), np.concatenate([z, z[:4]]))
+
+
+def test_row_count_comes_from_the_files_and_everything_is_validated_before_writing(tmp_path):
+    from chinesechesszero_amd.collect import TupleSink
+    s, p, z = _rows(12, 6)
+    a = TupleSink(str(tmp_path))
+    a.append(s[:6], p[:6], z[:6])
+    a.finalize()
+    a.close()
+    # a directory whose meta.json lacks total_count (round 1 wrote "total_samples"): the arrays are the evidence, nothing is lost
+    json.dump({"total_samples": 6, "iters": 1}, open(tmp_path / "meta.json", "w"))
+    b = TupleSink(str(tmp_path))
+    b.append(s[6:], p[6:], z[6:])
+    assert b.finalize() == 12 and np.array_equal(np.load(tmp_path / "states.npy"), s)
+    b.close()
+    # meta.json and the arrays disagree: refuse at open
+    m = json.load(open(tmp_path / "meta.json"))
+    m["total_count"] = 7
+    json.dump(m, open(tmp_path / "meta.json", "w"))
+    with pytest.raises(ValueError, match="meta.json says 7"):
+        TupleSink(str(tmp_path))
+    m["total_count"] = 12
+    json.dump(m, open(tmp_path / "meta.json", "w"))
+    # a shard of the wrong dtype: finalize() raises BEFORE any array is replaced (states.npy keeps its 12 rows)
+    c = TupleSink(str(tmp_path))
+    c.append(s[:3], p[:3], z[:3])
+    base = c._shards[-1][0]
+    np.save(base + "_p.npy", p[:3].astype(np.float32))
+    with pytest.raises(ValueError, match="float32"):
+        c.finalize()
+    assert np.load(tmp_path / "states.npy", mmap_mode="r").shape[0] == 12 and np.load(tmp_path / "winners.npy", mmap_mode="r").shape[0] == 12
+    c.close()
+
+
+def test_a_live_collector_owns_its_directory(tmp_path):
+    import subprocess
+    import sys as _sys
+    from chinesechesszero_amd.collect import TupleSink
+    other = subprocess.Popen([_sys.executable, "-c", "import time; time.sleep(60)"])
+    try:
+        open(tmp_path / ".collector.lock", "w").write(str(other.pid))
+        with pytest.raises(RuntimeError, match="in use by collector process"):
+            TupleSink(str(tmp_path))
+    finally:
+        other.kill()
+        other.wait()
+    a = TupleSink(str(tmp_path))       # the other collector is dead: its lock is taken over
+    assert open(tmp_path / ".collector.lock").read() == str(os.getpid())
+    a.close()
+    assert not os.path.exists(tmp_path / ".collector.lock")
 
 
 def test_float32_option_and_dtype_guard(tmp_path):
@@ -100,10 +184,9 @@ def test_float32_option_and_dtype_guard(tmp_path):
     a.append(s, p, z)
     a.finalize()
     assert np.load(tmp_path / "mcts.npy").dtype == np.float32 and json.load(open(tmp_path / "meta.json"))["mcts_dtype"] == "float32"
-    b = TupleSink(str(tmp_path))   # float64 sink on a float32 data set: refuse, do not silently convert
-    b.append(s, p, z)
-    with pytest.raises(ValueError, match="float32"):
-        b.finalize()
+    a.close()
+    with pytest.raises(ValueError, match="float32"):   # float64 sink on a float32 data set: refuse, do not silently convert
+        TupleSink(str(tmp_path))
 
 
 @pytest.mark.skipif(not os.path.exists("/root/reference/dataset.py"), reason="the reference tree is only mounted in the build container")

@@ -414,3 +414,38 @@ def test_rule_presets_install_tables_in_every_layer():
     finally:
         oracle.set_rules()
         tools.set_rules()
+
+
+@pytest.mark.parametrize("with_move_rank", [False, True])
+def test_random_eight_class_type_rank_on_positions_with_more_than_64_legal_moves(with_move_rank):
+    """the stable partition by the mover's piece type (two ballots per class) on lists longer than one wave --
+    the second-half path (entries 64..127) and several classes at once -- against the oracle's comparison sort."""
+    import oracle
+    from golden_cases import STARTS
+    from oracle import OracleBoard
+    rs = np.random.RandomState(77 + int(with_move_rank))
+    positions = [(STARTS["wide80"], 1, 0), (STARTS["wide80"], 0, 0), (None, 1, 0)]
+    for trial in range(4):
+        type_rank = [0] + rs.randint(0, 8, size=7).tolist()            # up to 8 classes, ties between types included
+        rank = rs.permutation(2086).astype(np.uint16) if with_move_rank else None
+        try:
+            oracle.set_rules(move_rank=rank, type_rank=type_rank)
+            e = _engine(len(positions), 8, seed=trial, move_rank=rank, type_rank=type_rank)
+            boards = []
+            for b, (sq, turn, half) in enumerate(positions):
+                ob = OracleBoard() if sq is None else OracleBoard.from_array(sq, turn, half)
+                if sq is not None:
+                    e.set_position(b, sq, turn, half)
+                boards.append(ob)
+            e.select_leaves()
+            info = e.leaf_info()
+            ks = []
+            for b, ob in enumerate(boards):
+                want = ob.legal_ids()
+                k = int(info["k"][b])
+                ks.append(k)
+                assert info["ids"][b][:k].tolist() == want, (trial, b, type_rank)
+            assert max(ks) > 64
+            e.check_healthy()
+        finally:
+            oracle.set_rules()
