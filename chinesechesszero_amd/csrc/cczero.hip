@@ -15,6 +15,7 @@
 #include "cczero_kernels.h"
 #include "cczero_netops.h"
 #include "cczero_conv.h"
+#include "cczero_conv3.h"
 #ifdef CCZ_CONV2 // experimental second form of the tower kernel: diagnostic / A-B builds only (make ab NAME=v2 ABFLAGS=-DCCZ_CONV2)
 #include "../../profiles/experiments/cczero_conv2.h"
 #endif
@@ -689,6 +690,16 @@ static int conv3x3_launch(const char *who, void *stream, const void *x_dev, cons
         return 0;
     }
 #endif
+    if (relu & 8) { // bit 3: the form without a barrier per half-step (cczero_conv3.h)
+        if (residual_dev)
+            hipLaunchKernelGGL(k_conv3x3_v3<true>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev,
+                               (const float *)bias_f32_dev, (const _Float16 *)residual_dev, (_Float16 *)y_dev, (int)n_pixels, (int)(relu & 3), cin);
+        else
+            hipLaunchKernelGGL(k_conv3x3_v3<false>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev,
+                               (const float *)bias_f32_dev, (const _Float16 *)nullptr, (_Float16 *)y_dev, (int)n_pixels, (int)(relu & 3), cin);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
 #ifndef CCZ_STAMPS
     relu &= 3; // bit 0: ReLU, bit 1: descending tile order; the diagnostic build passes ablation switches in bits 8.. (profiles/conv_microbench.py)
 #endif

@@ -153,15 +153,16 @@ def test_reset_tree_keeps_position_history_and_record():
     e.check_healthy()
 
 
-def test_rule_flag_stub_and_error_bits():
+def test_rule_flags_are_validated_and_error_bits():
     from chinesechesszero_amd import _lib
     from chinesechesszero_amd._lib import CczError
     L = _lib.lib()
     cfg = _lib.Config(n_boards=2, n_playout=4, c_puct=5, eps=0.25, alpha=0.2, temp=1.0, rule_flags=_lib.RULE_PERPETUAL_CHECK)
     h = C.c_void_p()
-    assert L.ccz_create(C.byref(cfg), C.byref(h)) == -6 and b"not implemented" in L.ccz_last_error()
+    assert L.ccz_create(C.byref(cfg), C.byref(h)) == 0      # round 2 refused the flag (-6, "not implemented"); it is a rule now
+    assert L.ccz_destroy(h) == 0
     cfg.rule_flags = 8
-    assert L.ccz_create(C.byref(cfg), C.byref(h)) == -1
+    assert L.ccz_create(C.byref(cfg), C.byref(h)) == -1 and b"unknown rule_flags" in L.ccz_last_error()
     # the two overflow kinds report separate bits (round 1 shared bit 2)
     assert _lib.ERR_BITS[2] != _lib.ERR_BITS[64] and "chain" in _lib.ERR_BITS[64] and "depth" in _lib.ERR_BITS[2]
 
