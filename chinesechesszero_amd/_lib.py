@@ -86,6 +86,7 @@ PROTOTYPES = {
     "ccz_game_status": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "ccz_root_positions": (C.c_int, [_P, _P, _P]),
     "ccz_leaf_info": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "ccz_leaf_keys": (C.c_int, [_P, _P, _P, _P]),
     "ccz_harvest_rows": (C.c_int, [_P, _P, C.POINTER(C.c_int64)]),
     "ccz_harvest": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "ccz_harvest_records": (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),

@@ -15,7 +15,9 @@
 #include "cczero_kernels.h"
 #include "cczero_netops.h"
 #include "cczero_conv.h"
-#include "cczero_conv3.h"
+#ifdef CCZ_CONV3 // round 3's form without a barrier per half-step: measured slower, A-B builds only (make ab NAME=v3 ABFLAGS=-DCCZ_CONV3)
+#include "../../profiles/experiments/cczero_conv3.h"
+#endif
 #ifdef CCZ_CONV2 // experimental second form of the tower kernel: diagnostic / A-B builds only (make ab NAME=v2 ABFLAGS=-DCCZ_CONV2)
 #include "../../profiles/experiments/cczero_conv2.h"
 #endif
@@ -197,6 +199,7 @@ int ccz_create(const ccz_config *cfg, ccz_engine **out)
     ALLOC(d.leaf_ids, B * kMaxLegal);
     ALLOC(d.leaf_k, B);
     ALLOC(d.leaf_status, B);
+    ALLOC(d.leaf_key, B);
     ALLOC(d.rec_sq, B * d.max_plies * 96);
     ALLOC(d.rec_turn, B * d.max_plies);
     ALLOC(d.rec_k, B * d.max_plies);
@@ -468,6 +471,15 @@ int ccz_leaf_info(ccz_engine *e, void *stream, uint8_t *status_host, int32_t *k_
     return 0;
 }
 
+int ccz_leaf_keys(ccz_engine *e, void *stream, uint64_t *keys_dev, uint8_t *status_dev)
+{
+    NEED(e);
+    hipStream_t s = (hipStream_t)stream;
+    if (keys_dev) HIP_TRY(hipMemcpyAsync(keys_dev, e->d.leaf_key, (size_t)e->d.B * 8, hipMemcpyDeviceToDevice, s));
+    if (status_dev) HIP_TRY(hipMemcpyAsync(status_dev, e->d.leaf_status, (size_t)e->d.B, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
 int ccz_harvest_rows(ccz_engine *e, void *stream, int64_t *rows_host)
 {
     NEED(e);
@@ -690,7 +702,8 @@ static int conv3x3_launch(const char *who, void *stream, const void *x_dev, cons
         return 0;
     }
 #endif
-    if (relu & 8) { // bit 3: the form without a barrier per half-step (cczero_conv3.h)
+#ifdef CCZ_CONV3
+    if (relu & 8) { // bit 3: the form without a barrier per half-step (profiles/experiments/cczero_conv3.h)
         if (residual_dev)
             hipLaunchKernelGGL(k_conv3x3_v3<true>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev,
                                (const float *)bias_f32_dev, (const _Float16 *)residual_dev, (_Float16 *)y_dev, (int)n_pixels, (int)(relu & 3), cin);
@@ -700,6 +713,7 @@ static int conv3x3_launch(const char *who, void *stream, const void *x_dev, cons
         HIP_TRY(hipGetLastError());
         return 0;
     }
+#endif
 #ifndef CCZ_STAMPS
     relu &= 3; // bit 0: ReLU, bit 1: descending tile order; the diagnostic build passes ablation switches in bits 8.. (profiles/conv_microbench.py)
 #endif

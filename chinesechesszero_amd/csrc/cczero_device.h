@@ -70,6 +70,7 @@ struct Dev {
     uint16_t *leaf_ids;   // [B][128]
     int32_t *leaf_k;      // [B]
     uint8_t *leaf_status; // [B]
+    uint64_t *leaf_key;   // [B] Zobrist key (pieces + side to move) of the pending leaf: what the evaluator input depends on
     uint8_t *rec_sq;   // [B][max_plies][96] root position before each move
     uint8_t *rec_turn; // [B][max_plies]
     uint8_t *rec_k;    // [B][max_plies]

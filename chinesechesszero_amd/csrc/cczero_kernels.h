@@ -369,6 +369,7 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
     CCZ_STAMP(D, b, lane, 6)
     if (lane == 0) {
         D.path_len[b] = depth;
+        D.leaf_key[b] = key;
         D.leaf_k[b] = L.n_legal > kMaxLegal ? kMaxLegal : L.n_legal;
         D.leaf_status[b] = (uint8_t)L.status;
         BoardStats &st = D.stats[b];

@@ -227,6 +227,14 @@ class SelfPlayEngine:
         check(self.L.ccz_leaf_info(self.h, self._stream(), _ptr(status), _ptr(k), _ptr(ids), _ptr(depth)))
         return {"status": status, "k": k, "ids": ids, "depth": depth}
 
+    def leaf_keys(self):
+        """(keys int64 [B], status uint8 [B]) of the pending leaves as device tensors (no sync): equal keys = equal evaluator
+        input (position + side to move)."""
+        keys = torch.empty((self.B,), dtype=torch.int64, device=self.device)
+        status = torch.empty((self.B,), dtype=torch.uint8, device=self.device)
+        check(self.L.ccz_leaf_keys(self.h, self._stream(), _ptr(keys), _ptr(status)))
+        return keys, status
+
     def stats(self) -> dict:
         s = Stats()
         check(self.L.ccz_get_stats(self.h, self._stream(), C.byref(s)))

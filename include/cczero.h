@@ -240,6 +240,12 @@ int ccz_root_positions(ccz_engine *e, void *stream, uint8_t *sq_host);
 int ccz_leaf_info(ccz_engine *e, void *stream, uint8_t *status_host, int32_t *k_host,
                   uint16_t *ids_host, int32_t *depth_host);
 
+/* Zobrist keys (pieces + side to move: everything the evaluator input of net.py:160-173 depends on) and CCZ_LEAF_* status of
+ * the pending leaves, copied device-to-device on `stream` (no sync): keys_dev uint64 [B], status_dev uint8 [B], either may be
+ * NULL. Equal keys = equal evaluator input: what a transposition / duplicate-leaf cache would key on (the reference
+ * evaluates every leaf separately, mcts.py:114). */
+int ccz_leaf_keys(ccz_engine *e, void *stream, uint64_t *keys_dev, uint8_t *status_dev);
+
 /* ---- training tuples ---------------------------------------------------------------------- */
 /* number of tuple rows the finished games would produce (syncs). */
 int ccz_harvest_rows(ccz_engine *e, void *stream, int64_t *rows_host);

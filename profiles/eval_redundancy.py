@@ -1,0 +1,151 @@
+"""How many leaf evaluations of the lockstep search are REDUNDANT?
+
+The evaluator input on the search path depends on the leaf POSITION and the side to move only (history planes are zero:
+reference net.py:160-173, mcts.py:214), i.e. on the leaf's Zobrist key, which k_step already holds (ccz_leaf_keys). The
+reference evaluates every leaf separately (mcts.py:114). Two kinds of repeats could be served from a cache instead of the
+40 x 256 tower:
+  (i)  duplicates inside ONE lockstep step: two boards of the batch select leaves with the same key;
+  (ii) transpositions inside ONE board: a key this board has evaluated before, in the current move or in the moves whose
+       subtree it kept (window = the last two moves' evaluations).
+Measured at steady state of the bench workload (boards spread over plies 1..P by bench.py's pre-roll), for the random-init
+40 x 256 net (the benchmark's evaluator) and for a sharp synthetic evaluator (deep, narrow trees: what a trained net does).
+
+    python profiles/eval_redundancy.py [--boards 4096] [--playout 400] [--moves 2] > profiles/r03_eval_redundancy.json
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+class SharpLinear:
+    """softmax / tanh of a fixed random projection of the live planes (tests/test_gpu_soak.py LinearEvaluator), scaled so that
+    a few moves hold most of the prior mass: depth without a trained net."""
+    batched = True
+
+    def __init__(self, device, seed=0, sharp=9.0):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        self.W = (torch.randn(1890, 2086, generator=g) * sharp / 5.6).to(device)
+        self.w = (torch.randn(1890, generator=g) * 0.7).to(device)
+
+    def __call__(self, leaf):
+        B = leaf.shape[0]
+        x = leaf.view(B, 17, 630)
+        x = torch.cat([x[:, 7], x[:, 15], x[:, 16]], dim=1).float()
+        return torch.softmax(x @ self.W, dim=1).contiguous(), torch.tanh(x @ self.w).contiguous()
+
+
+def measure(name, evaluator, a, dev):
+    from bench import preroll
+    from chinesechesszero_amd.selfplay import BatchedSelfPlay
+    B, n = a.boards, a.playout
+    sp = BatchedSelfPlay(evaluator, B, n_playout=n, seed=0, device=0, sampling="device", max_plies=a.max_plies)
+    e = sp.engine
+    preroll(e, a.preroll_plies, stagger=True)
+    logits = bool(getattr(evaluator, "returns_logits", False))
+    W = 2 * n                                              # per-board window: the evaluations of the last two moves
+    hist = torch.zeros((B, W), dtype=torch.int64, device=dev)
+    hist_valid = torch.zeros((B, W), dtype=torch.bool, device=dev)
+    head = 0
+    tot = {"leaves": 0, "expand": 0, "dup_in_step": 0, "seen_in_board": 0, "either": 0, "terminal": 0}
+    per_move = []
+    t0 = time.time()
+    for move in range(a.warm_moves + a.moves):
+        counted = move >= a.warm_moves
+        m = {k: 0 for k in tot}
+        leaf = e.select_leaves()
+        acc = torch.zeros(6, dtype=torch.int64, device=dev)
+        for i in range(n):
+            keys, status = e.leaf_keys()
+            exp = status == 0                              # CCZ_LEAF_EXPAND: the leaves whose evaluation is used
+            live = status != 3
+            # (i) duplicates inside the step, among the leaves that need the net: all but the first of every key
+            k_exp = keys[exp]
+            uniq = torch.unique(k_exp)
+            dup = k_exp.numel() - uniq.numel()
+            # (ii) seen before by the same board
+            seen = ((hist == keys[:, None]) & hist_valid).any(dim=1) & exp
+            # either: a cache keyed by (board-local history) OR deduplicated within the step -- count rows not needing the tower
+            first_of_key = torch.zeros_like(exp)
+            if k_exp.numel():
+                order = torch.argsort(keys.masked_fill(~exp, torch.iinfo(torch.int64).max), stable=True)
+                sk = keys[order]
+                se = exp[order]
+                is_first = torch.ones_like(se)
+                is_first[1:] = sk[1:] != sk[:-1]
+                first_of_key[order] = is_first & se
+            either = exp & (seen | ~first_of_key)
+            acc += torch.stack([live.sum(), exp.sum(), torch.as_tensor(dup, device=dev), seen.sum(), either.sum(), (live & ~exp).sum()])
+            hist[:, head] = keys
+            hist_valid[:, head] = exp
+            head = (head + 1) % W
+            prob, value = evaluator(leaf)
+            if i + 1 < n:
+                leaf = e.step_logits(prob, value) if logits else e.step(prob, value)
+            else:
+                (e.expand_backup_logits if logits else e.expand_backup)(prob, value)
+        vals = acc.tolist()
+        for k, v in zip(("leaves", "expand", "dup_in_step", "seen_in_board", "either", "terminal"), vals):
+            m[k] = int(v)
+            if counted:
+                tot[k] += int(v)
+        sp.finish_move()
+        st = e.game_status()
+        over = torch.as_tensor(st["over"].astype(bool), device=dev)
+        if bool(over.any()):
+            for _ in e.harvest_chunks(1 << 16):
+                pass
+            hist_valid[over] = False                       # a new game: nothing of the old one is in the new tree
+        per_move.append({"move": move, "counted": counted, **m})
+        print(f"[{name}] move {move}: {m}", file=sys.stderr, flush=True)
+    s = e.stats()
+    e.check_healthy()
+    ex = max(1, tot["expand"])
+    return {"evaluator": name, "boards": B, "sims_per_move": n, "moves_counted": a.moves, "warm_moves": a.warm_moves,
+            "leaves": tot["leaves"], "leaves_needing_the_net": tot["expand"], "terminal_leaves": tot["terminal"],
+            "dup_in_step": tot["dup_in_step"], "seen_before_in_same_board": tot["seen_in_board"], "either": tot["either"],
+            "rate_dup_in_step": tot["dup_in_step"] / ex, "rate_seen_before_in_same_board": tot["seen_in_board"] / ex,
+            "rate_combined": tot["either"] / ex, "rate_terminal_of_all_leaves": tot["terminal"] / max(1, tot["leaves"]),
+            "d_bar": s["sum_depth"] / max(1, s["sims"]), "depth_peak": s["depth_peak"], "seconds": time.time() - t0,
+            "per_move": per_move}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--boards", type=int, default=4096)
+    ap.add_argument("--playout", type=int, default=400)
+    ap.add_argument("--moves", type=int, default=2)
+    ap.add_argument("--warm-moves", type=int, default=1, help="moves searched before counting (fills the two-move window and the kept subtrees)")
+    ap.add_argument("--preroll-plies", type=int, default=200)
+    ap.add_argument("--max-plies", type=int, default=200)
+    ap.add_argument("--blocks", type=int, default=40)
+    ap.add_argument("--which", default="net,sharp")
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    out = {"what": __doc__.split("\n\n")[0], "results": []}
+    for which in a.which.split(","):
+        if which == "net":
+            from chinesechesszero_amd.net import PolicyValueNet
+            torch.manual_seed(0)
+            pvn = PolicyValueNet(device=dev, num_channels=256, resblocks_num=a.blocks)
+            pvn.refresh_inference_copy()
+            out["results"].append(measure(f"random-init {a.blocks}x256 net fp16 (the benchmark's evaluator)", pvn.evaluate_leaves_logits, a, dev))
+            del pvn
+        else:
+            out["results"].append(measure("sharp synthetic evaluator (softmax of a random projection x 9)", SharpLinear(dev, sharp=9.0), a, dev))
+        torch.cuda.empty_cache()
+    best = max(r["rate_combined"] for r in out["results"])
+    out["verdict"] = (f"combined redundancy {best:.1%} at most: " + ("a per-board key -> (priors, v) cache with compaction of the miss rows pays"
+                      if best >= 0.05 else "below the 5 % bar: a cache would add a hash probe and a compaction pass per step for less than it saves"))
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -18,8 +18,16 @@
 //     nobody still reads the buffer the next staging pieces overwrite (half-step 2): 8 per tile instead of 72.
 //   * epilogue: the whole 256 x 256 output block is transposed through LDS (the slabs are dead by then), so that the
 //     residual is read and the output written as whole 512-byte pixel rows.
+//
+// RESULT (profiles/r03_conv_v3.json, 4096 boards, one layer in isolation, interleaved on one device): bit-identical output
+// (same summation order per accumulator), but 393-407 us against 355-361 us for k_conv3x3_c256. Ablations of this kernel:
+// neither operand (MFMA + slab DMA + epilogue only) 297-301 us; without the pixel-fragment reads 341; without the validity
+// selects (16 v_cndmask per half-step + 32 v_and / v_cmp per tap) 377; without the weight loads 366; weight loads that always
+// hit L1 389. The costs add up: the loop is ISSUE-bound, not latency-bound (a deeper fragment window, 6 or 8 instead of 4,
+// gains 3 %), and a 32 x 256 block per wave needs 18 operand instructions per 32 MFMAs where the 128 x 64 block of
+// k_conv3x3_c256 needs 14-15 plus one barrier. The barrier is cheaper than the instructions that replace it. Not shipped.
 #pragma once
-#include "cczero_conv.h"
+#include "../../chinesechesszero_amd/csrc/cczero_conv.h"
 
 namespace ccz {
 
@@ -28,8 +36,13 @@ constexpr int kC3ZeroOff = 2 * kCvABytes;
 constexpr int kC3ERow = 528;                              // epilogue: bytes per pixel row (512 + pad)
 constexpr int kC3Lds = 256 * kC3ERow;                     // 135,168 B (the K loop needs 2 x 36,864 + 15 x 2,048 + 128)
 static_assert(kC3ZeroOff + 15 * 2048 + 128 <= kC3Lds, "zero rows must fit");
-constexpr int kC3Look = 4;                                // pixel fragments requested ahead of the MFMAs that use them
-constexpr int kC3Win = 6;                                 // register slots of the rolling window (288 fragments per chunk = 48 x 6)
+#ifndef C3_LOOK
+#define C3_LOOK 4
+#define C3_WIN 6
+#endif
+constexpr int kC3Look = C3_LOOK;                          // pixel fragments requested ahead of the MFMAs that use them
+constexpr int kC3Win = C3_WIN;                            // register slots of the rolling window; must divide 288 (fragments per chunk)
+static_assert(288 % kC3Win == 0 && kC3Look < kC3Win && kC3Look <= 8, "window geometry");
 
 struct C3Ctx {
     unsigned char *lds;
@@ -62,22 +75,32 @@ template <int TAP> __device__ __forceinline__ C3Tap c3_tap(const C3Ctx &c, int a
     C3Tap t;
     t.base = abase + row * 128;
     t.sw16 = ((row & 7) ^ c.q4) << 4;
+#ifndef C3_ABL_NOMASK
 #pragma unroll
     for (int n = 0; n < 16; ++n) t.ok[n] = (tw & (1u << (n + 16 * (TAP & 1)))) != 0u;
+#endif
     return t;
 }
 
 // pixel fragment of tile N, k-half KH: a tap that leaves the board reads a zero row
 template <int KH, int N> __device__ __forceinline__ cv_half8 c3_read_x(const C3Ctx &c, const C3Tap &t)
 {
+#ifdef C3_ABL_NOMASK
+    const int off = t.base + (t.sw16 ^ (KH << 6));
+#else
     const int off = t.ok[N] ? t.base + (t.sw16 ^ (KH << 6)) : kC3ZeroOff;
+#endif
     return *(const cv_half8 *)(c.lds + off + N * 2048);
 }
 
 // weight fragments of half-step U2 of chunk `chunk2`: two 16-row tiles, straight from global memory
 template <int U2> __device__ __forceinline__ void c3_load_w(const C3Ctx &c, int chunk2, cv_half8 (&a)[2])
 {
+#ifdef C3_ABL_WSAME
+    const _Float16 *s = c.wa + (chunk2 & 0); // every load hits the same (L1-resident) lines: the issue cost alone
+#else
     const _Float16 *s = c.wa + (U2 >> 1) * c.cin + chunk2 * 64 + (U2 & 1) * 32;
+#endif
     a[0] = *(const cv_half8 *)s;
     a[1] = *(const cv_half8 *)(s + 16l * (9 * c.cin));
 }
@@ -89,7 +112,7 @@ template <int U>
 __device__ __forceinline__ void c3_halfstep(const C3Ctx &c, cv_f32x4 (&acc)[2][16], int chunk, C3Tap &tap, const cv_half8 (&acur)[2],
                                              cv_half8 (&aload)[2], cv_half8 (&bw)[kC3Win])
 {
-    constexpr int KH = U & 1, TAP = U >> 1;
+    constexpr int KH = U & 1;
     constexpr int Un = (U + 1) % 18, KHn = Un & 1, TAPn = Un >> 1;
     unsigned char *const lds = c.lds;
 
@@ -106,10 +129,12 @@ __device__ __forceinline__ void c3_halfstep(const C3Ctx &c, cv_f32x4 (&acc)[2][1
         const int nxt = (chunk + 1) & c.cmask; // past the last chunk: re-stage chunk 0 into the free buffer (harmless, keeps the code static)
         cv_glds16(c.X + (c.xsrc[pass] + nxt * 64), lds + kC3Slab + ((chunk + 1) & 1) * kCvABytes + (pass < 4 ? pass * 64 : 224) * 128 + c.wave_dst);
     }
+#ifndef C3_ABL_NOW
     {
         constexpr int U2 = (U + 2) % 18;
         c3_load_w<U2>(c, (chunk + (U + 2 >= 18 ? 1 : 0)) & c.cmask, aload);
     }
+#endif
     if constexpr (U == 17) {
         // chunk boundary: every wave's slab pieces of the next chunk must have landed before anybody reads them. The
         // pieces are older than the four youngest loads (the weights of the next two half-steps).
@@ -118,23 +143,27 @@ __device__ __forceinline__ void c3_halfstep(const C3Ctx &c, cv_f32x4 (&acc)[2][1
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     }
-    // tile N: request the fragment kC3Look tiles ahead (the last kC3Look requests belong to the next half-step), then the two
-    // MFMAs of this tile
-#define C3_TILE(N, TP, KHX)                                                                                               \
+    // tile N: request the fragment kC3Look tiles ahead (the last kC3Look requests belong to the next half-step: from there on
+    // `tap` is the next tap's -- the current tap's flags are dead by then and the new ones take their registers), then the
+    // two MFMAs of this tile
+#ifdef C3_ABL_NOX
+#define C3_READ(N, KHX)
+#else
+#define C3_READ(N, KHX) bw[slot_rd] = c3_read_x<KHX, (N + kC3Look) % 16>(c, tap);
+#endif
+#define C3_TILE(N)                                                                                                        \
     {                                                                                                                     \
         constexpr int slot = (U * 16 + N) % kC3Win, slot_rd = (U * 16 + N + kC3Look) % kC3Win;                            \
-        bw[slot_rd] = c3_read_x<KHX, (N + kC3Look) % 16>(c, TP);                                                          \
+        if constexpr (N == 16 - kC3Look && KH == 1) tap = c3_tap<TAPn>(c, kC3Slab + ((chunk + (U == 17 ? 1 : 0)) & 1) * kCvABytes); \
+        if constexpr (N + kC3Look < 16) { C3_READ(N, KH) } else { C3_READ(N, KHn) }                                       \
         acc[0][N] = __builtin_amdgcn_mfma_f32_16x16x32_f16(acur[0], bw[slot], acc[0][N], 0, 0, 0);                        \
         acc[1][N] = __builtin_amdgcn_mfma_f32_16x16x32_f16(acur[1], bw[slot], acc[1][N], 0, 0, 0);                        \
         __builtin_amdgcn_sched_barrier(0); /* keep the window: left alone, the scheduler requests each fragment just */  \
     }                                      /* one tile ahead of its MFMAs (lowest register pressure) */
-    C3_TILE(0, tap, KH) C3_TILE(1, tap, KH) C3_TILE(2, tap, KH) C3_TILE(3, tap, KH) C3_TILE(4, tap, KH) C3_TILE(5, tap, KH)
-    C3_TILE(6, tap, KH) C3_TILE(7, tap, KH) C3_TILE(8, tap, KH) C3_TILE(9, tap, KH) C3_TILE(10, tap, KH) C3_TILE(11, tap, KH)
-    // the current tap's flags are dead from here on: the next tap's (every second half-step) take their registers
-    if constexpr (KH == 1) tap = c3_tap<TAPn>(c, kC3Slab + ((chunk + (U == 17 ? 1 : 0)) & 1) * kCvABytes);
-    C3_TILE(12, tap, KHn) C3_TILE(13, tap, KHn) C3_TILE(14, tap, KHn) C3_TILE(15, tap, KHn)
+    C3_TILE(0) C3_TILE(1) C3_TILE(2) C3_TILE(3) C3_TILE(4) C3_TILE(5) C3_TILE(6) C3_TILE(7)
+    C3_TILE(8) C3_TILE(9) C3_TILE(10) C3_TILE(11) C3_TILE(12) C3_TILE(13) C3_TILE(14) C3_TILE(15)
 #undef C3_TILE
-    static_assert(kC3Look == 4, "tiles 12..15 request the next half-step's fragments");
+#undef C3_READ
 }
 
 
@@ -210,10 +239,20 @@ __global__ __launch_bounds__(512) void k_conv3x3_v3(const _Float16 *__restrict__
     cv_half8 bw[kC3Win];
     C3Tap tap = c3_tap<0>(c, kC3Slab);
     bw[0] = c3_read_x<0, 0>(c, tap);
-    bw[1] = c3_read_x<0, 1>(c, tap);
-    bw[2] = c3_read_x<0, 2>(c, tap);
-    bw[3] = c3_read_x<0, 3>(c, tap);
-    static_assert(kC3Look == 4, "the prologue requests the first kC3Look fragments");
+    if constexpr (kC3Look > 1) bw[1] = c3_read_x<0, 1>(c, tap);
+    if constexpr (kC3Look > 2) bw[2] = c3_read_x<0, 2>(c, tap);
+    if constexpr (kC3Look > 3) bw[3] = c3_read_x<0, 3>(c, tap);
+    if constexpr (kC3Look > 4) bw[4] = c3_read_x<0, 4>(c, tap);
+    if constexpr (kC3Look > 5) bw[5] = c3_read_x<0, 5>(c, tap);
+    if constexpr (kC3Look > 6) bw[6] = c3_read_x<0, 6>(c, tap);
+    if constexpr (kC3Look > 7) bw[7] = c3_read_x<0, 7>(c, tap);
+#ifdef C3_ABL_NOX
+#pragma unroll
+    for (int i = 0; i < kC3Win; ++i) bw[i] = c3_read_x<0, 0>(c, tap);
+#endif
+#ifdef C3_ABL_NOW
+    c3_load_w<2>(c, 0, a2);
+#endif
     for (int chunk = 0; chunk <= c.cmask; ++chunk) {
 #define C3_H(u, cur, ld) c3_halfstep<u>(c, acc, chunk, tap, cur, ld, bw)
         C3_H(0, a0, a2); C3_H(1, a1, a0); C3_H(2, a2, a1); C3_H(3, a0, a2); C3_H(4, a1, a0); C3_H(5, a2, a1);
