@@ -276,6 +276,45 @@ class TupleSink:
     flush = finalize  # round-1 name
 
 
+def write_games_hdf5(records: torch.Tensor, h5_path: str, flags: int = 0, plane_of_type=None, h5py_module=None) -> int:
+    """The reference's OWN on-disk layout (collect.py:146-167): one group ``game_{i}`` per game in ``data.h5`` with datasets
+    ``states`` (fp16 [2T,17,7,10,9], gzip), ``mcts_probs`` (float64 [2T,2086], gzip), ``winners`` (float64 [2T]) -- the T samples
+    of the game followed by their T mirror images (``play_data + data_flip``, collect.py:131) -- and the file attribute ``iters``
+    counting the games. Input: compact ply records (``harvest_record_chunks`` / ``RecordGatherer``: they carry the game
+    boundaries the dense rows have lost); the rows are rebuilt on the GPU by ``ccz_expand_records``.
+
+    ``h5py`` is not part of this image, so the collector's default sink stays ``TupleSink`` (the converter's .npy
+    output, which is what the trainer reads); with h5py installed this function makes the GPU collector a drop-in producer for
+    the reference's ``convert.py`` as well. ``h5py_module``: the module to use (tests pass a recording stand-in). Returns the
+    new value of ``iters``."""
+    if h5py_module is None:
+        try:
+            import h5py as h5py_module
+        except ImportError as e:
+            raise ImportError("write_games_hdf5 needs h5py (not installed in this image); TupleSink writes the converter's .npy "
+                              "files instead") from e
+    from .engine import expand_records, game_aligned_chunks, rows_of_records
+    mul = rows_of_records(1, flags)
+    with h5py_module.File(h5_path, "a") as h5f:
+        it = int(h5f.attrs.get("iters", 0))
+        for part in game_aligned_chunks(records, 1 << 13):
+            part = part.contiguous()
+            states, pi, z = (t.cpu().numpy() for t in expand_records(part, flags, plane_of_type))
+            hdr = part[:, 96:100].cpu().numpy().view(np.uint16).reshape(-1, 2)   # (t, T) of every record
+            p = 0
+            while p < hdr.shape[0]:
+                T = int(hdr[p, 1])
+                lo, hi = mul * p, mul * (p + T)
+                g = h5f.create_group(f"game_{it}")
+                g.create_dataset("states", data=states[lo:hi], compression="gzip")
+                g.create_dataset("mcts_probs", data=pi[lo:hi].astype(np.float64), compression="gzip")
+                g.create_dataset("winners", data=z[lo:hi].astype(np.float64))
+                it += 1
+                h5f.attrs["iters"] = it
+                p += T
+    return it
+
+
 class CollectPipeline:
     def __init__(self, init_model=None, n_boards: int = 1, n_playout: int = PLAYOUT, device: int = 0, seed: int = 0,
                  data_dir: str = DATA_DIR, reference_quirks: bool = False, num_channels: int = 256, resblocks_num: int = 40,

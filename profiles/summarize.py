@@ -38,11 +38,21 @@ def main():
                     summary.setdefault(k, {})["avg_ns"] = float(r.get("AverageNs", 0) or 0)
                     summary[k]["calls"] = int(float(r.get("Calls", 0) or 0))
                     summary[k]["pct"] = float(r.get("Percentage", 0) or 0)
+    def bench_line(name):
+        p = os.path.join(out_dir, name)
+        if not os.path.exists(p):
+            return None
+        try:
+            return json.loads([l for l in open(p).read().splitlines() if l.startswith("{")][-1])
+        except Exception:
+            return None
+
     for kind, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         cc = find(os.path.join(out_dir, kind), "*counter_collection.csv")
         if not cc:
             continue
         acc = defaultdict(lambda: [0.0, 0])
+        kstep = []   # (dispatch id, value) of every k_step launch of the pass, to cut out the timed window below
         for r in csv.DictReader(open(cc)):
             if r.get("Counter_Name") != counter:
                 continue
@@ -51,10 +61,27 @@ def main():
                 if k in name:
                     acc[k][0] += float(r.get("Counter_Value", 0) or 0)
                     acc[k][1] += 1
+                    if k == "k_step":
+                        kstep.append((int(float(r.get("Dispatch_Id", 0) or 0)), float(r.get("Counter_Value", 0) or 0)))
         for k, (tot, n) in acc.items():
             if n:
                 summary.setdefault(k, {})[counter + "_raw_per_launch"] = tot / n
                 summary[k][counter + "_launches"] = n
+        # the k_step launches of the pass's TIMED WINDOW are its last (steps - move boundaries) ones: nothing launches k_step
+        # after the window. Their counters and the pass's own k-bar / d-bar / algorithmic bytes describe the same trees.
+        bl = bench_line(kind + "_bench.json")
+        if bl and kstep:
+            n_win = int(bl["steps"]) - int(bl["move_boundary"]["in_window"])
+            vals = [v for _, v in sorted(kstep, key=lambda t: t[0])][-n_win:]   # stable: file order if there is no dispatch id
+            w = summary.setdefault("k_step", {}).setdefault("window", {})
+            w[counter + "_raw_per_launch"] = sum(vals) / len(vals)
+            w["launches"] = len(vals)
+            rf = bl["roofline"]
+            shape = {"k_bar": rf["k_bar"], "d_bar": rf["d_bar"], "algorithmic_bytes_per_launch": rf["algorithmic_bytes_per_launch"]}
+            if "k_bar" in w and (abs(w["k_bar"] - shape["k_bar"]) > 1e-9 or abs(w["d_bar"] - shape["d_bar"]) > 1e-9):
+                w["warning"] = f"the fetch and write passes saw different trees: {shape} vs k_bar {w['k_bar']} d_bar {w['d_bar']}"
+            w.update(shape)
+            w["bench_args"] = f"--steps {bl['steps']} --warmup {bl['warmup']} (window: {bl['config']['window']})"
     cc = find(os.path.join(out_dir, "pmc_sq"), "*counter_collection.csv")
     if cc:  # SQ counters per launch (quad-cycle units for the *_CYCLES / WAIT / ACTIVE counters, MI355X_MICROARCH.md)
         acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
@@ -80,6 +107,15 @@ def main():
             # rocprofv3 FETCH_SIZE / WRITE_SIZE are in kilobytes; gfx950: double the fetch side
             d["hbm_bytes_per_launch"] = (2.0 * f + w) * 1024.0
             d["hbm_bytes_per_launch_uncorrected"] = (f + w) * 1024.0
+        win = d.get("window")
+        if win and "FETCH_SIZE_raw_per_launch" in win and "WRITE_SIZE_raw_per_launch" in win:
+            win["hbm_bytes_per_launch"] = (2.0 * win["FETCH_SIZE_raw_per_launch"] + win["WRITE_SIZE_raw_per_launch"]) * 1024.0
+            win["hbm_bytes_per_launch_uncorrected"] = (win["FETCH_SIZE_raw_per_launch"] + win["WRITE_SIZE_raw_per_launch"]) * 1024.0
+            win["traffic_over_algorithmic"] = win["hbm_bytes_per_launch"] / win["algorithmic_bytes_per_launch"]
+            win["traffic_over_algorithmic_uncorrected"] = win["hbm_bytes_per_launch_uncorrected"] / win["algorithmic_bytes_per_launch"]
+            win["note"] = ("counters and algorithmic bytes of the SAME launches: the timed window of the PMC passes (real-net alignment). "
+                           "fetch x2 = the gfx950 correction for wide coalesced reads (MI355X_MICROARCH.md, HBM); k_step's reads are mostly "
+                           "16-B records and scattered 4-B words, so the truth lies between the two ratios")
     for name in ("trace_bench.json", "pmc_fetch_bench.json", "pmc_write_bench.json", "pmc_sq_bench.json"):
         p = os.path.join(out_dir, name)
         if os.path.exists(p):
@@ -91,6 +127,10 @@ def main():
     with open(os.path.join(root, f"{tag}_summary.json"), "w") as f:
         json.dump(summary, f, indent=1)
     pm = {k: v for k, v in summary.items() if not k.startswith("_")}
+    tb = summary.get("_bench", {}).get("trace_bench.json")
+    if tb:  # bench.py replays these figures only for the workload they were measured on
+        pm["workload"] = {"boards_per_gpu": tb["config"]["boards_per_gpu"], "sims_per_move": tb["config"]["sims_per_move"],
+                          "evaluator": tb["config"]["evaluator"], "max_plies": tb["config"]["max_plies"]}
     pm["run"] = f"profiles/run_profile.sh {tag}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes of bench.py --steps 24"
     with open(os.path.join(root, "pmc_summary.json"), "w") as f:
         json.dump(pm, f, indent=1)

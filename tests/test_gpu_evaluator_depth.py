@@ -115,3 +115,36 @@ def test_shapes_off_the_fused_path_are_logged(caplog):
         inf(x)
     msgs = [r.getMessage() for r in caplog.records if "fused" in r.getMessage()]
     assert len(msgs) == 1 and "64" in msgs[0]
+
+
+def test_a_boards_evaluation_does_not_depend_on_its_slot_in_the_batch():
+    """The WHOLE evaluator (pack + stem + 80 tower convolutions + heads GEMM + FC layers), 40 x 256 at 4096 rows: the same
+    position placed in different rows of the batch -- first and last row of a pixel tile, either side of the 2048-board group
+    and of the 1024-board chain boundaries, the last row -- and among different neighbours gets bit-identical logits and value.
+    (What "results do not depend on which rank / slot a game runs in" rests on, at equal batch size.)"""
+    from chinesechesszero_amd.net import PolicyValueNet
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(7)
+    pvn = PolicyValueNet(device=dev)
+    pvn.refresh_inference_copy()
+    B = 4096
+    x = _leaf_batch(B, 24, seed=11)
+    probe = x[777].clone()
+    slots = [0, 1, 2, 255, 256, 1023, 1024, 2047, 2048, 3071, 3072, 4094, 4095]
+    xa = x.clone()
+    xa[slots] = probe
+    la, va = pvn.evaluate_leaves_logits(xa)
+    la, va = la.clone(), va.clone()
+    for s in slots[1:]:
+        assert torch.equal(la[s], la[slots[0]]) and torch.equal(va[s], va[slots[0]]), s
+    # other neighbours (the batch reversed around the probe rows): the probe's numbers do not move
+    xb = x.flip(0).contiguous()
+    xb[slots] = probe
+    lb, vb = pvn.evaluate_leaves_logits(xb)
+    for s in slots:
+        assert torch.equal(lb[s], la[slots[0]]) and torch.equal(vb[s], va[slots[0]]), s
+    # and every untouched row of the reversed batch equals its mirror row of the first batch
+    keep = torch.ones(B, dtype=torch.bool, device=dev)
+    keep[slots] = False
+    keep &= keep.flip(0)
+    assert torch.equal(lb[keep], la.flip(0)[keep]) and torch.equal(vb[keep], va.flip(0)[keep])

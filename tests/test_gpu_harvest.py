@@ -245,3 +245,58 @@ def test_records_expand_into_a_replay_ring_and_cut_games_are_refused():
     assert torch.equal(s[2 * (T0 - 1):], S[2 * T0:]) and torch.equal(z[2 * (T0 - 1):], Z[2 * T0:])
     with pytest.raises(ValueError):
         expand_records(rec.view(-1)[:-1], 0)
+
+
+class _FakeH5:
+    """A recording stand-in for the h5py calls of reference collect.py:146-167 (File(path, "a") as context manager, attrs,
+    create_group, create_dataset): h5py itself is not in this image."""
+    files = {}
+
+    class _Group(dict):
+        def create_dataset(self, name, data=None, compression=None):
+            self[name] = (np.asarray(data), compression)
+
+    class File:
+        def __init__(self, path, mode):
+            assert mode == "a"
+            self.store = _FakeH5.files.setdefault(path, {"attrs": {}, "groups": {}})
+            self.attrs = self.store["attrs"]
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def create_group(self, name):
+            assert name not in self.store["groups"]
+            g = _FakeH5._Group()
+            self.store["groups"][name] = g
+            return g
+
+
+def test_per_game_hdf5_groups_in_the_references_layout():
+    """collect.py:146-167: group game_{i} per game, states / mcts_probs (gzip) / winners, attrs["iters"]; rows = the dense
+    harvest, game by game (samples then mirror images)."""
+    from chinesechesszero_amd.collect import write_games_hdf5
+    _FakeH5.files.clear()
+    a, b = _play_out(6, 9, False, True), _play_out(6, 9, False, True)
+    st = a.engine.game_status()
+    S, P, Z = (t.cpu().numpy() for t in a.engine.harvest())
+    rec = torch.cat(list(b.engine.harvest_record_chunks(1 << 16)))
+    assert write_games_hdf5(rec[:int(st["plies"][:2].sum())], "mem.h5", 0, None, h5py_module=_FakeH5) == 2   # two calls append
+    assert write_games_hdf5(rec[int(st["plies"][:2].sum()):], "mem.h5", 0, None, h5py_module=_FakeH5) == 6
+    f = _FakeH5.files["mem.h5"]
+    assert f["attrs"]["iters"] == 6 and sorted(f["groups"]) == [f"game_{i}" for i in range(6)]
+    lo = 0
+    for i in range(6):
+        g = f["groups"][f"game_{i}"]
+        T2 = 2 * int(st["plies"][i])
+        assert g["states"][1] == "gzip" and g["mcts_probs"][1] == "gzip" and g["winners"][1] is None
+        assert g["states"][0].dtype == np.float16 and g["mcts_probs"][0].dtype == np.float64
+        assert np.array_equal(g["states"][0], S[lo:lo + T2]) and np.array_equal(g["mcts_probs"][0], P[lo:lo + T2].astype(np.float64))
+        assert np.array_equal(g["winners"][0], Z[lo:lo + T2].astype(np.float64))
+        lo += T2
+    assert lo == S.shape[0]
+    with pytest.raises(ImportError, match="h5py"):
+        write_games_hdf5(rec, "x.h5")
