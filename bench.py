@@ -64,6 +64,9 @@ def parse():
                     "one move of 4096 boards finishes ~14 k plies = ~28 k dense rows)")
     ap.add_argument("--replay-rows", type=int, default=0, help="N>1 / trainer: rows of the dense replay ring every rank keeps in HBM "
                     "(0 = 40,000 x world size: more than one move's rows of all ranks)")
+    ap.add_argument("--eval-cache-log2", type=int, default=22, help="evaluation cache of 2^n positions (528 B each; 0 = none): leaves whose "
+                    "position was evaluated before -- by this board, another board, or another board of the same step -- skip the "
+                    "network (the reference evaluates every leaf, mcts.py:114; results are identical bit for bit)")
     ap.add_argument("--value-f16", action="store_true", help="accumulate Q in float16 as the reference's CUDA path does (CCZ_FLAG_VALUE_F16, "
                     "net.py:178-189 -> mcts.py:63-71); default: float32, its CPU path")
     return ap.parse_args()
@@ -222,8 +225,10 @@ def main():
     else:
         evaluator = uniform_evaluator
     sp = BatchedSelfPlay(evaluator, B, n_playout=n, seed=0, board_id_base=rank * B, device=local_rank,
-                         sampling="device", max_plies=a.max_plies, value_f16=a.value_f16)
+                         sampling="device", max_plies=a.max_plies, value_f16=a.value_f16,
+                         eval_cache_log2=a.eval_cache_log2 if a.evaluator == "net" else 0)
     e = sp.engine
+    planned = [sp.planned]
     gather = RecordGatherer(max(a.gather_plies, e.max_plies), xdev) if world > 1 else None
     # the "shared replay buffer" of BASELINE configs[3]: every rank keeps the union of all ranks' rows as a dense ring in
     # its own HBM; finished games arrive as compact records and are expanded straight into the ring (ccz_expand_records)
@@ -317,14 +322,20 @@ def main():
             if timed:
                 e0, e1, e2 = ev(), ev(), ev()
                 e0.record()
-            prob, value = evaluator(state["leaf"])
-            if logits_in:  # the softmax+gather of the legal priors belongs to the evaluator side of the split
-                e.gather_priors(prob, value)
+            use_plan = planned[0] and logits_in
+            if use_plan:   # cache probe + plan, the network on the planned rows only, softmax + gather + cache store
+                prob, value = evaluator(state["leaf"], plan=e.eval_plan())
+                e.gather_priors_planned(prob, value)
+                value = None   # step / expand_backup then use the engine-owned leaf values (hits and fresh evaluations alike)
+            else:
+                prob, value = evaluator(state["leaf"])
+                if logits_in:  # the softmax+gather of the legal priors belongs to the evaluator side of the split
+                    e.gather_priors(prob, value)
             if timed:
                 e1.record()
             if last_of_move:
                 if logits_in:
-                    check_rc(e.L.ccz_expand_backup_compact(e.h, e._stream(), ptr_of(value)))
+                    check_rc(e.L.ccz_expand_backup_compact(e.h, e._stream(), None if value is None else ptr_of(value)))
                 else:
                     e.expand_backup(prob, value)
                 state["leaf"] = None
@@ -425,6 +436,8 @@ def main():
     if os.environ.get("CCZ_BENCH_TRACE") and rank == 0:  # per-step GPU time inside the timed window (diagnostics, stderr)
         print("trace: (simulation index within its move, ms) " + " ".join(f"{i}:{x.elapsed_time(y):.2f}" for i, x, y in trace[:4000]), file=sys.stderr)
     sims = s1["sims"] - s0["sims"]
+    probes = s1["cache_probes"] - s0["cache_probes"]
+    rows_per_step = ((probes - (s1["cache_hits"] - s0["cache_hits"]) - (s1["cache_shared_rows"] - s0["cache_shared_rows"])) / a.steps) if planned[0] else float(B)
     exp = max(1, s1["expansions"] - s0["expansions"])
     kbar = (s1["sum_children"] - s0["sum_children"]) / exp
     dbar = (s1["sum_depth"] - s0["sum_depth"]) / max(1, sims)
@@ -517,7 +530,16 @@ def main():
             "step_split_us": {"k_step": t_step * 1e6, "evaluator": t_net * 1e6},
             "trainer_updates": (train_steps[0] if trainer is not None else 0),
             "net_roofline": net_roofline,
-            "net_tflops": (flops * B / t_net / 1e12) if (a.evaluator == "net" and t_net == t_net) else None,
+            # rows the network really computed per step (with the evaluation cache: fewer than B) x 8.551 GFLOP
+            "net_tflops": (flops * rows_per_step / t_net / 1e12) if (a.evaluator == "net" and t_net == t_net) else None,
+            "eval_cache": ({"entries_log2": e.eval_cache_log2, "bytes": 528 << e.eval_cache_log2,
+                            "leaves_needing_the_net_in_window": probes, "hits_in_window": s1["cache_hits"] - s0["cache_hits"],
+                            "served_by_another_boards_row_in_window": s1["cache_shared_rows"] - s0["cache_shared_rows"],
+                            "rows_computed_per_step": rows_per_step,
+                            "fraction_of_needed_evaluations_skipped": 1.0 - rows_per_step * a.steps / max(1, probes),
+                            "stores_total": s1["cache_stores"],
+                            "what": "positions evaluated before (this board / another board / another board of the same step) skip the network; "
+                                    "visit counts unchanged bit for bit (tests/test_gpu_eval_cache.py)"} if planned[0] else None),
             "engine_hbm_gb": s1["hbm_bytes"] / 1e9, "nodes_peak": s1["nodes_peak"], "depth_peak": s1["depth_peak"],
             "plies": {"start_mean": float(plies0.mean()), "start_max": int(plies0.max()), "end_mean": float(plies1.mean())},
             "setup_seconds": setup_s,

@@ -22,7 +22,7 @@ MASK_WORDS = 66
 PLANES = 10710
 REC_BYTES, REC_HDR, REC_IDS, REC_PI = 880, 96, 112, 368  # compact ply record (include/cczero.h CCZ_REC_*)
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 RULE_PERPETUAL_CHECK = 1
 RULE_PAWN_MOVE_RESETS_CLOCK = 2
 FLAG_REFERENCE_QUIRKS = 1
@@ -46,7 +46,7 @@ class Config(C.Structure):
         ("alpha", C.c_float), ("temp", C.c_float), ("max_nodes", C.c_int32), ("max_depth", C.c_int32),
         ("max_plies", C.c_int32), ("flags", C.c_uint32), ("seed", C.c_uint64), ("board_id_base", C.c_uint64),
         ("device", C.c_int32), ("reserve_nodes", C.c_int32),
-        ("move_rank_host", C.c_void_p), ("plane_of_type", C.c_uint8 * 8), ("rule_flags", C.c_uint32), ("reserved0", C.c_uint32),
+        ("move_rank_host", C.c_void_p), ("plane_of_type", C.c_uint8 * 8), ("rule_flags", C.c_uint32), ("eval_cache_log2", C.c_uint32),
         ("type_rank", C.c_uint8 * 8),
     ]
 
@@ -57,6 +57,7 @@ class Stats(C.Structure):
         ("nodes_peak", C.c_int64), ("depth_peak", C.c_int64), ("sum_depth", C.c_int64), ("sum_children", C.c_int64),
         ("expansions", C.c_int64), ("terminal_leaves", C.c_int64), ("error_flags", C.c_int32), ("reserved", C.c_int32),
         ("hbm_bytes", C.c_int64), ("pruned_subtrees", C.c_int64),
+        ("cache_probes", C.c_int64), ("cache_hits", C.c_int64), ("cache_shared_rows", C.c_int64), ("cache_stores", C.c_int64),
     ]
 
 
@@ -80,6 +81,9 @@ PROTOTYPES = {
     "ccz_gather_priors": (C.c_int, [_P, _P, _P, C.c_int32]),
     "ccz_step_compact": (C.c_int, [_P, _P, _P, _P]),
     "ccz_expand_backup_compact": (C.c_int, [_P, _P, _P]),
+    "ccz_eval_plan": (C.c_int, [_P, _P, _P, _P]),
+    "ccz_gather_priors_planned": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
+    "ccz_eval_cache_clear": (C.c_int, [_P, _P]),
     "ccz_finish_move": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32]),
     "ccz_root_children": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "ccz_root_pi": (C.c_int, [_P, _P, _P, _P]),
@@ -98,6 +102,9 @@ PROTOTYPES = {
     "ccz_conv3x3_c256_f16": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32]),
     "ccz_conv3x3_stem_f16": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int32]),
     "ccz_pack_live_planes_f16": (C.c_int, [_P, _P, _P, C.c_int32]),
+    "ccz_pack_live_planes_rows_f16": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P]),
+    "ccz_conv3x3_c256_f16_live": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, _P, C.c_int32]),
+    "ccz_conv3x3_stem_f16_live": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int32, _P, C.c_int32]),
 }
 
 _lib = None

@@ -149,6 +149,7 @@ int ccz_create(const ccz_config *cfg, ccz_engine **out)
     d.seed = cfg->seed;
     d.board_id_base = cfg->board_id_base;
     // ---- run-time rule tables (ABI 2)
+    if (cfg->eval_cache_log2 && (cfg->eval_cache_log2 < 10 || cfg->eval_cache_log2 > 28)) { delete e; return fail(-1, "ccz_create: eval_cache_log2 must be 0 (no cache) or 10..28"); }
     if (cfg->rule_flags & ~(CCZ_RULE_PERPETUAL_CHECK | CCZ_RULE_PAWN_MOVE_RESETS_CLOCK)) { delete e; return fail(-1, "ccz_create: unknown rule_flags 0x%x", cfg->rule_flags); }
     d.rule_flags = cfg->rule_flags;
     {
@@ -200,6 +201,22 @@ int ccz_create(const ccz_config *cfg, ccz_engine **out)
     ALLOC(d.leaf_k, B);
     ALLOC(d.leaf_status, B);
     ALLOC(d.leaf_key, B);
+    d.cache = nullptr;
+    d.cache_mask = 0;
+    if (cfg->eval_cache_log2) {
+        const size_t slots = (size_t)1 << cfg->eval_cache_log2;
+        d.cache_mask = (uint32_t)(slots - 1);
+        ALLOC(d.cache, slots);
+        ALLOC(d.claim, slots);
+        ALLOC(d.cslot, B);
+        ALLOC(d.cstate, B);
+        ALLOC(d.cins, B);
+        ALLOC(d.crep, B);
+        ALLOC(d.row_of, B);
+        ALLOC(d.vleaf, B);
+        ALLOC(d.cache_stats, 4);
+        if (he == hipSuccess) he = hipMemset(d.claim, 0x7f, slots * 4);
+    }
     ALLOC(d.rec_sq, B * d.max_plies * 96);
     ALLOC(d.rec_turn, B * d.max_plies);
     ALLOC(d.rec_k, B * d.max_plies);
@@ -349,17 +366,54 @@ int ccz_gather_priors(ccz_engine *e, void *stream, const void *logits_dev, int32
     if (!logits_dev) return fail(-1, "ccz_gather_priors: null logits");
     hipStream_t s = (hipStream_t)stream;
     if (logits_f16)
-        hipLaunchKernelGGL(k_softmax_gather<_Float16>, dim3(e->d.B), dim3(64), 0, s, e->d, (const _Float16 *)logits_dev);
+        hipLaunchKernelGGL((k_softmax_gather<_Float16, false>), dim3(e->d.B), dim3(64), 0, s, e->d, (const _Float16 *)logits_dev, (const float *)nullptr);
     else
-        hipLaunchKernelGGL(k_softmax_gather<float>, dim3(e->d.B), dim3(64), 0, s, e->d, (const float *)logits_dev);
+        hipLaunchKernelGGL((k_softmax_gather<float, false>), dim3(e->d.B), dim3(64), 0, s, e->d, (const float *)logits_dev, (const float *)nullptr);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ccz_eval_plan(ccz_engine *e, void *stream, int32_t *miss_rows_dev, int32_t *n_miss_dev)
+{
+    NEED(e);
+    if (!e->d.cache) return fail(-1, "ccz_eval_plan: the engine was created without an evaluation cache (ccz_config.eval_cache_log2)");
+    if (!miss_rows_dev || !n_miss_dev) return fail(-1, "ccz_eval_plan: null output");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_cache_probe, dim3(e->d.B), dim3(64), 0, s, e->d);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_cache_plan, dim3(1), dim3(1024), 0, s, e->d, miss_rows_dev, n_miss_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ccz_gather_priors_planned(ccz_engine *e, void *stream, const void *logits_compact_dev, int32_t logits_f16, const float *value_compact_dev)
+{
+    NEED(e);
+    if (!e->d.cache) return fail(-1, "ccz_gather_priors_planned: the engine was created without an evaluation cache");
+    if (!logits_compact_dev || !value_compact_dev) return fail(-1, "ccz_gather_priors_planned: null logits / value");
+    hipStream_t s = (hipStream_t)stream;
+    if (logits_f16)
+        hipLaunchKernelGGL((k_softmax_gather<_Float16, true>), dim3(e->d.B), dim3(64), 0, s, e->d, (const _Float16 *)logits_compact_dev, value_compact_dev);
+    else
+        hipLaunchKernelGGL((k_softmax_gather<float, true>), dim3(e->d.B), dim3(64), 0, s, e->d, (const float *)logits_compact_dev, value_compact_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ccz_eval_cache_clear(ccz_engine *e, void *stream)
+{
+    NEED(e);
+    if (!e->d.cache) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(e->d.cache, 0, ((size_t)e->d.cache_mask + 1) * sizeof(CacheEntry), s));
+    HIP_TRY(hipMemsetAsync(e->d.claim, 0x7f, ((size_t)e->d.cache_mask + 1) * 4, s));
     return 0;
 }
 
 int ccz_step_compact(ccz_engine *e, void *stream, const float *value_dev, void *leaf_input_f16_dev)
 {
     NEED(e);
-    if (!value_dev) return fail(-1, "ccz_step_compact: null value");
+    if (!value_dev && !e->d.cache) return fail(-1, "ccz_step_compact: null value (engine-owned leaf values exist only with an evaluation cache)");
     hipLaunchKernelGGL(k_step<true>, dim3(e->d.B), dim3(64), 0, (hipStream_t)stream, e->d, (const float *)e->d.prior128, value_dev,
                        (uint16_t *)leaf_input_f16_dev);
     HIP_TRY(hipGetLastError());
@@ -369,7 +423,7 @@ int ccz_step_compact(ccz_engine *e, void *stream, const float *value_dev, void *
 int ccz_expand_backup_compact(ccz_engine *e, void *stream, const float *value_dev)
 {
     NEED(e);
-    if (!value_dev) return fail(-1, "ccz_expand_backup_compact: null value");
+    if (!value_dev && !e->d.cache) return fail(-1, "ccz_expand_backup_compact: null value (engine-owned leaf values exist only with an evaluation cache)");
     hipLaunchKernelGGL(k_expand_backup<true>, dim3(e->d.B), dim3(64), 0, (hipStream_t)stream, e->d, (const float *)e->d.prior128,
                        value_dev);
     HIP_TRY(hipGetLastError());
@@ -634,6 +688,14 @@ int ccz_get_stats(ccz_engine *e, void *stream, ccz_stats *out)
         if (b.nodes_peak > out->nodes_peak) out->nodes_peak = b.nodes_peak;
         if (b.depth_peak > out->depth_peak) out->depth_peak = b.depth_peak;
     }
+    if (e->d.cache) {
+        unsigned long long cs[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpy(cs, e->d.cache_stats, sizeof cs, hipMemcpyDeviceToHost));
+        out->cache_probes = (int64_t)cs[0];
+        out->cache_hits = (int64_t)cs[1];
+        out->cache_shared_rows = (int64_t)cs[2];
+        out->cache_stores = (int64_t)cs[3];
+    }
     out->error_flags = err[0];
     out->reserved = err[1]; // bounds-checked diagnostic build: source line of the stray index (0 otherwise)
     out->hbm_bytes = (int64_t)e->bytes;
@@ -680,7 +742,7 @@ int ccz_bias_act_f16(void *stream, void *y_dev, const void *bias_dev, const void
 }
 
 static int conv3x3_launch(const char *who, void *stream, const void *x_dev, const void *w_dev, const void *bias_f32_dev, const void *residual_dev, void *y_dev,
-                          int64_t n_pixels, int32_t relu, int cin)
+                          int64_t n_pixels, int32_t relu, int cin, const int32_t *live_rows_dev = nullptr, int32_t row0 = 0)
 {
     if (!x_dev || !w_dev || !bias_f32_dev || !y_dev || n_pixels < 0 || n_pixels % 90 || n_pixels > (int64_t)INT32_MAX / kCvC) /* 32-bit element offsets in the kernel */
         return fail(-1, "%s: bad arguments (n_pixels must be boards * 90, at most 93206 boards per call)", who);
@@ -719,10 +781,10 @@ static int conv3x3_launch(const char *who, void *stream, const void *x_dev, cons
 #endif
     if (residual_dev)
         hipLaunchKernelGGL(k_conv3x3_c256<true>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev,
-                           (const float *)bias_f32_dev, (const _Float16 *)residual_dev, (_Float16 *)y_dev, (int)n_pixels, (int)relu, cin);
+                           (const float *)bias_f32_dev, (const _Float16 *)residual_dev, (_Float16 *)y_dev, (int)n_pixels, (int)relu, cin, (const int *)live_rows_dev, (int)row0);
     else
         hipLaunchKernelGGL(k_conv3x3_c256<false>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev,
-                           (const float *)bias_f32_dev, (const _Float16 *)nullptr, (_Float16 *)y_dev, (int)n_pixels, (int)relu, cin);
+                           (const float *)bias_f32_dev, (const _Float16 *)nullptr, (_Float16 *)y_dev, (int)n_pixels, (int)relu, cin, (const int *)live_rows_dev, (int)row0);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -738,12 +800,38 @@ int ccz_conv3x3_stem_f16(void *stream, const void *x64_dev, const void *w_dev, c
     return conv3x3_launch("ccz_conv3x3_stem_f16", stream, x64_dev, w_dev, bias_f32_dev, nullptr, y_dev, n_pixels, relu, 64);
 }
 
+int ccz_conv3x3_c256_f16_live(void *stream, const void *x_dev, const void *w_dev, const void *bias_f32_dev, const void *residual_dev, void *y_dev,
+                              int64_t n_pixels, int32_t relu, const int32_t *live_rows_dev, int32_t row0)
+{
+    if (!live_rows_dev || row0 < 0) return fail(-1, "ccz_conv3x3_c256_f16_live: null live-row count or negative row0");
+    return conv3x3_launch("ccz_conv3x3_c256_f16_live", stream, x_dev, w_dev, bias_f32_dev, residual_dev, y_dev, n_pixels, relu, 256, live_rows_dev, row0);
+}
+
+int ccz_conv3x3_stem_f16_live(void *stream, const void *x64_dev, const void *w_dev, const void *bias_f32_dev, void *y_dev, int64_t n_pixels, int32_t relu,
+                              const int32_t *live_rows_dev, int32_t row0)
+{
+    if (!live_rows_dev || row0 < 0) return fail(-1, "ccz_conv3x3_stem_f16_live: null live-row count or negative row0");
+    return conv3x3_launch("ccz_conv3x3_stem_f16_live", stream, x64_dev, w_dev, bias_f32_dev, nullptr, y_dev, n_pixels, relu, 64, live_rows_dev, row0);
+}
+
+int ccz_pack_live_planes_rows_f16(void *stream, const void *leaf_dev, void *x64_dev, int32_t n_boards, const int32_t *rows_dev, const int32_t *n_rows_dev)
+{
+    if (!leaf_dev || !x64_dev || n_boards < 0 || !rows_dev || !n_rows_dev) return fail(-1, "ccz_pack_live_planes_rows_f16: bad arguments");
+    if ((uintptr_t)x64_dev & 15) return fail(-1, "ccz_pack_live_planes_rows_f16: output must be 16-byte aligned");
+    if (n_boards == 0) return 0;
+    hipLaunchKernelGGL(k_pack_live_planes, dim3((unsigned)n_boards), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)leaf_dev, (half8_t *)x64_dev, (int)n_boards,
+                       (const int *)rows_dev, (const int *)n_rows_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int ccz_pack_live_planes_f16(void *stream, const void *leaf_dev, void *x64_dev, int32_t n_boards)
 {
     if (!leaf_dev || !x64_dev || n_boards < 0) return fail(-1, "ccz_pack_live_planes_f16: bad arguments");
     if ((uintptr_t)x64_dev & 15) return fail(-1, "ccz_pack_live_planes_f16: output must be 16-byte aligned");
     if (n_boards == 0) return 0;
-    hipLaunchKernelGGL(k_pack_live_planes, dim3((unsigned)n_boards), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)leaf_dev, (half8_t *)x64_dev, (int)n_boards);
+    hipLaunchKernelGGL(k_pack_live_planes, dim3((unsigned)n_boards), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)leaf_dev, (half8_t *)x64_dev, (int)n_boards,
+                       (const int *)nullptr, (const int *)nullptr);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -218,15 +218,26 @@ __device__ __forceinline__ void cv_halfstep(const CvCtx &c, cv_f32x4 (&acc)[8][4
 template <bool RES>
 __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict__ X, const _Float16 *__restrict__ W,
                                                           const float *__restrict__ bias, const _Float16 *R,
-                                                          _Float16 *Y, int M, int relu, int cin)
+                                                          _Float16 *Y, int M, int relu, int cin, const int *live_rows, int row0)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kCvLds];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q4 = lane >> 4;
     const int wm = w >> 2, wn = w & 3;
+    int tiles = gridDim.x;
+    if (live_rows) {
+        // Planned evaluator boundary (ccz_eval_plan): only the first *live_rows boards of the batch hold rows to compute; this
+        // launch covers boards row0 .. row0 + M / 90 of it. The grid is sized for the whole range (no host sync on the count);
+        // workgroups beyond the live tiles leave at once.
+        int live = *live_rows - row0;
+        live = live < 0 ? 0 : (live > M / 90 ? M / 90 : live);
+        M = live * 90;
+        tiles = (M + kCvBM - 1) / kCvBM;
+        if ((int)blockIdx.x >= tiles) return;
+    }
     // flags bit 1: tiles in descending order (the tiles written last by the previous layer are then read first)
-    const long p0 = (long)((relu & 2) ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * kCvBM;
+    const long p0 = (long)((relu & 2) ? tiles - 1 - blockIdx.x : blockIdx.x) * kCvBM;
 
 #ifdef CCZ_STAMPS
     const unsigned long long st_prolog = cv_stamp();

@@ -46,6 +46,16 @@ struct __align__(8) BoardMeta {
     uint32_t game_no;
 };
 
+// One entry of the evaluation cache (ccz_config.eval_cache_log2): what the evaluator returned for a position -- the priors of
+// its legal moves in `legal_moves` order (what k_softmax_gather writes to prior128) and the value -- keyed by the Zobrist key.
+struct __align__(16) CacheEntry {
+    uint64_t key;   // 0 = empty
+    float v;
+    uint32_t k;     // number of legal moves (checked on a hit)
+    float pri[kMaxLegal];
+};
+static_assert(sizeof(CacheEntry) == 528, "cache entry is 528 bytes");
+
 struct BoardStats {
     unsigned long long sims, moves, games, truncated, sum_depth, sum_children, expansions, terminal, pruned;
     int32_t nodes_peak, depth_peak;
@@ -70,6 +80,19 @@ struct Dev {
     uint16_t *leaf_ids;   // [B][128]
     int32_t *leaf_k;      // [B]
     uint8_t *leaf_status; // [B]
+    // ---- evaluation cache (optional: cache == nullptr without it). The evaluator input of the search path depends on the leaf
+    // position and side to move only (net.py:160-173: history planes zero), i.e. on leaf_key: a position evaluated before -- by
+    // this board, by another one, or by another board in this very step -- need not go through the tower again.
+    CacheEntry *cache;    // [cache_mask + 1] direct-mapped by the key
+    uint32_t cache_mask;
+    int32_t *claim;       // [cache_mask + 1] lowest board index that missed on this slot in the current step (INT_MAX: nobody)
+    uint32_t *cslot;      // [B] slot of the pending leaf
+    uint8_t *cstate;      // [B] 0 = miss: needs a row of the evaluator, 1 = hit, 2 = no evaluation needed (terminal leaf, none)
+    uint8_t *cins;        // [B] this board's fresh evaluation is stored (it is the slot's claim winner)
+    int32_t *crep;        // [B] the board whose evaluator row this board uses (itself, or the same-key board of lower index)
+    int32_t *row_of;      // [B] compact evaluator row holding this board's logits / value (misses)
+    float *vleaf;         // [B] leaf value of the pending leaf (step / expand_backup read it when value_dev == NULL)
+    unsigned long long *cache_stats; // [4] leaves probed, hits, served by another board's row of the same step, entries stored
     uint64_t *leaf_key;   // [B] Zobrist key (pieces + side to move) of the pending leaf: what the evaluator input depends on
     uint8_t *rec_sq;   // [B][max_plies][96] root position before each move
     uint8_t *rec_turn; // [B][max_plies]

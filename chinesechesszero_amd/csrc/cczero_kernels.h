@@ -429,7 +429,7 @@ __device__ inline TopPatch expand_backup_phase(const Dev &D, int b, int lane, co
     const int status = D.leaf_status[b];
     const int d = D.path_len[b];
     const int k_leaf = D.leaf_k[b];
-    const float v_net = value[b];
+    const float v_net = value ? value[b] : D.vleaf[b]; // value == nullptr: the engine-owned leaf values of the planned evaluator boundary
     const int32_t *path = D.path + (size_t)b * D.maxd;
     const uint16_t *ids = D.leaf_ids + (size_t)b * kMaxLegal;
     const int id0 = ids[lane], id1 = ids[64 + lane];
@@ -555,19 +555,27 @@ __global__ __launch_bounds__(64) void k_step(Dev D, const float *prob, const flo
 // logits once (coalesced), reduces max and sum on the DPP network, and writes only the <= 128 priors the
 // expansion will use, aligned with leaf_ids. Replaces two full [B,2086] torch passes (log_softmax, exp) and
 // turns the expansion's scattered 4-byte gather (one 64-B line per legal move) into one coalesced 512-B read.
-template <typename T>
-__global__ __launch_bounds__(64) void k_softmax_gather(Dev D, const T *logits)
+// PLANNED: the evaluator ran on the compact rows of k_cache_plan; board b's logits sit in row row_of[b] of `logits`, its value in
+// vcompact[row_of[b]]; cache hits already hold their priors and value (k_cache_probe); a fresh evaluation whose board won the
+// slot's claim is stored in the cache.
+template <typename T, bool PLANNED>
+__global__ __launch_bounds__(64) void k_softmax_gather(Dev D, const T *logits, const float *vcompact)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
     __shared__ float row[kNMoves + 2];
     if (D.leaf_status[b] != CCZ_LEAF_EXPAND) return;
+    int src = b;
+    if (PLANNED) {
+        if (D.cstate[b] != 0) return; // hit: prior128 / vleaf were filled by the probe
+        src = D.row_of[b];
+    }
     const int k = D.leaf_k[b];
     const uint16_t *ids = D.leaf_ids + (size_t)b * kMaxLegal;
     const int id0 = ids[lane], id1 = ids[64 + lane];
-    const T *src = logits + (size_t)b * kNMoves;
+    const T *srcrow = logits + (size_t)src * kNMoves;
     float mx = -__builtin_huge_valf();
     for (int i = lane; i < kNMoves; i += 64) {
-        const float x = (float)src[i];
+        const float x = (float)srcrow[i];
         row[i] = x;
         mx = fmaxf(mx, x);
     }
@@ -577,8 +585,112 @@ __global__ __launch_bounds__(64) void k_softmax_gather(Dev D, const T *logits)
     sum = wave_sum_f32(sum);
     wave_sync();
     float *out = D.prior128 + (size_t)b * kMaxLegal;
-    if (lane < k) out[lane] = __expf(row[id0] - mx) / sum;
-    if (64 + lane < k) out[64 + lane] = __expf(row[id1] - mx) / sum;
+    const float p0 = lane < k ? __expf(row[id0] - mx) / sum : 0.0f;
+    const float p1 = 64 + lane < k ? __expf(row[id1] - mx) / sum : 0.0f;
+    if (lane < k) out[lane] = p0;
+    if (64 + lane < k) out[64 + lane] = p1;
+    if (PLANNED) {
+        const float v = vcompact[src];
+        const uint32_t slot = D.cslot[b];
+        if (lane == 0) {
+            D.vleaf[b] = v;
+            D.claim[slot] = 0x7fffffff; // (every board that missed on the slot resets it: idempotent)
+        }
+        if (D.cins[b]) { // the slot's claim winner stores its evaluation; the key goes last, behind the payload
+            CacheEntry *e = D.cache + slot;
+            e->pri[lane] = p0;
+            e->pri[64 + lane] = p1;
+            if (lane == 0) { e->v = v; e->k = (uint32_t)k; }
+            __threadfence();
+            if (lane == 0) { e->key = D.leaf_key[b]; atomicAdd(D.cache_stats + 3, 1ull); }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ evaluation cache: probe, plan
+__device__ __forceinline__ uint32_t cache_slot(uint64_t key, uint32_t mask) { return (uint32_t)(key ^ (key >> 29)) & mask; }
+
+// One wave per board: look the pending leaf up. Hit: its priors and value go straight to prior128 / vleaf. Miss: the board
+// bids for the slot (lowest board index wins: deterministic) -- the winner's evaluation will be stored there, and boards that
+// missed with the SAME key in this step share the winner's evaluator row (k_cache_plan).
+__global__ __launch_bounds__(64) void k_cache_probe(Dev D)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (D.leaf_status[b] != CCZ_LEAF_EXPAND) {
+        if (lane == 0) D.cstate[b] = 2;
+        return;
+    }
+    const uint64_t key = D.leaf_key[b];
+    const uint32_t slot = cache_slot(key, D.cache_mask);
+    const CacheEntry *e = D.cache + slot;
+    const uint64_t ekey = e->key;
+    const uint32_t ek = e->k;
+    const float ev = e->v, q0 = e->pri[lane], q1 = e->pri[64 + lane];
+    const bool hit = ekey == key && ek == (uint32_t)D.leaf_k[b];
+    if (hit) {
+        float *out = D.prior128 + (size_t)b * kMaxLegal;
+        out[lane] = q0;
+        out[64 + lane] = q1;
+    }
+    if (lane == 0) {
+        D.cslot[b] = slot;
+        D.cstate[b] = hit ? 1 : 0;
+        if (hit) D.vleaf[b] = ev;
+        else atomicMin(D.claim + slot, b);
+        atomicAdd(D.cache_stats + 0, 1ull);
+        if (hit) atomicAdd(D.cache_stats + 1, 1ull);
+    }
+}
+
+// One workgroup: representatives and the compaction plan. A miss whose slot was won by a board with the same key uses that
+// board's row; every other miss is its own representative (a different key on the same slot is evaluated but not stored).
+// miss_rows[0 .. n_miss) = the representatives in ascending board order: the rows the evaluator computes.
+__global__ __launch_bounds__(1024) void k_cache_plan(Dev D, int32_t *miss_rows, int32_t *n_miss)
+{
+    __shared__ int s_scan[1024];
+    __shared__ int s_base;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    int shared = 0;
+    for (int b0 = 0; b0 < D.B; b0 += 1024) {
+        const int b = b0 + tid;
+        int isrep = 0;
+        if (b < D.B && D.cstate[b] == 0) {
+            const int w = D.claim[D.cslot[b]];
+            const bool same = w >= 0 && w < D.B && D.cstate[w] == 0 && D.leaf_key[w] == D.leaf_key[b];
+            const int rep = same ? w : b;
+            D.crep[b] = rep;
+            D.cins[b] = (uint8_t)(w == b);
+            isrep = rep == b;
+            shared += !isrep;
+        }
+        // inclusive scan of isrep over the 1024 threads
+        s_scan[tid] = isrep;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int v = tid >= off ? s_scan[tid - off] : 0;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        const int base = s_base;
+        if (isrep) {
+            const int pos = base + s_scan[tid] - 1;
+            D.row_of[b] = pos;
+            miss_rows[pos] = b;
+        }
+        __syncthreads();
+        if (tid == 1023) s_base = base + s_scan[1023];
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int b = tid; b < D.B; b += 1024)
+        if (D.cstate[b] == 0 && D.crep[b] != b) // (read past this CU's L1: the row was written a moment ago by another wave)
+            D.row_of[b] = __hip_atomic_load(D.row_of + D.crep[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (shared) atomicAdd(D.cache_stats + 2, (unsigned long long)shared);
+    if (tid == 0) *n_miss = s_base;
 }
 
 // ------------------------------------------------------------------ pi from root visits (mcts.py:162-166)

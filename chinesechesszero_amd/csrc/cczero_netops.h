@@ -30,10 +30,17 @@ __global__ __launch_bounds__(256) void k_bias_act(half8_t *__restrict__ y, const
 // The evaluator input [B, 17, 7, 10, 9] fp16 (reference net.py:174-177) has 21 planes that can be non-zero on the
 // search path (groups 7, 15, 16 = planes 49..55 and 105..118, net.py:160-173): pack them as NHWC rows of 64 channels
 // (21 live + 43 zeros), the stem input of the tower convolution kernel. One workgroup per board, 16 B per lane.
-__global__ __launch_bounds__(256) void k_pack_live_planes(const _Float16 *__restrict__ leaf, half8_t *__restrict__ out, int n_boards)
+// rows != nullptr (planned evaluator boundary, ccz_eval_plan): output row i is board rows[i], for i < *n_rows only.
+__global__ __launch_bounds__(256) void k_pack_live_planes(const _Float16 *__restrict__ leaf, half8_t *__restrict__ out, int n_boards,
+                                                          const int *__restrict__ rows, const int *__restrict__ n_rows)
 {
     const long b = blockIdx.x;
-    const _Float16 *src = leaf + b * (119 * 90);
+    long sb = b;
+    if (rows) {
+        if (b >= *n_rows) return;
+        sb = rows[b];
+    }
+    const _Float16 *src = leaf + sb * (119 * 90);
     for (int i = threadIdx.x; i < 90 * 8; i += 256) {
         const int p = i >> 3, cpos = i & 7;
         half8_t v = (half8_t)(_Float16)0;

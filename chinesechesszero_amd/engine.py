@@ -32,10 +32,11 @@ class SelfPlayEngine:
                  device: int = 0, max_nodes: int = 0, max_depth: int = 0, max_plies: int = 0,
                  reference_quirks: bool = False, mirror: bool = True, reserve_nodes: int = 0,
                  move_rank="tools", plane_of_type="tools", value_f16: bool = False, type_rank="tools",
-                 pawn_move_resets_clock="tools", perpetual_check="tools"):
+                 pawn_move_resets_clock="tools", perpetual_check="tools", eval_cache_log2: int = 0):
         """``move_rank`` (uint16[2086] permutation, None = ascending id) and ``plane_of_type`` (8 entries, None = type-1)
         are the run-time rule tables of ``ccz_config`` (ABI 2); the default "tools" takes the process-wide choice of
-        :func:`chinesechesszero_amd.tools.set_rules`."""
+        :func:`chinesechesszero_amd.tools.set_rules`. ``eval_cache_log2`` = n > 0: an evaluation cache of 2^n positions
+        (528 B each) for the planned evaluator boundary (:meth:`eval_plan`, ``include/cczero.h`` ccz_eval_plan)."""
         self.L = _lib.lib()
         if not torch.cuda.is_available():
             raise CczError("no GPU visible to PyTorch-ROCm; the engine has no CPU fallback")
@@ -79,10 +80,15 @@ class SelfPlayEngine:
             if len(self.type_rank) != 8:
                 raise ValueError("type_rank must have 8 entries")
             cfg.type_rank = (C.c_uint8 * 8)(*self.type_rank)
+        self.eval_cache_log2 = int(eval_cache_log2)
+        cfg.eval_cache_log2 = self.eval_cache_log2
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             check(self.L.ccz_create(C.byref(cfg), C.byref(h)))
         self.h = h
+        # the evaluation plan of the current step (planned evaluator boundary): rows the evaluator has to compute, their number
+        self.miss_rows = torch.zeros((self.B,), dtype=torch.int32, device=self.device)
+        self.n_miss = torch.zeros((1,), dtype=torch.int32, device=self.device)
         # torch-owned boundary buffers (evaluator input / outputs, move buffers)
         self.leaf_input = torch.zeros((self.B, 17, 7, 10, 9), dtype=torch.float16, device=self.device)
         self.moves_out = torch.full((self.B,), -1, dtype=torch.int32, device=self.device)
@@ -169,9 +175,35 @@ class SelfPlayEngine:
         f16 = self._check_logits(logits, value)
         check(self.L.ccz_gather_priors(self.h, self._stream(), _ptr(logits), f16))
 
-    def step_compact(self, value: torch.Tensor) -> torch.Tensor:
+    def step_compact(self, value: torch.Tensor | None) -> torch.Tensor:
+        """``value`` None: the engine-owned leaf values of the planned boundary (:meth:`gather_priors_planned`)."""
         check(self.L.ccz_step_compact(self.h, self._stream(), _ptr(value), _ptr(self.leaf_input)))
         return self.leaf_input
+
+    # ------------------------------------------------------------------ planned evaluator boundary (evaluation cache)
+    def eval_plan(self):
+        """Probe the evaluation cache for the pending leaves and plan the evaluator's batch: returns the device tensors
+        ``(miss_rows int32 [B], n_miss int32 [1])`` -- the boards whose leaves still need the network (deduplicated, ascending)
+        and their number. No host sync: the evaluator's kernels read the count on the device."""
+        check(self.L.ccz_eval_plan(self.h, self._stream(), _ptr(self.miss_rows), _ptr(self.n_miss)))
+        return self.miss_rows, self.n_miss
+
+    def gather_priors_planned(self, logits: torch.Tensor, value: torch.Tensor):
+        """``logits`` [B,2086] / ``value`` [B] as the planned evaluator returns them: COMPACT, row i = board miss_rows[i]."""
+        f16 = self._check_logits(logits, value)
+        check(self.L.ccz_gather_priors_planned(self.h, self._stream(), _ptr(logits), f16, _ptr(value)))
+
+    def step_planned(self, logits: torch.Tensor, value: torch.Tensor) -> torch.Tensor:
+        self.gather_priors_planned(logits, value)
+        return self.step_compact(None)
+
+    def expand_backup_planned(self, logits: torch.Tensor, value: torch.Tensor):
+        self.gather_priors_planned(logits, value)
+        check(self.L.ccz_expand_backup_compact(self.h, self._stream(), None))
+
+    def clear_eval_cache(self):
+        """Forget every cached evaluation (the evaluator's weights changed)."""
+        check(self.L.ccz_eval_cache_clear(self.h, self._stream()))
 
     # ------------------------------------------------------------------ once per move
     def finish_move(self, forced_moves=None, temps=None, keep_tree: bool = True) -> torch.Tensor:

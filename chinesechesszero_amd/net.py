@@ -165,8 +165,10 @@ class InferenceNet(nn.Module):
     TOWER_GROUP_BOARDS = 2048  # boards per sequential group (working set of a group fits the Infinity Cache); env CCZ_TOWER_GROUPS
     TOWER_CHAINS = 2  # independent board ranges run as concurrent launch chains (one HIP stream each); env CCZ_TOWER_CHAINS (<= 8)
 
-    def _tower_fused(self, x):
+    def _tower_fused(self, x, plan=None):
         """40 residual blocks = 80 launches of one kernel: conv3x3 + bias [+ x] + ReLU each (reference net.py:20-43).
+        ``plan`` = (rows, n_rows) of the planned evaluator boundary: only the first ``n_rows`` (a device value) boards of ``x``
+        are live; every launch skips the tiles past them (``ccz_conv3x3_c256_f16_live``).
 
         Boards are independent, so the batch is cut into ``TOWER_CHAINS`` contiguous board ranges whose 80-launch
         chains run on separate HIP streams: the tile tail of one chain's layer (1440 tiles on 256 CUs = 5.6 rounds,
@@ -187,10 +189,10 @@ class InferenceNet(nn.Module):
             groups = 1
         gstep = -(-(-(-Bt // groups)) // 128) * 128 if groups > 1 else Bt
         for g0 in range(0, Bt, gstep):
-            self._tower_range(L, C, x, y, g0, min(Bt, g0 + gstep))
+            self._tower_range(L, C, x, y, g0, min(Bt, g0 + gstep), plan)
         return x
 
-    def _tower_range(self, L, C, x, y, lo, hi):
+    def _tower_range(self, L, C, x, y, lo, hi, plan=None):
         """Boards [lo, hi) through all 80 layers, as TOWER_CHAINS concurrent launch chains."""
         from . import _lib
         B = hi - lo
@@ -214,7 +216,7 @@ class InferenceNet(nn.Module):
             st = cur if k == 0 else self._chain_streams[1][k - 1]
             if k:
                 st.wait_event(fork)
-            chains.append((st, C.c_void_p(st.cuda_stream), C.c_void_p(x.data_ptr() + b0 * row), C.c_void_p(y.data_ptr() + b0 * row), (b1 - b0) * 90))
+            chains.append((st, C.c_void_p(st.cuda_stream), C.c_void_p(x.data_ptr() + b0 * row), C.c_void_p(y.data_ptr() + b0 * row), (b1 - b0) * 90, b0))
         # launches are enqueued layer by layer across the chains, so that the chains advance together (the same layer's
         # weights stay hot in L2) and no chain waits for the host to finish enqueuing another one. The tile order
         # alternates from layer to layer: what the previous layer wrote last (still in the Infinity Cache) is read
@@ -222,36 +224,72 @@ class InferenceNet(nn.Module):
         down = 2 if os.environ.get("CCZ_CONV_ZIGZAG", "1") == "1" else 0
         v2 = 4 if os.environ.get("CCZ_CONV_V2", "0") == "1" else 0  # A/B only: the experimental two-workgroups-per-CU form
         # (cczero_conv2.h, compiled into diagnostic builds with -DCCZ_CONV2; the shipped library ignores the bit)
+        live = None if plan is None else C.c_void_p(plan[1].data_ptr())
         for i in range(0, len(self.ws), 2):
             w1, b1_, w2, b2_ = (C.c_void_p(t.data_ptr()) for t in (self.ws[i], self.bs32[i], self.ws[i + 1], self.bs32[i + 1]))
-            for _, s, xp, yp, n_pixels in chains:
-                _lib.check(L.ccz_conv3x3_c256_f16(s, xp, w1, b1_, None, yp, n_pixels, 1 | down | v2))
-            for _, s, xp, yp, n_pixels in chains:
-                _lib.check(L.ccz_conv3x3_c256_f16(s, yp, w2, b2_, xp, xp, n_pixels, 1 | v2))  # output written over the residual input
+            if live is None:
+                for _, s, xp, yp, n_pixels, _b0 in chains:
+                    _lib.check(L.ccz_conv3x3_c256_f16(s, xp, w1, b1_, None, yp, n_pixels, 1 | down | v2))
+                for _, s, xp, yp, n_pixels, _b0 in chains:
+                    _lib.check(L.ccz_conv3x3_c256_f16(s, yp, w2, b2_, xp, xp, n_pixels, 1 | v2))  # output written over the residual input
+            else:  # the same launches, each told where its board range starts in the compacted batch
+                for _, s, xp, yp, n_pixels, b0 in chains:
+                    _lib.check(L.ccz_conv3x3_c256_f16_live(s, xp, w1, b1_, None, yp, n_pixels, 1 | down, live, b0))
+                for _, s, xp, yp, n_pixels, b0 in chains:
+                    _lib.check(L.ccz_conv3x3_c256_f16_live(s, yp, w2, b2_, xp, xp, n_pixels, 1, live, b0))
         for st, *_ in chains[1:]:  # every side stream is joined into the current stream
             join = torch.cuda.Event()
             join.record(st)
             cur.wait_event(join)
 
-    def _stem_fused(self, leaf_input):
+    def _stem_fused(self, leaf_input, plan=None):
         """Stem on the same MFMA kernel: pack the 21 live planes as NHWC rows of 64 channels, then one 64-channel chunk of
-        the tower convolution (conv3x3 + bias + ReLU). Replaces cat + layout copy + MIOpen convolution + epilogue pass."""
+        the tower convolution (conv3x3 + bias + ReLU). Replaces cat + layout copy + MIOpen convolution + epilogue pass.
+        With a ``plan`` the pack GATHERS: output row i is board rows[i], for the live rows only."""
         import ctypes as C
         from . import _lib
         L = _lib.lib()
         B = leaf_input.shape[0]
         s = C.c_void_p(torch.cuda.current_stream(leaf_input.device).cuda_stream)
-        x64 = torch.empty((B, 90, 64), dtype=torch.float16, device=leaf_input.device)
-        y = torch.empty((B, 256, 10, 9), dtype=torch.float16, device=leaf_input.device, memory_format=torch.channels_last)
-        _lib.check(L.ccz_pack_live_planes_f16(s, C.c_void_p(leaf_input.data_ptr()), C.c_void_p(x64.data_ptr()), B))
-        _lib.check(L.ccz_conv3x3_stem_f16(s, C.c_void_p(x64.data_ptr()), C.c_void_p(self.stem_w64.data_ptr()), C.c_void_p(self.stem_b32.data_ptr()),
-                                          C.c_void_p(y.data_ptr()), B * 90, 1))
+        if plan is None:
+            x64 = torch.empty((B, 90, 64), dtype=torch.float16, device=leaf_input.device)
+            y = torch.empty((B, 256, 10, 9), dtype=torch.float16, device=leaf_input.device, memory_format=torch.channels_last)
+            _lib.check(L.ccz_pack_live_planes_f16(s, C.c_void_p(leaf_input.data_ptr()), C.c_void_p(x64.data_ptr()), B))
+            _lib.check(L.ccz_conv3x3_stem_f16(s, C.c_void_p(x64.data_ptr()), C.c_void_p(self.stem_w64.data_ptr()), C.c_void_p(self.stem_b32.data_ptr()),
+                                              C.c_void_p(y.data_ptr()), B * 90, 1))
+            return y
+        rows, n_rows = plan
+        # rows past the live ones are never computed: they must still hold finite numbers for the heads' GEMMs (whose results
+        # for those rows nobody reads). Two persistent buffers, zeroed ONCE: whatever a row holds later is an old finite result.
+        bufs = self.__dict__.setdefault("_plan_bufs", {})
+        key = (B, leaf_input.device)
+        if key not in bufs:
+            bufs[key] = (torch.zeros((B, 90, 64), dtype=torch.float16, device=leaf_input.device),
+                         torch.zeros((B, 256, 10, 9), dtype=torch.float16, device=leaf_input.device, memory_format=torch.channels_last))
+        x64, y = bufs[key]
+        _lib.check(L.ccz_pack_live_planes_rows_f16(s, C.c_void_p(leaf_input.data_ptr()), C.c_void_p(x64.data_ptr()), B,
+                                                   C.c_void_p(rows.data_ptr()), C.c_void_p(n_rows.data_ptr())))
+        _lib.check(L.ccz_conv3x3_stem_f16_live(s, C.c_void_p(x64.data_ptr()), C.c_void_p(self.stem_w64.data_ptr()), C.c_void_p(self.stem_b32.data_ptr()),
+                                               C.c_void_p(y.data_ptr()), B * 90, 1, C.c_void_p(n_rows.data_ptr()), 0))
         return y
 
     @torch.no_grad()
-    def forward(self, leaf_input: torch.Tensor, return_logits: bool = False):
+    def forward(self, leaf_input: torch.Tensor, return_logits: bool = False, plan=None):
+        """``plan`` = (rows int32 [B], n_rows int32 [1]) device tensors of the planned evaluator boundary (``ccz_eval_plan``):
+        outputs are COMPACT -- row i is the evaluation of board rows[i], for i < n_rows; the other rows are unspecified. On the
+        fused path only the live rows are computed; elsewhere the rows are gathered and the whole batch is evaluated."""
         B = leaf_input.shape[0]
-        if (hasattr(self, "stem_w64") and leaf_input.is_cuda and leaf_input.dtype == torch.float16 and leaf_input.is_contiguous()
+        fused_ok = (hasattr(self, "stem_w64") and leaf_input.is_cuda and leaf_input.dtype == torch.float16 and leaf_input.is_contiguous()
+                    and B >= self.FUSED_MIN_BOARDS and self.dtype == torch.float16 and os.environ.get("CCZ_FUSED_CONV", "1") != "0"
+                    and os.environ.get("CCZ_FUSED_STEM", "1") != "0" and self.stem_w64.shape[0] == 256)
+        if plan is not None and not fused_ok:
+            leaf_input = leaf_input.index_select(0, plan[0].long().clamp_(0, B - 1))
+            plan = None
+        tower_done = False
+        if plan is not None:
+            x = self._tower_fused(self._stem_fused(leaf_input, plan), plan)
+            tower_done = True
+        elif (hasattr(self, "stem_w64") and leaf_input.is_cuda and leaf_input.dtype == torch.float16 and leaf_input.is_contiguous()
                 and B >= self.FUSED_MIN_BOARDS and self.dtype == torch.float16 and os.environ.get("CCZ_FUSED_CONV", "1") != "0"
                 and os.environ.get("CCZ_FUSED_STEM", "1") != "0"):
             x = self._stem_fused(leaf_input)
@@ -261,7 +299,9 @@ class InferenceNet(nn.Module):
                 x = torch.cat([x[:, 49:56], x[:, 105:119]], dim=1)
             x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
             x = self._epilogue(F.conv2d(x, self.stem_w, None, padding=1), self.stem_b)
-        if self._use_fused_tower(x):
+        if tower_done:
+            pass
+        elif self._use_fused_tower(x):
             x = self._tower_fused(x)
         else:
             if x.is_cuda and x.dtype == torch.float16 and os.environ.get("CCZ_FUSED_CONV", "1") != "0":
@@ -338,19 +378,21 @@ class PolicyValueNet:
     evaluate_leaves.graph_safe = True   # static shapes, no host sync: may be captured into a hipGraph
 
     @torch.no_grad()
-    def evaluate_leaves_logits(self, leaf_input: torch.Tensor):
+    def evaluate_leaves_logits(self, leaf_input: torch.Tensor, plan=None):
         """Same as :meth:`evaluate_leaves` but returns the policy head's logits ([B,2086], fp16 on the GPU): the
-        engine's ``ccz_step_logits`` turns them into priors of the legal moves only."""
+        engine's ``ccz_step_logits`` turns them into priors of the legal moves only. ``plan``: the planned boundary of an engine
+        with an evaluation cache (``SelfPlayEngine.eval_plan()``): only the planned rows are computed, outputs are compact."""
         if self._infer is None:
             self.refresh_inference_copy()
         if os.environ.get("CCZ_MIOPEN_FIND", "1") == "0":
-            return self._infer(leaf_input, return_logits=True)
+            return self._infer(leaf_input, return_logits=True, plan=plan)
         with torch.backends.cudnn.flags(enabled=True, benchmark=True):
-            return self._infer(leaf_input, return_logits=True)
+            return self._infer(leaf_input, return_logits=True, plan=plan)
 
     evaluate_leaves_logits.batched = True
     evaluate_leaves_logits.graph_safe = True
     evaluate_leaves_logits.returns_logits = True
+    evaluate_leaves_logits.accepts_plan = True
 
     # ---- reference surface --------------------------------------------------------------------
     def policy_value(self, state_batch):

@@ -95,11 +95,32 @@ class BatchedSelfPlay:
         self.rngs = [np.random.RandomState((seed + board_id_base + b) % (2**32)) for b in range(n_boards)] if sampling == "numpy" else None
         self.use_graph = use_graph
         self._graph = None
+        # planned evaluator boundary: the engine holds an evaluation cache (eval_cache_log2 > 0) and the evaluator can compute a
+        # planned subset of the rows (PolicyValueNet.evaluate_leaves_logits): positions evaluated before are not sent through
+        # the network again (include/cczero.h ccz_eval_plan). Same results, bit for bit.
+        self.planned = bool(self.engine.eval_cache_log2 > 0 and getattr(evaluator, "accepts_plan", False)
+                            and getattr(evaluator, "returns_logits", False))
+        self._cache_version = self._evaluator_version()
+
+    def _evaluator_version(self):
+        return getattr(getattr(self.evaluator, "__self__", None), "weights_version", None)
+
+    def _planned_eval(self, leaf):
+        """(logits, value) of the planned rows; cached evaluations of other weights are dropped first."""
+        e = self.engine
+        v = self._evaluator_version()
+        if v != self._cache_version:
+            e.clear_eval_cache()
+            self._cache_version = v
+        return self.evaluator(leaf, plan=e.eval_plan())
 
     # one lockstep simulation of every board
     def simulate(self):
         e = self.engine
         leaf = e.select_leaves()
+        if self.planned:
+            e.expand_backup_planned(*self._planned_eval(leaf))
+            return
         prob, value = self.evaluator(leaf)
         (e.expand_backup_logits if getattr(self.evaluator, "returns_logits", False) else e.expand_backup)(prob, value)
 
@@ -111,13 +132,18 @@ class BatchedSelfPlay:
         interval = max(1, self.n_playout // 100)
         acc = 0
         leaf = e.select_leaves()
-        if self.use_graph and self._graph is None:
+        if self.use_graph and self._graph is None and not self.planned:
             self._graph = GraphedStep(e, self.evaluator)
         logits = getattr(self.evaluator, "returns_logits", False)
         step = e.step_logits if logits else e.step
         last = e.expand_backup_logits if logits else e.expand_backup
         for i in range(self.n_playout):
-            if i + 1 < self.n_playout:
+            if self.planned:
+                if i + 1 < self.n_playout:
+                    leaf = e.step_planned(*self._planned_eval(leaf))
+                else:
+                    e.expand_backup_planned(*self._planned_eval(leaf))
+            elif i + 1 < self.n_playout:
                 if self._graph is not None:
                     self._graph.replay()
                 else:

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define CCZ_ABI_VERSION 2
+#define CCZ_ABI_VERSION 3
 #define CCZ_NSQ 90
 #define CCZ_SQ_STRIDE 96            /* mailbox row stride in bytes (90 squares + 6 pad)         */
 #define CCZ_NMOVES 2086             /* action space, reference tools.py:172-272                 */
@@ -114,7 +114,7 @@ typedef struct ccz_config {
     const uint16_t *move_rank_host;
     uint8_t plane_of_type[8];
     uint32_t rule_flags;   /* CCZ_RULE_*                                                         */
-    uint32_t reserved0;
+    uint32_t eval_cache_log2; /* 0 = none; n = an evaluation cache of 2^n entries of 528 B (ABI 3): see ccz_eval_plan */
     uint8_t type_rank[8];
 } ccz_config;
 
@@ -134,6 +134,11 @@ typedef struct ccz_stats {
     int64_t hbm_bytes;       /* device memory held by the engine                                 */
     int64_t pruned_subtrees; /* nodes whose children were dropped at re-root time to keep the kept
                                 subtree within the pool budget (0 in normal runs)                 */
+    /* evaluation cache (ABI 3; all zero without one) */
+    int64_t cache_probes;      /* leaves that needed an evaluation                                */
+    int64_t cache_hits;        /* ... served from the cache                                       */
+    int64_t cache_shared_rows; /* ... served by the evaluator row of another board of the same step (same position) */
+    int64_t cache_stores;      /* entries written                                                 */
 } ccz_stats;
 
 #define CCZ_ERR_NODE_POOL 1   /* a board ran out of tree nodes (raise max_nodes)                 */
@@ -201,6 +206,27 @@ int ccz_step(ccz_engine *e, void *stream, const float *prob_dev, const float *va
 int ccz_gather_priors(ccz_engine *e, void *stream, const void *logits_dev, int32_t logits_f16);
 int ccz_step_compact(ccz_engine *e, void *stream, const float *value_dev, void *leaf_input_f16_dev);
 int ccz_expand_backup_compact(ccz_engine *e, void *stream, const float *value_dev);
+
+/* Evaluation cache (ccz_config.eval_cache_log2 > 0). On the search path the evaluator sees the leaf POSITION and the side to move
+ * only (net.py:160-173: the history planes are zero; mcts.py:214 passes none), i.e. a function of the leaf's Zobrist key. The
+ * reference evaluates every leaf on its own (mcts.py:114); here a position that was evaluated before -- by this board (a
+ * transposition), by another board (every restarted game walks through openings that earlier games searched), or by another
+ * board in this very step -- is not sent through the network again. Results are unchanged bit for bit as long as the evaluator is
+ * a deterministic function of the position that does not depend on the row it sits in (tests/test_gpu_evaluator_depth.py).
+ *   ccz_eval_plan: probes the direct-mapped table (2^n entries: key, value, the priors of the legal moves) for every pending
+ *     leaf that needs an evaluation; hits receive their priors and value at once. The misses are deduplicated (boards with the
+ *     same key share one row) and compacted: miss_rows_dev int32 [B] receives the board index of every row the evaluator has to
+ *     compute, ascending; *n_miss_dev (int32 on the device) their number. No host sync.
+ *   The evaluator then runs on those rows only: ccz_pack_live_planes_rows_f16 gathers them, the ccz_conv3x3_*_live entry points
+ *     skip the tiles beyond the live rows; logits / values come back COMPACT: row i belongs to board miss_rows_dev[i].
+ *   ccz_gather_priors_planned: ccz_gather_priors for the misses (each reads the row of its representative), and the fresh
+ *     evaluations are stored in the table. Afterwards ccz_step_compact / ccz_expand_backup_compact with value_dev == NULL use
+ *     the engine-owned leaf values (hits: from the table; misses: value_compact_dev[row]).
+ *   ccz_eval_cache_clear: forget everything (the evaluator's weights changed). */
+int ccz_eval_plan(ccz_engine *e, void *stream, int32_t *miss_rows_dev, int32_t *n_miss_dev);
+int ccz_gather_priors_planned(ccz_engine *e, void *stream, const void *logits_compact_dev, int32_t logits_f16,
+                              const float *value_compact_dev);
+int ccz_eval_cache_clear(ccz_engine *e, void *stream);
 
 /* ---- once per move ------------------------------------------------------------------------ */
 /* Replaces MCTS.get_move_probs' tail (mcts.py:162-166), MCTS_AI.get_action's choice
@@ -332,6 +358,19 @@ int ccz_conv3x3_stem_f16(void *stream, const void *x64_dev, const void *w_dev, c
  * -> NHWC rows of 64 channels: planes 49..55 (group 7), 105..118 (groups 15, 16), then zeros (net.py:160-173 leaves
  * every other group zero on the search path). */
 int ccz_pack_live_planes_f16(void *stream, const void *leaf_dev, void *x64_dev, int32_t n_boards);
+
+/* The same three for the planned evaluator boundary (ccz_eval_plan): the number of rows to compute is a DEVICE value, so that
+ * no host sync stands between the plan and the evaluator. ccz_pack_live_planes_rows_f16: output row i = board rows_dev[i] for
+ * i < *n_rows_dev (the rest is left alone). The *_live convolutions: this launch covers boards row0 .. row0 + n_pixels / 90 of a
+ * batch of which only the first *live_rows_dev boards are live; the grid is sized for n_pixels, tiles past the live rows exit at
+ * once, the last live tile may be partial. */
+int ccz_pack_live_planes_rows_f16(void *stream, const void *leaf_dev, void *x64_dev, int32_t n_boards,
+                                  const int32_t *rows_dev, const int32_t *n_rows_dev);
+int ccz_conv3x3_c256_f16_live(void *stream, const void *x_dev, const void *w_dev, const void *bias_f32_dev,
+                              const void *residual_dev, void *y_dev, int64_t n_pixels, int32_t relu,
+                              const int32_t *live_rows_dev, int32_t row0);
+int ccz_conv3x3_stem_f16_live(void *stream, const void *x64_dev, const void *w_dev, const void *bias_f32_dev,
+                              void *y_dev, int64_t n_pixels, int32_t relu, const int32_t *live_rows_dev, int32_t row0);
 
 #ifdef __cplusplus
 }
