@@ -265,7 +265,7 @@ class InferenceNet(nn.Module):
         key = (B, leaf_input.device)
         if key not in bufs:
             bufs[key] = (torch.zeros((B, 90, 64), dtype=torch.float16, device=leaf_input.device),
-                         torch.zeros((B, 256, 10, 9), dtype=torch.float16, device=leaf_input.device, memory_format=torch.channels_last))
+                         torch.empty((B, 256, 10, 9), dtype=torch.float16, device=leaf_input.device, memory_format=torch.channels_last).zero_())
         x64, y = bufs[key]
         _lib.check(L.ccz_pack_live_planes_rows_f16(s, C.c_void_p(leaf_input.data_ptr()), C.c_void_p(x64.data_ptr()), B,
                                                    C.c_void_p(rows.data_ptr()), C.c_void_p(n_rows.data_ptr())))
