@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--eval-cache-log2", type=int, default=22, help="evaluation cache of 2^n positions (528 B each; 0 = none): leaves whose "
                     "position was evaluated before -- by this board, another board, or another board of the same step -- skip the "
                     "network (the reference evaluates every leaf, mcts.py:114; results are identical bit for bit)")
+    ap.add_argument("--warm-moves", type=int, default=2, help="untimed setup: full moves searched with the real evaluator before the "
+                    "alignment steps, so that the timed window sees the evaluation cache as continuous self-play leaves it (restarted "
+                    "games walking through openings that earlier games searched) instead of a cold table; 0 = none")
     ap.add_argument("--value-f16", action="store_true", help="accumulate Q in float16 as the reference's CUDA path does (CCZ_FLAG_VALUE_F16, "
                     "net.py:178-189 -> mcts.py:63-71); default: float32, its CPU path")
     return ap.parse_args()
@@ -363,6 +366,8 @@ def main():
     t_setup = time.perf_counter()
     if a.preroll_plies > 0:
         preroll(e, a.preroll_plies, stagger=True)
+    if a.evaluator == "net" and planned[0]:
+        run(a.warm_moves * n, False)   # whole moves, boundaries included: trees, games and the evaluation cache in steady state
     st_pre = e.game_status()
     half = min(a.steps, n) // 2
     phase = (n - half - a.warmup) % n if a.align else 0
@@ -376,7 +381,7 @@ def main():
             e.expand_backup(*uniform_evaluator(state["leaf"]))
             state["leaf"] = None
             step_no[0] += 1
-        assert step_no[0] == phase
+        assert step_no[0] % n == phase
         evaluator, logits_in = real, bool(getattr(real, "returns_logits", False))
     else:
         run(phase, False)
@@ -499,6 +504,8 @@ def main():
         net_desc = f"random-init {a.blocks}x{a.channels} policy-value net fp16" if a.evaluator == "net" else "stub evaluator (uniform priors, v=0)"
         state_desc = (f"boards in steady state (plies 1..{a.preroll_plies} of their games, evenly; games adjudicated at {a.max_plies} plies)"
                       if a.preroll_plies > 0 else "all boards from the opening position")
+        if planned[0]:
+            state_desc += f", evaluation cache of 2^{e.eval_cache_log2} positions warmed by {a.warm_moves} untimed moves"
         out = {
             "metric": "self-play MCTS simulations/sec", "value": value, "unit": "sims/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
@@ -506,7 +513,7 @@ def main():
             "dtype": "u8 rules / f32 Q / f64 PUCT (net: fp16)", "data": "synthetic",
             "config": {"workload": f"{B} concurrent boards/GPU x {n} sims/move, Dirichlet root noise on (device Philox), " + net_desc + ", " + state_desc,
                        "boards_per_gpu": B, "sims_per_move": n, "evaluator": a.evaluator,
-                       "preroll_plies": a.preroll_plies, "max_plies": a.max_plies,
+                       "preroll_plies": a.preroll_plies, "max_plies": a.max_plies, "warm_moves": a.warm_moves if planned[0] else 0,
                        "window": f"{a.steps} steps starting at simulation {phase + a.warmup} of a move: "
                                  f"{boundary['n']} move boundary(ies) inside the timed window"},
             "moves_per_sec": moves_per_sec,

@@ -21,7 +21,8 @@ max_plies = int(sys.argv[4]) if len(sys.argv) > 4 else 200
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 pvn = PolicyValueNet(device=dev)
-sp = BatchedSelfPlay(pvn.evaluate_leaves_logits, B, n_playout=n, seed=0, max_plies=max_plies)
+cache_log2 = int(os.environ.get("CCZ_EVAL_CACHE_LOG2", "22"))
+sp = BatchedSelfPlay(pvn.evaluate_leaves_logits, B, n_playout=n, seed=0, max_plies=max_plies, eval_cache_log2=cache_log2)
 e = sp.engine
 rows = games = decisive = truncated = 0
 lengths = []
@@ -55,5 +56,8 @@ out = {"boards": B, "sims_per_move": n, "moves_played_per_board": moves, "wall_s
        "min_game_plies": int(min(lengths)) if lengths else None, "error_flags": st["error_flags"],
        "nodes_peak": st["nodes_peak"], "depth_peak": st["depth_peak"], "k_bar": st["sum_children"] / max(1, st["expansions"]),
        "d_bar": st["sum_depth"] / max(1, st["sims"]), "terminal_leaf_share": st["terminal_leaves"] / max(1, st["sims"]),
-       "max_plies_cap": max_plies}
+       "max_plies_cap": max_plies,
+       "eval_cache": {"entries_log2": cache_log2, "leaves_needing_the_net": st["cache_probes"], "hits": st["cache_hits"],
+                      "served_by_another_boards_row": st["cache_shared_rows"], "stores": st["cache_stores"],
+                      "fraction_skipped": (st["cache_hits"] + st["cache_shared_rows"]) / max(1, st["cache_probes"])} if cache_log2 else None}
 print(json.dumps(out))
