@@ -64,7 +64,7 @@ def parse():
                     "one move of 4096 boards finishes ~14 k plies = ~28 k dense rows)")
     ap.add_argument("--replay-rows", type=int, default=0, help="N>1 / trainer: rows of the dense replay ring every rank keeps in HBM "
                     "(0 = 40,000 x world size: more than one move's rows of all ranks)")
-    ap.add_argument("--eval-cache-log2", type=int, default=22, help="evaluation cache of 2^n positions (528 B each; 0 = none): leaves whose "
+    ap.add_argument("--eval-cache-log2", type=int, default=24, help="evaluation cache of 2^n positions (528 B each; 0 = none): leaves whose "
                     "position was evaluated before -- by this board, another board, or another board of the same step -- skip the "
                     "network (the reference evaluates every leaf, mcts.py:114; results are identical bit for bit)")
     ap.add_argument("--warm-moves", type=int, default=2, help="untimed setup: full moves searched with the real evaluator before the "

@@ -420,7 +420,7 @@ class CollectPipeline:
             # compact evaluator boundary (logits in, the engine gathers the legal priors) and, on the fused evaluator path (>= 192
             # boards), the evaluation cache: positions evaluated before skip the network (same results)
             self.selfplay = BatchedSelfPlay(self.policy_value_net.evaluate_leaves_logits, self.n_boards, n_playout=self.n_playout,
-                                            eval_cache_log2=22 if self.n_boards >= 192 else 0,
+                                            eval_cache_log2=24 if self.n_boards >= 192 else 0,
                                             c_puct=self.c_puct, temp=self.temp, seed=self.seed, board_id_base=rank * self.n_boards,
                                             device=self.device, reference_quirks=self.reference_quirks, max_plies=self.max_plies)
             if getattr(self, "_viewer", None) is not None:

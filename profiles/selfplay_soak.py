@@ -21,7 +21,7 @@ max_plies = int(sys.argv[4]) if len(sys.argv) > 4 else 200
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 pvn = PolicyValueNet(device=dev)
-cache_log2 = int(os.environ.get("CCZ_EVAL_CACHE_LOG2", "22"))
+cache_log2 = int(os.environ.get("CCZ_EVAL_CACHE_LOG2", "24"))
 sp = BatchedSelfPlay(pvn.evaluate_leaves_logits, B, n_playout=n, seed=0, max_plies=max_plies, eval_cache_log2=cache_log2)
 e = sp.engine
 rows = games = decisive = truncated = 0
