@@ -344,6 +344,11 @@ class PolicyValueNet:
                                           eps=1e-8, weight_decay=self.l2_const)
         if model:
             self.policy_value_net.load_state_dict(torch.load(model, map_location=self.device))
+            # the planes a trained net expects follow cchess's PIECE_TYPES numbering, which cannot be read in this image:
+            # say which rule preset the encoders use (never switched silently)
+            from . import tools
+            tools.log(f"weights loaded from {model}: piece planes and legal-move order follow rule preset '{tools.PRESET}' "
+                      "(reference-trained weights: try tools.set_rules(preset='python-chess-lineage') [unverified] if this one plays nonsense)")
         self._infer = None
         self._graph = None
         self.weights_version = 0  # bumped whenever the inference copy is rebuilt or invalidated (hipGraphs hold its addresses)

@@ -23,6 +23,10 @@ def main():
     out_dir, tag = sys.argv[1], sys.argv[2]
     root = os.path.dirname(os.path.abspath(__file__))
     summary = {}
+    prev = os.path.join(root, f"{tag}_summary.json")
+    if os.path.exists(prev):   # the passes may come from several gpurun calls (the box does not persist): merge into what is there
+        with open(prev) as f:
+            summary = json.load(f)
     stats = find(os.path.join(out_dir, "trace"), "*kernel_stats.csv")
     if stats:
         rows = list(csv.DictReader(open(stats)))
