@@ -801,17 +801,17 @@ int ccz_conv3x3_stem_f16(void *stream, const void *x64_dev, const void *w_dev, c
 }
 
 int ccz_conv3x3_c256_f16_live(void *stream, const void *x_dev, const void *w_dev, const void *bias_f32_dev, const void *residual_dev, void *y_dev,
-                              int64_t n_pixels, int32_t relu, const int32_t *live_rows_dev, int32_t row0)
+                              int64_t n_pixels, int32_t relu, const int32_t *live_rows_dev, int32_t part, int32_t n_parts)
 {
-    if (!live_rows_dev || row0 < 0) return fail(-1, "ccz_conv3x3_c256_f16_live: null live-row count or negative row0");
-    return conv3x3_launch("ccz_conv3x3_c256_f16_live", stream, x_dev, w_dev, bias_f32_dev, residual_dev, y_dev, n_pixels, relu, 256, live_rows_dev, row0);
+    if (!live_rows_dev || n_parts < 1 || n_parts > 256 || part < 0 || part >= n_parts) return fail(-1, "ccz_conv3x3_c256_f16_live: null live-row count or bad part / n_parts");
+    return conv3x3_launch("ccz_conv3x3_c256_f16_live", stream, x_dev, w_dev, bias_f32_dev, residual_dev, y_dev, n_pixels, relu, 256, live_rows_dev, part | (n_parts << 16));
 }
 
 int ccz_conv3x3_stem_f16_live(void *stream, const void *x64_dev, const void *w_dev, const void *bias_f32_dev, void *y_dev, int64_t n_pixels, int32_t relu,
-                              const int32_t *live_rows_dev, int32_t row0)
+                              const int32_t *live_rows_dev, int32_t part, int32_t n_parts)
 {
-    if (!live_rows_dev || row0 < 0) return fail(-1, "ccz_conv3x3_stem_f16_live: null live-row count or negative row0");
-    return conv3x3_launch("ccz_conv3x3_stem_f16_live", stream, x64_dev, w_dev, bias_f32_dev, nullptr, y_dev, n_pixels, relu, 64, live_rows_dev, row0);
+    if (!live_rows_dev || n_parts < 1 || n_parts > 256 || part < 0 || part >= n_parts) return fail(-1, "ccz_conv3x3_stem_f16_live: null live-row count or bad part / n_parts");
+    return conv3x3_launch("ccz_conv3x3_stem_f16_live", stream, x64_dev, w_dev, bias_f32_dev, nullptr, y_dev, n_pixels, relu, 64, live_rows_dev, part | (n_parts << 16));
 }
 
 int ccz_pack_live_planes_rows_f16(void *stream, const void *leaf_dev, void *x64_dev, int32_t n_boards, const int32_t *rows_dev, const int32_t *n_rows_dev)

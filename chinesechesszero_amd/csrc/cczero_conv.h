@@ -227,14 +227,24 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict
     const int wm = w >> 2, wn = w & 3;
     int tiles = gridDim.x;
     if (live_rows) {
-        // Planned evaluator boundary (ccz_eval_plan): only the first *live_rows boards of the batch hold rows to compute; this
-        // launch covers boards row0 .. row0 + M / 90 of it. The grid is sized for the whole range (no host sync on the count);
-        // workgroups beyond the live tiles leave at once.
-        int live = *live_rows - row0;
-        live = live < 0 ? 0 : (live > M / 90 ? M / 90 : live);
+        // Planned evaluator boundary (ccz_eval_plan): only the first *live_rows boards of the batch hold rows to compute, a
+        // number that stays on the device. The batch is cut into n_parts EQUAL ranges of the LIVE rows (multiples of 8 boards;
+        // the last tile of a range is partial); this launch is range `part` of them (the argument carries part | n_parts << 16)
+        // and finds its boards itself. The grid is sized for the largest possible range; workgroups beyond the live tiles leave at once.
+        const int part = row0 & 0xffff, n_parts = row0 >> 16;
+        const int L = *live_rows;
+        const int per = ((L + n_parts - 1) / n_parts + 7) / 8 * 8;
+        const int first = part * per;
+        int live = L - first;
+        live = live < 0 ? 0 : (live > per ? per : live);
+        live = live > M / 90 ? M / 90 : live;
         M = live * 90;
         tiles = (M + kCvBM - 1) / kCvBM;
         if ((int)blockIdx.x >= tiles) return;
+        const long off = (long)first * 90 * kCvC;
+        X += (long)first * 90 * cin;
+        Y += off;
+        if (RES) R += off;
     }
     // flags bit 1: tiles in descending order (the tiles written last by the previous layer are then read first)
     const long p0 = (long)((relu & 2) ? tiles - 1 - blockIdx.x : blockIdx.x) * kCvBM;

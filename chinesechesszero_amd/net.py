@@ -187,12 +187,54 @@ class InferenceNet(nn.Module):
         groups = int(os.environ.get("CCZ_TOWER_GROUPS", "0")) or -(-Bt // self.TOWER_GROUP_BOARDS)
         if torch.cuda.is_current_stream_capturing():
             groups = 1
+        if plan is not None:
+            self._tower_planned(L, C, x, y, plan, groups)
+            return x
         gstep = -(-(-(-Bt // groups)) // 128) * 128 if groups > 1 else Bt
         for g0 in range(0, Bt, gstep):
-            self._tower_range(L, C, x, y, g0, min(Bt, g0 + gstep), plan)
+            self._tower_range(L, C, x, y, g0, min(Bt, g0 + gstep))
         return x
 
-    def _tower_range(self, L, C, x, y, lo, hi, plan=None):
+    def _tower_planned(self, L, C, x, y, plan, groups):
+        """The tower on the LIVE rows of a planned batch (``ccz_eval_plan``): the live rows -- a device-side count -- are cut
+        into groups x chains EQUAL ranges by the kernel itself (``ccz_conv3x3_c256_f16_live``: part / n_parts), so that the
+        concurrent chains of a group stay balanced whatever the live count is. Launch structure as in :meth:`_tower_range`:
+        groups one after the other (Infinity-Cache residency), the chains of a group on separate streams."""
+        from . import _lib
+        B = x.shape[0]
+        cur = torch.cuda.current_stream(x.device)
+        want = int(os.environ.get("CCZ_TOWER_CHAINS", self.TOWER_CHAINS))
+        per_group = -(-B // groups)
+        chains = 1 if torch.cuda.is_current_stream_capturing() else max(1, min(want, 8, per_group // 256))
+        n_parts = groups * chains
+        cap = -(-(-(-B // n_parts)) // 8) * 8 * 90           # pixels of the largest range a launch may get
+        if chains > 1:
+            pool = getattr(self, "_chain_streams", None)
+            if pool is None or pool[0] != x.device or len(pool[1]) < chains - 1:
+                pool = (x.device, [torch.cuda.Stream(device=x.device) for _ in range(7)])
+                self._chain_streams = pool
+        live = C.c_void_p(plan[1].data_ptr())
+        xp, yp = C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr())
+        down = 2 if os.environ.get("CCZ_CONV_ZIGZAG", "1") == "1" else 0
+        for g in range(groups):
+            streams = [cur] + [self._chain_streams[1][k] for k in range(chains - 1)]
+            if chains > 1:
+                fork = torch.cuda.Event()
+                fork.record(cur)
+                for st in streams[1:]:
+                    st.wait_event(fork)
+            for i in range(0, len(self.ws), 2):
+                w1, b1_, w2, b2_ = (C.c_void_p(t.data_ptr()) for t in (self.ws[i], self.bs32[i], self.ws[i + 1], self.bs32[i + 1]))
+                for k, st in enumerate(streams):
+                    _lib.check(L.ccz_conv3x3_c256_f16_live(C.c_void_p(st.cuda_stream), xp, w1, b1_, None, yp, cap, 1 | down, live, g * chains + k, n_parts))
+                for k, st in enumerate(streams):
+                    _lib.check(L.ccz_conv3x3_c256_f16_live(C.c_void_p(st.cuda_stream), yp, w2, b2_, xp, xp, cap, 1, live, g * chains + k, n_parts))
+            for st in streams[1:]:
+                join = torch.cuda.Event()
+                join.record(st)
+                cur.wait_event(join)
+
+    def _tower_range(self, L, C, x, y, lo, hi):
         """Boards [lo, hi) through all 80 layers, as TOWER_CHAINS concurrent launch chains."""
         from . import _lib
         B = hi - lo
@@ -224,19 +266,12 @@ class InferenceNet(nn.Module):
         down = 2 if os.environ.get("CCZ_CONV_ZIGZAG", "1") == "1" else 0
         v2 = 4 if os.environ.get("CCZ_CONV_V2", "0") == "1" else 0  # A/B only: the experimental two-workgroups-per-CU form
         # (cczero_conv2.h, compiled into diagnostic builds with -DCCZ_CONV2; the shipped library ignores the bit)
-        live = None if plan is None else C.c_void_p(plan[1].data_ptr())
         for i in range(0, len(self.ws), 2):
             w1, b1_, w2, b2_ = (C.c_void_p(t.data_ptr()) for t in (self.ws[i], self.bs32[i], self.ws[i + 1], self.bs32[i + 1]))
-            if live is None:
-                for _, s, xp, yp, n_pixels, _b0 in chains:
-                    _lib.check(L.ccz_conv3x3_c256_f16(s, xp, w1, b1_, None, yp, n_pixels, 1 | down | v2))
-                for _, s, xp, yp, n_pixels, _b0 in chains:
-                    _lib.check(L.ccz_conv3x3_c256_f16(s, yp, w2, b2_, xp, xp, n_pixels, 1 | v2))  # output written over the residual input
-            else:  # the same launches, each told where its board range starts in the compacted batch
-                for _, s, xp, yp, n_pixels, b0 in chains:
-                    _lib.check(L.ccz_conv3x3_c256_f16_live(s, xp, w1, b1_, None, yp, n_pixels, 1 | down, live, b0))
-                for _, s, xp, yp, n_pixels, b0 in chains:
-                    _lib.check(L.ccz_conv3x3_c256_f16_live(s, yp, w2, b2_, xp, xp, n_pixels, 1, live, b0))
+            for _, s, xp, yp, n_pixels, _b0 in chains:
+                _lib.check(L.ccz_conv3x3_c256_f16(s, xp, w1, b1_, None, yp, n_pixels, 1 | down | v2))
+            for _, s, xp, yp, n_pixels, _b0 in chains:
+                _lib.check(L.ccz_conv3x3_c256_f16(s, yp, w2, b2_, xp, xp, n_pixels, 1 | v2))  # output written over the residual input
         for st, *_ in chains[1:]:  # every side stream is joined into the current stream
             join = torch.cuda.Event()
             join.record(st)
@@ -270,7 +305,7 @@ class InferenceNet(nn.Module):
         _lib.check(L.ccz_pack_live_planes_rows_f16(s, C.c_void_p(leaf_input.data_ptr()), C.c_void_p(x64.data_ptr()), B,
                                                    C.c_void_p(rows.data_ptr()), C.c_void_p(n_rows.data_ptr())))
         _lib.check(L.ccz_conv3x3_stem_f16_live(s, C.c_void_p(x64.data_ptr()), C.c_void_p(self.stem_w64.data_ptr()), C.c_void_p(self.stem_b32.data_ptr()),
-                                               C.c_void_p(y.data_ptr()), B * 90, 1, C.c_void_p(n_rows.data_ptr()), 0))
+                                               C.c_void_p(y.data_ptr()), -(-B // 8) * 8 * 90, 1, C.c_void_p(n_rows.data_ptr()), 0, 1))
         return y
 
     @torch.no_grad()

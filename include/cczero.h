@@ -361,16 +361,19 @@ int ccz_pack_live_planes_f16(void *stream, const void *leaf_dev, void *x64_dev, 
 
 /* The same three for the planned evaluator boundary (ccz_eval_plan): the number of rows to compute is a DEVICE value, so that
  * no host sync stands between the plan and the evaluator. ccz_pack_live_planes_rows_f16: output row i = board rows_dev[i] for
- * i < *n_rows_dev (the rest is left alone). The *_live convolutions: this launch covers boards row0 .. row0 + n_pixels / 90 of a
- * batch of which only the first *live_rows_dev boards are live; the grid is sized for n_pixels, tiles past the live rows exit at
- * once, the last live tile may be partial. */
+ * i < *n_rows_dev (the rest is left alone). The *_live convolutions take the pointers of the WHOLE batch: the first *live_rows_dev
+ * boards are live and are cut into n_parts equal ranges (multiples of 8 boards) of which this launch computes range `part` -- so
+ * that concurrent launch chains stay balanced whatever the live count is; n_pixels = the largest range a launch may get
+ * (ceil(boards / n_parts) rounded up to 8 boards, x 90): the grid is sized for it, tiles past the live rows exit at once, the
+ * last live tile may be partial. */
 int ccz_pack_live_planes_rows_f16(void *stream, const void *leaf_dev, void *x64_dev, int32_t n_boards,
                                   const int32_t *rows_dev, const int32_t *n_rows_dev);
 int ccz_conv3x3_c256_f16_live(void *stream, const void *x_dev, const void *w_dev, const void *bias_f32_dev,
                               const void *residual_dev, void *y_dev, int64_t n_pixels, int32_t relu,
-                              const int32_t *live_rows_dev, int32_t row0);
+                              const int32_t *live_rows_dev, int32_t part, int32_t n_parts);
 int ccz_conv3x3_stem_f16_live(void *stream, const void *x64_dev, const void *w_dev, const void *bias_f32_dev,
-                              void *y_dev, int64_t n_pixels, int32_t relu, const int32_t *live_rows_dev, int32_t row0);
+                              void *y_dev, int64_t n_pixels, int32_t relu, const int32_t *live_rows_dev,
+                              int32_t part, int32_t n_parts);
 
 #ifdef __cplusplus
 }
