@@ -151,8 +151,10 @@ class InferenceNet(nn.Module):
             y = y + residual
         return F.relu_(y)
 
-    FUSED_MIN_BOARDS = 192  # below this the 256-pixel tiles of the fused kernel leave most of the chip idle (eager evaluator,
-    # profiles/evaluator_crossover.py: 128 boards MIOpen 3.69 ms vs fused 3.96; 256 boards 4.43 vs 3.99; <= 64 both ~3.85, host-bound)
+    FUSED_MIN_BOARDS = 1  # every batch runs on the hand-written convolution: up to 96 boards on k_conv3x3_small (one wave per
+    # 16 x 16 NT block, spread over the chip), above that on the 256-pixel tiles of k_conv3x3_c256 -- bit-identical results, so a
+    # board's tower activations do not depend on the batch size. (Round 2 sent batches under 192 boards to MIOpen + an epilogue
+    # pass: 12.1 us per tower layer at one board, profiles/r03_single_board.json.)
 
     def _use_fused_tower(self, x) -> bool:
         """The hand-written MFMA convolution (libcczero ccz_conv3x3_c256_f16) covers the tower's shape only:
@@ -266,6 +268,7 @@ class InferenceNet(nn.Module):
         down = 2 if os.environ.get("CCZ_CONV_ZIGZAG", "1") == "1" else 0
         v2 = 4 if os.environ.get("CCZ_CONV_V2", "0") == "1" else 0  # A/B only: the experimental two-workgroups-per-CU form
         # (cczero_conv2.h, compiled into diagnostic builds with -DCCZ_CONV2; the shipped library ignores the bit)
+        v2 |= self._force_flag()
         for i in range(0, len(self.ws), 2):
             w1, b1_, w2, b2_ = (C.c_void_p(t.data_ptr()) for t in (self.ws[i], self.bs32[i], self.ws[i + 1], self.bs32[i + 1]))
             for _, s, xp, yp, n_pixels, _b0 in chains:
@@ -276,6 +279,12 @@ class InferenceNet(nn.Module):
             join = torch.cuda.Event()
             join.record(st)
             cur.wait_event(join)
+
+    @staticmethod
+    def _force_flag() -> int:
+        """A/B switch ``CCZ_CONV_FORCE=small|tile``: run every convolution on k_conv3x3_small / on the 256-pixel tile kernel
+        whatever the batch size (the library picks by batch size otherwise; the results are bit-identical either way)."""
+        return {"small": 16, "tile": 32}.get(os.environ.get("CCZ_CONV_FORCE", ""), 0)
 
     def _stem_fused(self, leaf_input, plan=None):
         """Stem on the same MFMA kernel: pack the 21 live planes as NHWC rows of 64 channels, then one 64-channel chunk of
@@ -291,7 +300,7 @@ class InferenceNet(nn.Module):
             y = torch.empty((B, 256, 10, 9), dtype=torch.float16, device=leaf_input.device, memory_format=torch.channels_last)
             _lib.check(L.ccz_pack_live_planes_f16(s, C.c_void_p(leaf_input.data_ptr()), C.c_void_p(x64.data_ptr()), B))
             _lib.check(L.ccz_conv3x3_stem_f16(s, C.c_void_p(x64.data_ptr()), C.c_void_p(self.stem_w64.data_ptr()), C.c_void_p(self.stem_b32.data_ptr()),
-                                              C.c_void_p(y.data_ptr()), B * 90, 1))
+                                              C.c_void_p(y.data_ptr()), B * 90, 1 | self._force_flag()))
             return y
         rows, n_rows = plan
         # rows past the live ones are never computed: they must still hold finite numbers for the heads' GEMMs (whose results
@@ -345,8 +354,8 @@ class InferenceNet(nn.Module):
                 if key not in seen:  # once per shape: the caller should know this batch does not run on the MFMA kernel
                     seen.add(key)
                     from .tools import log
-                    log(f"evaluator: batch of {key[0]} boards x {key[1]} channels is off the fused tower kernel "
-                        f"(k_conv3x3_c256 serves 256 channels at >= {self.FUSED_MIN_BOARDS} boards): MIOpen convolutions + one-pass epilogue")
+                    log(f"evaluator: batch of {key[0]} boards x {key[1]} channels is off the fused tower kernels "
+                        f"(k_conv3x3_c256 / k_conv3x3_small serve 256-channel towers): MIOpen convolutions + one-pass epilogue")
             for i in range(0, len(self.ws), 2):
                 y = self._epilogue(F.conv2d(x, self.ws[i], None, padding=1), self.bs[i])
                 x = self._epilogue(F.conv2d(y, self.ws[i + 1], None, padding=1), self.bs[i + 1], x)

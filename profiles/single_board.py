@@ -4,8 +4,9 @@ collect.py:133-143 calls the surface) -- VERDICT r02 item 7.
 Measures, with the full 40 x 256 net:
   * sims/s of ``MCTS_AI(n_playout=200).get_action`` through the host mirror (hipGraph replay of evaluator + k_step per playout),
   * the per-playout split: graph replay wall time, the evaluator alone (eager and replayed), the simulator kernel alone,
-  * the evaluator at batch 1 on the three tower paths: MIOpen + one-pass epilogue (what B < 192 takes), the MFMA tower kernel
-    forced on a single board (one 256-pixel tile on ONE compute unit), and for scale the same at 192 and 4096 boards,
+  * the evaluator by batch size on the tower paths: k_conv3x3_small (one wave per 16 x 16 NT block; what batches of up to 96
+    boards take), the 256-pixel tile kernel (a single board = one partial tile on ONE compute unit), MIOpen + one-pass epilogue
+    (what batches under 192 boards took until round 3),
 so that "is MIOpen at the launch floor at B = 1?" has a number: per-layer time against the ~1.2-1.5 us kernel boundary
 (MI355X_MICROARCH.md price list, row `boundary`) and the ~10-16 us graph-replay floor.
 
@@ -83,22 +84,25 @@ def main():
         t.add_(1.0)
     pieces["one_trivial_kernel_graph_replay_us"] = 1e6 * timed(empty.replay, 500)
     out["per_playout_pieces"] = pieces
-    launches = 1 + 2 * 80 + 2 + 1 + 3 + 3 + 2      # layout/stem conv+epilogue, 80 x (conv + epilogue), heads GEMM + relu, FCs, tanh, gather, k_step
+    launches = 2 + 80 + 2 + 1 + 3 + 3 + 2      # pack + stem, 80 tower convolutions, heads GEMM + relu, FCs, tanh, gather, k_step
     out["per_playout_pieces"]["kernels_per_playout_approx"] = launches
     out["per_playout_pieces"]["us_per_kernel_in_the_replayed_evaluator"] = pieces["evaluator_graph_replay_us"] / launches
 
     # ---- the evaluator by batch size and tower path (graph-replayed: launch overhead out of the picture)
     inf = pvn._infer
     rows = []
-    for B in (1, 8, 64, 191, 192, 1024, 4096):
+    for B in (1, 8, 32, 64, 96, 128, 192, 1024, 4096):
         x = torch.zeros((B, 17, 7, 10, 9), dtype=torch.float16, device=dev)
         x[:, 7] = (torch.rand((B, 7, 10, 9), device=dev) > 0.9).half()
         x[:, 16] = 1.0
-        for path in ("default", "mfma", "miopen"):
+        for path in ("default", "small", "tile", "miopen"):
             old_min, old_env = InferenceNet.FUSED_MIN_BOARDS, os.environ.get("CCZ_FUSED_CONV")
             try:
-                if path == "mfma":
-                    InferenceNet.FUSED_MIN_BOARDS = 1
+                os.environ.pop("CCZ_CONV_FORCE", None)
+                if path in ("small", "tile"):
+                    if path == "small" and B > 1024:
+                        continue
+                    os.environ["CCZ_CONV_FORCE"] = path
                 elif path == "miopen":
                     os.environ["CCZ_FUSED_CONV"] = "0"
                 with torch.backends.cudnn.flags(enabled=True, benchmark=True):
@@ -112,6 +116,7 @@ def main():
                 rows.append({"boards": B, "tower": path, "evaluator_us": us, "us_per_board": us / B, "us_per_tower_layer": us / 80})
             finally:
                 InferenceNet.FUSED_MIN_BOARDS = old_min
+                os.environ.pop("CCZ_CONV_FORCE", None)
                 if old_env is None:
                     os.environ.pop("CCZ_FUSED_CONV", None)
                 else:
@@ -120,8 +125,9 @@ def main():
     out["evaluator_by_batch"] = rows
     out["reference_python_on_8_cpu_cores_sims_per_sec"] = 30.0   # the reference's own mcts.py + net.py, fp32, build container
     b1 = {r["tower"]: r for r in rows if r["boards"] == 1}
-    out["reading"] = (f"batch 1: MIOpen path {b1['miopen']['evaluator_us']:.0f} us per evaluation = {b1['miopen']['us_per_tower_layer']:.1f} us per tower "
-                      f"layer (conv + epilogue = 2 launches); the MFMA tile kernel on one CU {b1['mfma']['evaluator_us']:.0f} us. "
+    out["reading"] = (f"batch 1: k_conv3x3_small {b1['small']['evaluator_us']:.0f} us per evaluation = {b1['small']['us_per_tower_layer']:.1f} us per tower layer; "
+                      f"MIOpen path {b1['miopen']['evaluator_us']:.0f} us = {b1['miopen']['us_per_tower_layer']:.1f} us per layer (conv + epilogue = 2 launches); "
+                      f"the 256-pixel tile kernel on one CU {b1['tile']['evaluator_us']:.0f} us. "
                       f"MCTS_AI at n_playout = 200: {out['mcts_ai_get_action']['sims_per_sec']:.0f} sims/s against 30 for the reference's Python on 8 cores.")
     print(json.dumps(out, indent=1))
 

@@ -31,21 +31,63 @@ def test_conv_kernel_matches_fp32_convolution(boards):
     b = (torch.randn(256, generator=g) * 0.2).to(dev)
     ref = F.conv2d(x.float(), w.float(), b, padding=1)
     for res, relu in ((None, 1), (r, 1), (None, 0), (r, 0)):
-        y = torch.full_like(x, float("nan"))
-        _conv(x, w, b, res, y, relu)
-        want = ref if res is None else ref + res.float()
-        if relu:
-            want = F.relu(want)
-        err = (y.float() - want).abs().max().item()
-        assert err < 4e-3 * max(1.0, want.abs().max().item()), (boards, res is not None, relu, err)
+        for force_tile in (0, 32):   # the kernel the batch size selects (small batches: k_conv3x3_small), and the tile kernel
+            y = torch.full_like(x, float("nan"))
+            _conv(x, w, b, res, y, relu | force_tile)
+            want = ref if res is None else ref + res.float()
+            if relu:
+                want = F.relu(want)
+            err = (y.float() - want).abs().max().item()
+            assert err < 4e-3 * max(1.0, want.abs().max().item()), (boards, res is not None, relu, force_tile, err)
     # flag bit 1 (descending tile order) changes nothing in the result
-    ya, yb = _conv(x, w, b, r, torch.empty_like(x), 1), _conv(x, w, b, r, torch.empty_like(x), 3)
+    ya, yb = _conv(x, w, b, r, torch.empty_like(x), 1 | 32), _conv(x, w, b, r, torch.empty_like(x), 3 | 32)
     assert torch.equal(ya, yb)
     # the output may be written over the residual input (how the tower uses it)
     y = r.clone(memory_format=torch.preserve_format)
     _conv(x, w, b, y, y, 1)
     want = F.relu(ref + r.float())
     assert (y.float() - want).abs().max().item() < 4e-3 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("boards", [1, 2, 3, 7, 24, 25, 96, 130])
+def test_small_batch_kernel_is_bit_identical_to_the_tile_kernel(boards):
+    """k_conv3x3_small (one wave per 16 x 16 NT block: what batches of up to 96 boards run on) performs the same operations
+    in the same order as k_conv3x3_c256: identical bits, with and without residual / ReLU, tower and stem shape; both against
+    float32 as well. Flag bit 4 forces the small kernel, bit 5 the tile kernel."""
+    from chinesechesszero_amd import _lib
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(100 + boards)
+    cl = torch.channels_last
+    x = (torch.randn(boards, 256, 10, 9, generator=g) * 0.7).to(dev).half().contiguous(memory_format=cl)
+    r = (torch.randn(boards, 256, 10, 9, generator=g) * 0.7).to(dev).half().contiguous(memory_format=cl)
+    w = (torch.randn(256, 256, 3, 3, generator=g) * 0.03).to(dev).half().contiguous(memory_format=cl)
+    b = (torch.randn(256, generator=g) * 0.2).to(dev)
+    ref = F.conv2d(x.float(), w.float(), b, padding=1)
+    for res, relu in ((None, 1), (r, 1), (r, 0)):
+        ys = _conv(x, w, b, res, torch.full_like(x, float("nan")), relu | 16)
+        yt = _conv(x, w, b, res, torch.full_like(x, float("nan")), relu | 32)
+        assert torch.equal(ys, yt), (boards, res is not None, relu)
+        want = ref if res is None else ref + res.float()
+        if relu:
+            want = F.relu(want)
+        assert (ys.float() - want).abs().max().item() < 4e-3 * max(1.0, want.abs().max().item())
+    # in place over the residual, as the tower calls it
+    ya, yb = r.clone(memory_format=torch.preserve_format), r.clone(memory_format=torch.preserve_format)
+    _conv(x, w, b, ya, ya, 1 | 16)
+    _conv(x, w, b, yb, yb, 1 | 32)
+    assert torch.equal(ya, yb)
+    # the stem shape (one 64-channel chunk)
+    L = _lib.lib()
+    s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    x64 = torch.zeros(boards * 90, 64, device=dev, dtype=torch.float16)
+    x64[:, :21] = (torch.rand(boards * 90, 21, generator=g) > 0.8).to(dev).half()
+    w64 = (torch.randn(256, 3, 3, 64, generator=g) * 0.05).to(dev).half()
+    outs = []
+    for flag in (16, 32):
+        y = torch.full((boards * 90, 256), float("nan"), device=dev, dtype=torch.float16)
+        _lib.check(L.ccz_conv3x3_stem_f16(s, C.c_void_p(x64.data_ptr()), C.c_void_p(w64.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(y.data_ptr()), boards * 90, 1 | flag))
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1]) and not torch.isnan(outs[0]).any()
 
 
 def test_conv_kernel_board_edges_are_zero_padded_per_board():

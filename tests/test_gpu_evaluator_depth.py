@@ -103,18 +103,51 @@ def test_fused_evaluator_at_full_depth_is_no_worse_than_the_reference_autocast_p
 
 
 def test_shapes_off_the_fused_path_are_logged(caplog):
-    """The MFMA kernel serves 256 channels at >= 192 boards; anything else takes MIOpen + the epilogue pass and says so once."""
+    """The hand-written kernels serve 256-channel towers at every batch size; a tower of another width takes MIOpen + the
+    epilogue pass and says so once per shape."""
     import logging
     from chinesechesszero_amd.net import InferenceNet, Net
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
-    inf = InferenceNet(Net(256, 1).to(dev).eval()).to(dev).eval()
+    inf = InferenceNet(Net(128, 1).to(dev).eval()).to(dev).eval()
     x = torch.zeros((64, 17, 7, 10, 9), dtype=torch.float16, device=dev)
     with caplog.at_level(logging.INFO, logger="chinesechesszero_amd"):
         inf(x)
         inf(x)
     msgs = [r.getMessage() for r in caplog.records if "fused" in r.getMessage()]
-    assert len(msgs) == 1 and "64" in msgs[0]
+    assert len(msgs) == 1 and "64 boards x 128 channels" in msgs[0]
+    inf256 = InferenceNet(Net(256, 1).to(dev).eval()).to(dev).eval()
+    with caplog.at_level(logging.INFO, logger="chinesechesszero_amd"):
+        caplog.clear()
+        inf256(x)
+        inf256(x[:1])
+    assert not [r for r in caplog.records if "fused" in r.getMessage()]      # 64 boards and ONE board: both on the fused kernels
+
+
+def test_tower_activations_do_not_depend_on_the_batch_size():
+    """One board evaluated alone (k_conv3x3_small, NT = 1), in a batch of 24 (NT = 2), of 90 (NT = 4) and of 300 (the 256-pixel
+    tile kernel): the stem + tower output of that board is the same, bit for bit -- the small-batch kernel performs the tile
+    kernel's operations in the tile kernel's order. (The heads are GEMMs of torch and may pick another kernel per batch size:
+    logits agree to float16 round-off, not bit for bit.)"""
+    from chinesechesszero_amd.net import InferenceNet, Net
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3)
+    inf = InferenceNet(Net(256, 6).to(dev).eval()).to(dev).eval()
+    x = _leaf_batch(300, 16, seed=5)
+    probe = x[123:124].clone()
+    outs = []
+    for B in (1, 24, 90, 300):
+        xb = x[:B].clone()
+        xb[B // 2] = probe[0]
+        t = inf._tower_fused(inf._stem_fused(xb))
+        outs.append(t[B // 2].clone())
+        lg, v = inf(xb, return_logits=True)
+        if B == 1:
+            lg1, v1 = lg[0].float().clone(), v[0].clone()
+        else:
+            assert (lg[B // 2].float() - lg1).abs().max().item() < 2e-2 and abs(float(v[B // 2] - v1)) < 2e-3
+    for t in outs[1:]:
+        assert torch.equal(t, outs[0])
 
 
 def test_a_boards_evaluation_does_not_depend_on_its_slot_in_the_batch():
