@@ -51,7 +51,7 @@ def main():
         except Exception:
             return None
 
-    for kind, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    for kind, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("pmc_cfetch", "FETCH_SIZE"), ("pmc_cwrite", "WRITE_SIZE")):
         cc = find(os.path.join(out_dir, kind), "*counter_collection.csv")
         if not cc:
             continue
@@ -74,7 +74,7 @@ def main():
         # the k_step launches of the pass's TIMED WINDOW are its last (steps - move boundaries) ones: nothing launches k_step
         # after the window. Their counters and the pass's own k-bar / d-bar / algorithmic bytes describe the same trees.
         bl = bench_line(kind + "_bench.json")
-        if bl and kstep:
+        if bl and kstep and kind in ("pmc_fetch", "pmc_write"):
             n_win = int(bl["steps"]) - int(bl["move_boundary"]["in_window"])
             vals = [v for _, v in sorted(kstep, key=lambda t: t[0])][-n_win:]   # stable: file order if there is no dispatch id
             w = summary.setdefault("k_step", {}).setdefault("window", {})
@@ -86,24 +86,25 @@ def main():
                 w["warning"] = f"the fetch and write passes saw different trees: {shape} vs k_bar {w['k_bar']} d_bar {w['d_bar']}"
             w.update(shape)
             w["bench_args"] = f"--steps {bl['steps']} --warmup {bl['warmup']} (window: {bl['config']['window']})"
-    cc = find(os.path.join(out_dir, "pmc_sq"), "*counter_collection.csv")
-    if cc:  # SQ counters per launch (quad-cycle units for the *_CYCLES / WAIT / ACTIVE counters, MI355X_MICROARCH.md)
-        acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
-        for r in csv.DictReader(open(cc)):
-            name = r.get("Kernel_Name", "")
-            for k in ("k_step", "k_softmax_gather", "k_finish_move", "k_harvest", "k_conv3x3"):
-                if k in name:
-                    a = acc[k][r.get("Counter_Name")]
-                    a[0] += float(r.get("Counter_Value", 0) or 0)
-                    a[1] += 1
-        for k, d in acc.items():
-            sq = {c: v[0] / v[1] for c, v in d.items() if v[1]}
-            wc = sq.get("SQ_WAVE_CYCLES")
-            if wc:
-                sq["wait_any_frac"] = sq.get("SQ_WAIT_ANY", 0.0) / wc
-                sq["wait_inst_any_frac"] = sq.get("SQ_WAIT_INST_ANY", 0.0) / wc
-                sq["active_inst_any_frac"] = sq.get("SQ_ACTIVE_INST_ANY", 0.0) / wc
-            summary.setdefault(k, {})["sq_per_launch"] = sq
+    for sqdir in ("pmc_sq", "pmc_csq"):
+      cc = find(os.path.join(out_dir, sqdir), "*counter_collection.csv")
+      if cc:  # SQ counters per launch (quad-cycle units for the *_CYCLES / WAIT / ACTIVE counters, MI355X_MICROARCH.md)
+          acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+          for r in csv.DictReader(open(cc)):
+              name = r.get("Kernel_Name", "")
+              for k in ("k_step", "k_softmax_gather", "k_finish_move", "k_harvest", "k_conv3x3"):
+                  if k in name:
+                      a = acc[k][r.get("Counter_Name")]
+                      a[0] += float(r.get("Counter_Value", 0) or 0)
+                      a[1] += 1
+          for k, d in acc.items():
+              sq = {c: v[0] / v[1] for c, v in d.items() if v[1]}
+              wc = sq.get("SQ_WAVE_CYCLES")
+              if wc:
+                  sq["wait_any_frac"] = sq.get("SQ_WAIT_ANY", 0.0) / wc
+                  sq["wait_inst_any_frac"] = sq.get("SQ_WAIT_INST_ANY", 0.0) / wc
+                  sq["active_inst_any_frac"] = sq.get("SQ_ACTIVE_INST_ANY", 0.0) / wc
+              summary.setdefault(k, {})["sq_per_launch"] = sq
     for k, d in summary.items():
         f = d.get("FETCH_SIZE_raw_per_launch")
         w = d.get("WRITE_SIZE_raw_per_launch")
@@ -120,7 +121,8 @@ def main():
             win["note"] = ("counters and algorithmic bytes of the SAME launches: the timed window of the PMC passes (real-net alignment). "
                            "fetch x2 = the gfx950 correction for wide coalesced reads (MI355X_MICROARCH.md, HBM); k_step's reads are mostly "
                            "16-B records and scattered 4-B words, so the truth lies between the two ratios")
-    for name in ("trace_bench.json", "pmc_fetch_bench.json", "pmc_write_bench.json", "pmc_sq_bench.json"):
+    for name in ("trace_bench.json", "pmc_fetch_bench.json", "pmc_write_bench.json", "pmc_sq_bench.json", "pmc_cfetch_bench.json",
+                 "pmc_cwrite_bench.json", "pmc_csq_bench.json"):
         p = os.path.join(out_dir, name)
         if os.path.exists(p):
             try:
@@ -135,7 +137,8 @@ def main():
     if tb:  # bench.py replays these figures only for the workload they were measured on
         pm["workload"] = {"boards_per_gpu": tb["config"]["boards_per_gpu"], "sims_per_move": tb["config"]["sims_per_move"],
                           "evaluator": tb["config"]["evaluator"], "max_plies": tb["config"]["max_plies"]}
-    pm["run"] = f"profiles/run_profile.sh {tag}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes of bench.py --steps 24"
+    pm["run"] = (f"profiles/run_profile.sh {tag}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes of bench.py --steps 24, "
+                 "counter collection filtered per kernel (k_step: the bench's full command shape; k_conv3x3: short passes)")
     with open(os.path.join(root, "pmc_summary.json"), "w") as f:
         json.dump(pm, f, indent=1)
     print(json.dumps({k: v for k, v in summary.items() if not k.startswith("_")}, indent=1))
