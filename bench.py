@@ -575,9 +575,7 @@ def tower_roofline(a, pvn, e, state, B, ev):
     inf = pvn._infer
     leaf = state["leaf"] if state["leaf"] is not None else e.select_leaves()
     with torch.no_grad():
-        x = leaf.view(B, 119, 10, 9)
-        x = torch.cat([x[:, 49:56], x[:, 105:119]], dim=1).to(torch.float16).contiguous(memory_format=torch.channels_last)
-        x0 = inf._epilogue(F.conv2d(x, inf.stem_w, None, padding=1), inf.stem_b)
+        x0 = inf._stem_fused(leaf)
         inf._tower_fused(x0.clone(memory_format=torch.preserve_format))
         xs = [x0.clone(memory_format=torch.preserve_format) for _ in range(3)]
         c0, c1 = ev(), ev()

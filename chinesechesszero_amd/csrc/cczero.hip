@@ -215,7 +215,6 @@ int ccz_create(const ccz_config *cfg, ccz_engine **out)
         ALLOC(d.crep, B);
         ALLOC(d.row_of, B);
         ALLOC(d.vleaf, B);
-        ALLOC(d.cache_stats, 4);
         if (he == hipSuccess) he = hipMemset(d.claim, 0x7f, slots * 4);
     }
     ALLOC(d.rec_sq, B * d.max_plies * 96);
@@ -686,16 +685,12 @@ int ccz_get_stats(ccz_engine *e, void *stream, ccz_stats *out)
         out->expansions += (int64_t)b.expansions;
         out->terminal_leaves += (int64_t)b.terminal;
         out->pruned_subtrees += (int64_t)b.pruned;
+        out->cache_probes += (int64_t)b.cache_probes;
+        out->cache_hits += (int64_t)b.cache_hits;
+        out->cache_shared_rows += (int64_t)b.cache_shared;
+        out->cache_stores += (int64_t)b.cache_stores;
         if (b.nodes_peak > out->nodes_peak) out->nodes_peak = b.nodes_peak;
         if (b.depth_peak > out->depth_peak) out->depth_peak = b.depth_peak;
-    }
-    if (e->d.cache) {
-        unsigned long long cs[4] = {0, 0, 0, 0};
-        HIP_TRY(hipMemcpy(cs, e->d.cache_stats, sizeof cs, hipMemcpyDeviceToHost));
-        out->cache_probes = (int64_t)cs[0];
-        out->cache_hits = (int64_t)cs[1];
-        out->cache_shared_rows = (int64_t)cs[2];
-        out->cache_stores = (int64_t)cs[3];
     }
     out->error_flags = err[0];
     out->reserved = err[1]; // bounds-checked diagnostic build: source line of the stray index (0 otherwise)

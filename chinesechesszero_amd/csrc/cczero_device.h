@@ -59,6 +59,9 @@ static_assert(sizeof(CacheEntry) == 528, "cache entry is 528 bytes");
 struct BoardStats {
     unsigned long long sims, moves, games, truncated, sum_depth, sum_children, expansions, terminal, pruned;
     int32_t nodes_peak, depth_peak;
+    // evaluation cache, counted per board by the board's own wave (no atomics): leaves probed, hits, leaves served by another
+    // board's evaluator row of the same step, entries stored
+    unsigned int cache_probes, cache_hits, cache_shared, cache_stores;
 };
 
 struct Dev {
@@ -92,7 +95,6 @@ struct Dev {
     int32_t *crep;        // [B] the board whose evaluator row this board uses (itself, or the same-key board of lower index)
     int32_t *row_of;      // [B] compact evaluator row holding this board's logits / value (misses)
     float *vleaf;         // [B] leaf value of the pending leaf (step / expand_backup read it when value_dev == NULL)
-    unsigned long long *cache_stats; // [4] leaves probed, hits, served by another board's row of the same step, entries stored
     uint64_t *leaf_key;   // [B] Zobrist key (pieces + side to move) of the pending leaf: what the evaluator input depends on
     uint8_t *rec_sq;   // [B][max_plies][96] root position before each move
     uint8_t *rec_turn; // [B][max_plies]

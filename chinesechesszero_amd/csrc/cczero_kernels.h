@@ -596,13 +596,11 @@ __global__ __launch_bounds__(64) void k_softmax_gather(Dev D, const T *logits, c
             D.vleaf[b] = v;
             D.claim[slot] = 0x7fffffff; // (every board that missed on the slot resets it: idempotent)
         }
-        if (D.cins[b]) { // the slot's claim winner stores its evaluation; the key goes last, behind the payload
+        if (D.cins[b]) { // the slot's claim winner stores its evaluation (nobody reads the table before the next launch)
             CacheEntry *e = D.cache + slot;
             e->pri[lane] = p0;
             e->pri[64 + lane] = p1;
-            if (lane == 0) { e->v = v; e->k = (uint32_t)k; }
-            __threadfence();
-            if (lane == 0) { e->key = D.leaf_key[b]; atomicAdd(D.cache_stats + 3, 1ull); }
+            if (lane == 0) { e->v = v; e->k = (uint32_t)k; e->key = D.leaf_key[b]; D.stats[b].cache_stores += 1u; }
         }
     }
 }
@@ -637,8 +635,9 @@ __global__ __launch_bounds__(64) void k_cache_probe(Dev D)
         D.cstate[b] = hit ? 1 : 0;
         if (hit) D.vleaf[b] = ev;
         else atomicMin(D.claim + slot, b);
-        atomicAdd(D.cache_stats + 0, 1ull);
-        if (hit) atomicAdd(D.cache_stats + 1, 1ull);
+        BoardStats &st = D.stats[b];
+        st.cache_probes += 1u;
+        if (hit) st.cache_hits += 1u;
     }
 }
 
@@ -647,12 +646,11 @@ __global__ __launch_bounds__(64) void k_cache_probe(Dev D)
 // miss_rows[0 .. n_miss) = the representatives in ascending board order: the rows the evaluator computes.
 __global__ __launch_bounds__(1024) void k_cache_plan(Dev D, int32_t *miss_rows, int32_t *n_miss)
 {
-    __shared__ int s_scan[1024];
+    __shared__ int s_wave[16];
     __shared__ int s_base;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) s_base = 0;
     __syncthreads();
-    int shared = 0;
     for (int b0 = 0; b0 < D.B; b0 += 1024) {
         const int b = b0 + tid;
         int isrep = 0;
@@ -663,25 +661,28 @@ __global__ __launch_bounds__(1024) void k_cache_plan(Dev D, int32_t *miss_rows, 
             D.crep[b] = rep;
             D.cins[b] = (uint8_t)(w == b);
             isrep = rep == b;
-            shared += !isrep;
+            if (!isrep) D.stats[b].cache_shared += 1u;
         }
-        // inclusive scan of isrep over the 1024 threads
-        s_scan[tid] = isrep;
+        // exclusive position of every representative: ballot inside the wave, 16 wave totals through LDS
+        const uint64_t m = __ballot(isrep);
+        const int in_wave = __popcll(m & lanemask_lt(lane)), wave_total = __popcll(m);
+        if (lane == 0) s_wave[wv] = wave_total;
         __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            const int v = tid >= off ? s_scan[tid - off] : 0;
-            __syncthreads();
-            s_scan[tid] += v;
-            __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int t = s_wave[i];
+            before += i < wv ? t : 0;
+            total += t;
         }
         const int base = s_base;
         if (isrep) {
-            const int pos = base + s_scan[tid] - 1;
+            const int pos = base + before + in_wave;
             D.row_of[b] = pos;
             miss_rows[pos] = b;
         }
         __syncthreads();
-        if (tid == 1023) s_base = base + s_scan[1023];
+        if (tid == 0) s_base = base + total;
         __syncthreads();
     }
     __threadfence_block();
@@ -689,7 +690,6 @@ __global__ __launch_bounds__(1024) void k_cache_plan(Dev D, int32_t *miss_rows, 
     for (int b = tid; b < D.B; b += 1024)
         if (D.cstate[b] == 0 && D.crep[b] != b) // (read past this CU's L1: the row was written a moment ago by another wave)
             D.row_of[b] = __hip_atomic_load(D.row_of + D.crep[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (shared) atomicAdd(D.cache_stats + 2, (unsigned long long)shared);
     if (tid == 0) *n_miss = s_base;
 }
 
