@@ -737,7 +737,7 @@ int ccz_bias_act_f16(void *stream, void *y_dev, const void *bias_dev, const void
     return 0;
 }
 
-constexpr int64_t kSmallMaxPixels = 96 * 90; // up to 96 boards (profiles/r03_single_board.json: crossover with the tile kernel)
+constexpr int64_t kSmallMaxPixels = 24 * 90; // up to 24 boards (profiles/r03_single_board.json: crossover with the tile kernel)
 
 static int conv3x3_launch(const char *who, void *stream, const void *x_dev, const void *w_dev, const void *bias_f32_dev, const void *residual_dev, void *y_dev,
                           int64_t n_pixels, int32_t relu, int cin, const int32_t *live_rows_dev = nullptr, int32_t row0 = 0)
@@ -756,11 +756,12 @@ static int conv3x3_launch(const char *who, void *stream, const void *x_dev, cons
         const dim3 grid((unsigned)((n_pixels + 16 * nt - 1) / (16 * nt)), 16);
         const size_t shm = (size_t)(16 * nt + 2 * kCvHalo + 1) * cin * 2;
         const int rl = relu & 1;
-#define CCZ_SMALL(NT_, RES_)                                                                                                   \
-        hipLaunchKernelGGL((k_conv3x3_small<NT_, RES_>), grid, dim3(64), shm, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev, \
-                           (const float *)bias_f32_dev, (const _Float16 *)residual_dev, (_Float16 *)y_dev, (int)n_pixels, rl, cin)
-        if (residual_dev) { if (nt == 1) CCZ_SMALL(1, true); else if (nt == 2) CCZ_SMALL(2, true); else CCZ_SMALL(4, true); }
-        else { if (nt == 1) CCZ_SMALL(1, false); else if (nt == 2) CCZ_SMALL(2, false); else CCZ_SMALL(4, false); }
+#define CCZ_SMALL(NT_, RES_, CIN_)                                                                                             \
+        hipLaunchKernelGGL((k_conv3x3_small<NT_, RES_, CIN_>), grid, dim3(64), shm, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev, \
+                           (const float *)bias_f32_dev, (const _Float16 *)residual_dev, (_Float16 *)y_dev, (int)n_pixels, rl)
+        if (cin == 64) { if (nt == 1) CCZ_SMALL(1, false, 64); else if (nt == 2) CCZ_SMALL(2, false, 64); else CCZ_SMALL(4, false, 64); }
+        else if (residual_dev) { if (nt == 1) CCZ_SMALL(1, true, 256); else if (nt == 2) CCZ_SMALL(2, true, 256); else CCZ_SMALL(4, true, 256); }
+        else { if (nt == 1) CCZ_SMALL(1, false, 256); else if (nt == 2) CCZ_SMALL(2, false, 256); else CCZ_SMALL(4, false, 256); }
 #undef CCZ_SMALL
         HIP_TRY(hipGetLastError());
         return 0;

@@ -24,32 +24,52 @@
 
 namespace ccz {
 
-constexpr int kSmAhead = 6; // weight fragments in flight ahead of the MFMA that uses them
+constexpr int kSmAhead = 18; // weight fragments in flight ahead of the MFMA that uses them: one 64-channel chunk (~600 cycles of
+                             // dependent MFMAs at NT = 1, about an L2 round trip)
 
 // LDS: slab rows of `cin` fp16 (512 B for the tower, 128 B for the stem chunk), 16-byte chunk c of row r stored at position
 // c ^ (r & 15) (within its group of 16 chunks for 512-byte rows; rows of 8 chunks use c ^ (r & 7)); then one zero row.
-template <int NT, bool RES>
+template <int NT, bool RES, int CIN>
 __global__ __launch_bounds__(64) void k_conv3x3_small(const _Float16 *__restrict__ X, const _Float16 *__restrict__ W,
                                                         const float *__restrict__ bias, const _Float16 *R, _Float16 *Y, int M,
-                                                        int relu, int cin)
+                                                        int relu)
 {
+    constexpr int cin = CIN;
     constexpr int kPix = 16 * NT, kRows = kPix + 2 * kCvHalo;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x;
     const int r = lane & 15, q4 = lane >> 4;
     const long p0 = (long)blockIdx.x * kPix;
     const int co0 = blockIdx.y * 16;
-    const int row_bytes = cin * 2, cpr = cin >> 3; // bytes and 16-byte chunks per slab row
-    const int swz = cpr >= 16 ? 15 : 7;
-    const int zero_off = kRows * row_bytes;
+    constexpr int row_bytes = cin * 2, cpr = cin >> 3; // bytes and 16-byte chunks per slab row
+    constexpr int swz = cpr >= 16 ? 15 : 7;
+    constexpr int zero_off = kRows * row_bytes;
 
-    // ---- the slab: rows p0 - 10 .. p0 + kPix + 10 (clamped into the tensor: a clamped row is only ever read by a masked tap)
-    for (int i = lane; i < kRows * cpr; i += 64) {
-        const int row = i / cpr, c = i - row * cpr;
-        long p = p0 - kCvHalo + row;
-        p = p < 0 ? 0 : (p > (long)M - 1 ? (long)M - 1 : p);
-        const cv_half8 v = *(const cv_half8 *)(X + p * cin + c * 8);
-        *(cv_half8 *)(lds + row * row_bytes + (((c & ~swz) | ((c ^ row) & swz)) << 4)) = v;
+    // ---- the slab: rows p0 - 10 .. p0 + kPix + 10 (clamped into the tensor: a clamped row is only ever read by a masked tap).
+    // Loads in batches of 9 per lane, all in flight before the first LDS write (one memory round trip per batch: a loop of
+    // load -> write pairs took 18 round trips and made a layer 29 us at one board).
+    constexpr int kPieces = kRows * cpr, kIters = (kPieces + 63) / 64, kBatch = 9;
+#pragma unroll
+    for (int it0 = 0; it0 < kIters; it0 += kBatch) {
+        cv_half8 v[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int i = (it0 + j) * 64 + lane;
+            if (it0 + j < kIters && i < kPieces) {
+                const int row = i / cpr, c = i % cpr;
+                long p = p0 - kCvHalo + row;
+                p = p < 0 ? 0 : (p > (long)M - 1 ? (long)M - 1 : p);
+                v[j] = *(const cv_half8 *)(X + p * cin + c * 8);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int i = (it0 + j) * 64 + lane;
+            if (it0 + j < kIters && i < kPieces) {
+                const int row = i / cpr, c = i % cpr;
+                *(cv_half8 *)(lds + row * row_bytes + (((c & ~swz) | ((c ^ row) & swz)) << 4)) = v[j];
+            }
+        }
     }
     for (int i = lane; i < row_bytes / 4; i += 64) *(uint32_t *)(lds + zero_off + i * 4) = 0u;
 
@@ -76,7 +96,7 @@ __global__ __launch_bounds__(64) void k_conv3x3_small(const _Float16 *__restrict
     }
 
     // ---- K loop: half-step h = (chunk, tap, half); weights of half-step h + kSmAhead are requested while h computes
-    const int n_half = (cin >> 6) * 18;
+    constexpr int n_half = (cin >> 6) * 18;
     const _Float16 *wl = W + (long)(co0 + r) * (9 * cin) + q4 * 8;
     auto wsrc = [&](int h) {
         const int chunk = h / 18, u = h - chunk * 18;
