@@ -737,7 +737,7 @@ int ccz_bias_act_f16(void *stream, void *y_dev, const void *bias_dev, const void
     return 0;
 }
 
-constexpr int64_t kSmallMaxPixels = 24 * 90; // up to 24 boards (profiles/r03_single_board.json: crossover with the tile kernel)
+constexpr int64_t kSmallMaxPixels = 48 * 90; // up to 48 boards (profiles/r03_single_board.json: crossover with the tile kernel)
 
 static int conv3x3_launch(const char *who, void *stream, const void *x_dev, const void *w_dev, const void *bias_f32_dev, const void *residual_dev, void *y_dev,
                           int64_t n_pixels, int32_t relu, int cin, const int32_t *live_rows_dev = nullptr, int32_t row0 = 0)
@@ -748,20 +748,18 @@ static int conv3x3_launch(const char *who, void *stream, const void *x_dev, cons
         return fail(-1, "%s: pointers must be 16-byte aligned", who);
     if (x_dev == y_dev) return fail(-1, "%s: the output may alias the residual but not the input", who);
     if (n_pixels == 0) return 0;
-    // Small batches (one game at a time; up to kSmallMaxPixels): the one-wave-per-16x16-block kernel spreads them over the chip
+    // Small batches (one game at a time; up to kSmallMaxPixels): the 16-channel x 64-pixel-block kernel spreads them over the chip
     // instead of filling a few 256-pixel tiles. Same operations in the same order: bit-identical results (cczero_conv_small.h).
     // flags bit 4 forces it, bit 5 forces the tile kernel (A/B runs, tests).
     if (!live_rows_dev && !(relu & 32) && ((relu & 16) || n_pixels <= kSmallMaxPixels)) {
-        const int nt = n_pixels <= 2 * 90 ? 1 : (n_pixels <= 24 * 90 ? 2 : 4);
-        const dim3 grid((unsigned)((n_pixels + 16 * nt - 1) / (16 * nt)), 16);
-        const size_t shm = (size_t)(16 * nt + 2 * kCvHalo + 1) * cin * 2;
+        const dim3 grid((unsigned)((n_pixels + kSmPix - 1) / kSmPix), 16);
         const int rl = relu & 1;
-#define CCZ_SMALL(NT_, RES_, CIN_)                                                                                             \
-        hipLaunchKernelGGL((k_conv3x3_small<NT_, RES_, CIN_>), grid, dim3(64), shm, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev, \
+#define CCZ_SMALL(RES_, CIN_)                                                                                                  \
+        hipLaunchKernelGGL((k_conv3x3_small<RES_, CIN_>), grid, dim3(256), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev, \
                            (const float *)bias_f32_dev, (const _Float16 *)residual_dev, (_Float16 *)y_dev, (int)n_pixels, rl)
-        if (cin == 64) { if (nt == 1) CCZ_SMALL(1, false, 64); else if (nt == 2) CCZ_SMALL(2, false, 64); else CCZ_SMALL(4, false, 64); }
-        else if (residual_dev) { if (nt == 1) CCZ_SMALL(1, true, 256); else if (nt == 2) CCZ_SMALL(2, true, 256); else CCZ_SMALL(4, true, 256); }
-        else { if (nt == 1) CCZ_SMALL(1, false, 256); else if (nt == 2) CCZ_SMALL(2, false, 256); else CCZ_SMALL(4, false, 256); }
+        if (cin == 64) CCZ_SMALL(false, 64);
+        else if (residual_dev) CCZ_SMALL(true, 256);
+        else CCZ_SMALL(false, 256);
 #undef CCZ_SMALL
         HIP_TRY(hipGetLastError());
         return 0;

@@ -61,7 +61,7 @@ def main():
     for (n, L, fl), y in zip(libs, ys):
         run(L, y, fl)
     torch.cuda.synchronize()
-    sample = sorted({0, 1, B // 2, B - 1})
+    sample = sorted({0, min(1, B - 1), B // 2, B - 1})
     ref = F.conv2d(x[sample].float(), w.float(), bias, padding=1)
     ref = F.relu(ref + res[sample].float()) if a.res else F.relu(ref)
     out = {"boards": B, "res": a.res, "err_vs_fp32": (ys[0][sample].float() - ref).abs().max().item(),
