@@ -737,7 +737,7 @@ int ccz_bias_act_f16(void *stream, void *y_dev, const void *bias_dev, const void
     return 0;
 }
 
-constexpr int64_t kSmallMaxPixels = 48 * 90; // up to 48 boards (profiles/r03_single_board.json: crossover with the tile kernel)
+constexpr int64_t kSmallMaxPixels = 64 * 90; // up to 64 boards (profiles/r03_single_board.json: crossover with the tile kernel)
 
 static int conv3x3_launch(const char *who, void *stream, const void *x_dev, const void *w_dev, const void *bias_f32_dev, const void *residual_dev, void *y_dev,
                           int64_t n_pixels, int32_t relu, int cin, const int32_t *live_rows_dev = nullptr, int32_t row0 = 0)
