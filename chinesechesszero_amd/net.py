@@ -151,8 +151,8 @@ class InferenceNet(nn.Module):
             y = y + residual
         return F.relu_(y)
 
-    FUSED_MIN_BOARDS = 1  # every batch runs on the hand-written convolution: up to 96 boards on k_conv3x3_small (one wave per
-    # 16 x 16 NT block, spread over the chip), above that on the 256-pixel tiles of k_conv3x3_c256 -- bit-identical results, so a
+    FUSED_MIN_BOARDS = 1  # every batch runs on the hand-written convolution: up to 64 boards on k_conv3x3_small (16-channel x
+    # 64-pixel blocks spread over the chip), above that on the 256-pixel tiles of k_conv3x3_c256 -- bit-identical results, so a
     # board's tower activations do not depend on the batch size. (Round 2 sent batches under 192 boards to MIOpen + an epilogue
     # pass: 12.1 us per tower layer at one board, profiles/r03_single_board.json.)
 

@@ -4,7 +4,7 @@ collect.py:133-143 calls the surface) -- VERDICT r02 item 7.
 Measures, with the full 40 x 256 net:
   * sims/s of ``MCTS_AI(n_playout=200).get_action`` through the host mirror (hipGraph replay of evaluator + k_step per playout),
   * the per-playout split: graph replay wall time, the evaluator alone (eager and replayed), the simulator kernel alone,
-  * the evaluator by batch size on the tower paths: k_conv3x3_small (one wave per 16 x 16 NT block; what batches of up to 96
+  * the evaluator by batch size on the tower paths: k_conv3x3_small (a 16-channel x 64-pixel block per workgroup; what batches of up to 64
     boards take), the 256-pixel tile kernel (a single board = one partial tile on ONE compute unit), MIOpen + one-pass epilogue
     (what batches under 192 boards took until round 3),
 so that "is MIOpen at the launch floor at B = 1?" has a number: per-layer time against the ~1.2-1.5 us kernel boundary

@@ -125,8 +125,7 @@ def test_shapes_off_the_fused_path_are_logged(caplog):
 
 
 def test_tower_activations_do_not_depend_on_the_batch_size():
-    """One board evaluated alone (k_conv3x3_small, NT = 1), in a batch of 24 (NT = 2), of 90 (NT = 4) and of 300 (the 256-pixel
-    tile kernel): the stem + tower output of that board is the same, bit for bit -- the small-batch kernel performs the tile
+    """One board evaluated alone and in a batch of 24 (k_conv3x3_small), of 90 and of 300 (the 256-pixel tile kernel): the stem + tower output of that board is the same, bit for bit -- the small-batch kernel performs the tile
     kernel's operations in the tile kernel's order. (The heads are GEMMs of torch and may pick another kernel per batch size:
     logits agree to float16 round-off, not bit for bit.)"""
     from chinesechesszero_amd.net import InferenceNet, Net
