@@ -510,7 +510,11 @@ def main():
             "metric": "self-play MCTS simulations/sec", "value": value, "unit": "sims/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8 rules / f32 Q / f64 PUCT (net: fp16)", "data": "synthetic",
+            # the reference has two arithmetic paths: CPU = float32 net + float32 Q, CUDA = fp16 autocast net + float16 Q
+            # (net.py:178-199 -> mcts.py:63-71 under NEP 50). The headline pairs its GPU net precision with its CPU-path Q (what
+            # the golden traces pin); --value-f16 is its CUDA path end to end (profiles/r03_bench_value_f16.json: the same rate)
+            "dtype": ("u8 rules / f16 Q (reference CUDA path) / f64 PUCT (net: fp16)" if a.value_f16 else
+                      "u8 rules / f32 Q (reference CPU path) / f64 PUCT (net: fp16)"), "data": "synthetic",
             "config": {"workload": f"{B} concurrent boards/GPU x {n} sims/move, Dirichlet root noise on (device Philox), " + net_desc + ", " + state_desc,
                        "boards_per_gpu": B, "sims_per_move": n, "evaluator": a.evaluator,
                        "preroll_plies": a.preroll_plies, "max_plies": a.max_plies, "warm_moves": a.warm_moves if planned[0] else 0,

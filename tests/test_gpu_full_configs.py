@@ -99,3 +99,45 @@ def test_baseline_config5_single_gpu_half_4096_boards_x_800_sims():
     assert st["nodes_peak"] <= (800 + 64) * 512
     e.check_healthy()
     e.close()
+
+
+def test_full_size_with_the_real_net_and_the_evaluation_cache_stays_healthy():
+    """4096 boards, the real 40 x 256 evaluator on the planned boundary (evaluation cache, device-side live-row counts, four
+    concurrent tower launches over the live rows), 2 moves x 48 simulations with their boundaries, harvest and restart: error
+    flags 0, the tree invariants of mcts.py on every board, the cache's books balance. (bench.py runs this shape for thousands
+    of steps; this is the driver-run check that watches the flags.)"""
+    from chinesechesszero_amd.net import PolicyValueNet
+    from chinesechesszero_amd.selfplay import BatchedSelfPlay
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    pvn = PolicyValueNet(device=dev)
+    B, n = 4096, 48
+    sp = BatchedSelfPlay(pvn.evaluate_leaves_logits, B, n_playout=n, seed=2, max_plies=3, eval_cache_log2=20)
+    assert sp.planned
+    e = sp.engine
+    rows = 0
+    for move in range(4):        # the 3-ply cap ends every game at its 4th move: a full-batch boundary + restart inside the test
+        leaf = e.select_leaves()
+        for i in range(n):
+            lg, v = sp._planned_eval(leaf)
+            if i + 1 < n:
+                leaf = e.step_planned(lg, v)
+            else:
+                e.expand_backup_planned(lg, v)
+        rc = e.root_children()
+        live = e.game_status()["over"] == 0
+        k = rc["k"]
+        tot = np.array([rc["visits"][b, :k[b]].sum() for b in range(B)])
+        assert np.all(rc["root_visits"][live] >= n) and np.all(tot[live] == rc["root_visits"][live] - 1)   # mcts.py: root N = 1 + sum of children
+        assert np.all(np.abs(rc["q"]) <= 1.0 + 1e-6) and np.all(k[live] > 0)
+        sp.finish_move()
+        if e.game_status()["over"].any():
+            for s_, p_, z_ in e.harvest_chunks(1 << 16):
+                rows += int(z_.shape[0])
+                assert torch.allclose(p_.sum(1), torch.ones_like(p_[:, 0]), atol=1e-4)
+    e.check_healthy()
+    st = e.stats()
+    assert st["error_flags"] == 0 and st["sims"] == 4 * B * n and st["games"] == B
+    assert rows == B * 3 * 2                                            # every board: one 3-ply game, samples + mirror images
+    assert st["cache_probes"] == st["expansions"] and st["cache_hits"] + st["cache_shared_rows"] > B * (n - 1)   # move 1: 4096 identical searches share one row
+    assert st["cache_stores"] <= st["cache_probes"] - st["cache_hits"] - st["cache_shared_rows"]
