@@ -114,7 +114,9 @@ class RecordGatherer(_FusedGather):
 
     def gather(self, records: torch.Tensor, more: bool = False, user: int = 0) -> torch.Tensor:
         """Every rank passes its new records uint8 [P, 880] (possibly none); every rank gets all of them, rank-major,
-        as one uint8 [sum P, 880] tensor on this gatherer's device. ``more`` / ``user``: as :meth:`TupleGatherer.gather`."""
+        as one uint8 [sum P, 880] tensor on this gatherer's device. ``more`` / ``user``: as :meth:`TupleGatherer.gather`.
+        The result may be a VIEW of the receive buffer (no copy when one rank's segment is all there is): consume it -- or
+        enqueue its consumer on the current stream -- before the next ``gather``."""
         n = int(records.shape[0])
         self.rounds = self.collectives = 0
         self.seconds = 0.0
