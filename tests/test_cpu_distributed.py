@@ -296,3 +296,20 @@ def test_collect_batched_gather_loop_world2(tmp_path):
     assert all(r[1] for r in res), res
     assert res[0][2] == 5 + 2 + 3 + 1 + 4 and res[1][2] == 0   # rank 0 stores the union, rank 1 nothing
     assert res[0][3] == res[1][3] == 2 + 3                     # finished "games" (boards flagged over) counted globally
+
+
+def test_game_aligned_chunks_cut_between_games_only():
+    """engine.game_aligned_chunks (what bounds the dense temporaries when records are expanded): chunks hold whole games, at
+    most the asked number of records unless ONE game is longer; nothing is lost or reordered."""
+    from chinesechesszero_amd.engine import game_aligned_chunks, rows_of_records
+    lengths = (5, 3, 9, 1, 1, 12, 4)
+    rec = _records(3, lengths)
+    for cap in (1, 4, 5, 8, 9, 13, 35, 100):
+        parts = list(game_aligned_chunks(rec, cap))
+        assert torch.equal(torch.cat(parts), rec)
+        for p in parts:
+            t = p[:, 96:98].contiguous().view(torch.int16).view(-1)
+            T = p[:, 98:100].contiguous().view(torch.int16).view(-1)
+            assert int(t[0]) == 0 and int(t[-1]) == int(T[-1]) - 1                  # starts and ends on a game boundary
+            assert p.shape[0] <= cap or p.shape[0] == int(T[0])                     # over the cap only for one long game
+    assert rows_of_records(7, 0) == 14 and rows_of_records(7, 2) == 7             # mirror images double the rows; CCZ_FLAG_NO_MIRROR does not
