@@ -366,7 +366,7 @@ def main():
     t_setup = time.perf_counter()
     if a.preroll_plies > 0:
         preroll(e, a.preroll_plies, stagger=True)
-    if a.evaluator == "net" and planned[0]:
+    if a.evaluator == "net":
         run(a.warm_moves * n, False)   # whole moves, boundaries included: trees, games and the evaluation cache in steady state
     st_pre = e.game_status()
     half = min(a.steps, n) // 2
@@ -504,8 +504,8 @@ def main():
         net_desc = f"random-init {a.blocks}x{a.channels} policy-value net fp16" if a.evaluator == "net" else "stub evaluator (uniform priors, v=0)"
         state_desc = (f"boards in steady state (plies 1..{a.preroll_plies} of their games, evenly; games adjudicated at {a.max_plies} plies)"
                       if a.preroll_plies > 0 else "all boards from the opening position")
-        if planned[0]:
-            state_desc += f", evaluation cache of 2^{e.eval_cache_log2} positions warmed by {a.warm_moves} untimed moves"
+        if a.evaluator == "net":
+            state_desc += f", {a.warm_moves} untimed moves searched before the window" + (f" (they warm the evaluation cache of 2^{e.eval_cache_log2} positions)" if planned[0] else "")
         out = {
             "metric": "self-play MCTS simulations/sec", "value": value, "unit": "sims/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
@@ -517,7 +517,7 @@ def main():
                       "u8 rules / f32 Q (reference CPU path) / f64 PUCT (net: fp16)"), "data": "synthetic",
             "config": {"workload": f"{B} concurrent boards/GPU x {n} sims/move, Dirichlet root noise on (device Philox), " + net_desc + ", " + state_desc,
                        "boards_per_gpu": B, "sims_per_move": n, "evaluator": a.evaluator,
-                       "preroll_plies": a.preroll_plies, "max_plies": a.max_plies, "warm_moves": a.warm_moves if planned[0] else 0,
+                       "preroll_plies": a.preroll_plies, "max_plies": a.max_plies, "warm_moves": a.warm_moves if a.evaluator == "net" else 0,
                        "window": f"{a.steps} steps starting at simulation {phase + a.warmup} of a move: "
                                  f"{boundary['n']} move boundary(ies) inside the timed window"},
             "moves_per_sec": moves_per_sec,
