@@ -22,7 +22,8 @@ MASK_WORDS = 66
 PLANES = 10710
 REC_BYTES, REC_HDR, REC_IDS, REC_PI = 880, 96, 112, 368  # compact ply record (include/cczero.h CCZ_REC_*)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
+CONV_RELU, CONV_DESCENDING, CONV_FORCE_SMALL, CONV_FORCE_TILE, CONV_G16 = 1, 2, 16, 32, 64  # CCZ_CONV_* flag bits
 RULE_PERPETUAL_CHECK = 1
 RULE_PAWN_MOVE_RESETS_CLOCK = 2
 FLAG_REFERENCE_QUIRKS = 1
@@ -103,6 +104,7 @@ PROTOTYPES = {
     "ccz_conv3x3_stem_f16": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int32]),
     "ccz_pack_live_planes_f16": (C.c_int, [_P, _P, _P, C.c_int32]),
     "ccz_pack_live_planes_rows_f16": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P]),
+    "ccz_pack_live_planes_g16_f16": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P]),
     "ccz_conv3x3_c256_f16_live": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, _P, C.c_int32, C.c_int32]),
     "ccz_conv3x3_stem_f16_live": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int32, _P, C.c_int32, C.c_int32]),
 }

@@ -16,8 +16,12 @@
 #include "cczero_netops.h"
 #include "cczero_conv.h"
 #include "cczero_conv_small.h"
+#include "cczero_conv_g16.h"
 #ifdef CCZ_CONV3 // round 3's form without a barrier per half-step: measured slower, A-B builds only (make ab NAME=v3 ABFLAGS=-DCCZ_CONV3)
 #include "../../profiles/experiments/cczero_conv3.h"
+#endif
+#ifdef CCZ_CONV4 // group-of-16 layout, off-board taps skipped: A-B builds only (make ab NAME=v4 ABFLAGS=-DCCZ_CONV4)
+#include "../../profiles/experiments/cczero_conv4.h"
 #endif
 #ifdef CCZ_CONV2 // experimental second form of the tower kernel: diagnostic / A-B builds only (make ab NAME=v2 ABFLAGS=-DCCZ_CONV2)
 #include "../../profiles/experiments/cczero_conv2.h"
@@ -748,6 +752,19 @@ static int conv3x3_launch(const char *who, void *stream, const void *x_dev, cons
         return fail(-1, "%s: pointers must be 16-byte aligned", who);
     if (x_dev == y_dev) return fail(-1, "%s: the output may alias the residual but not the input", who);
     if (n_pixels == 0) return 0;
+    if (relu & CCZ_CONV_G16) { // rows in the group-of-16 layout: whole-rank tiles, off-board taps skipped (cczero_conv_g16.h)
+        if (n_pixels % 1440) return fail(-1, "%s: CCZ_CONV_G16 needs a multiple of 16 boards", who);
+        const unsigned t16 = (unsigned)(n_pixels / kG5Rows);
+        const int fl = relu & 3;
+        if (residual_dev)
+            hipLaunchKernelGGL(k_conv3x3_g16<true>, dim3(t16), dim3(512), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev,
+                               (const float *)bias_f32_dev, (const _Float16 *)residual_dev, (_Float16 *)y_dev, (int)n_pixels, fl, cin, (const int *)live_rows_dev, (int)row0);
+        else
+            hipLaunchKernelGGL(k_conv3x3_g16<false>, dim3(t16), dim3(512), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev,
+                               (const float *)bias_f32_dev, (const _Float16 *)nullptr, (_Float16 *)y_dev, (int)n_pixels, fl, cin, (const int *)live_rows_dev, (int)row0);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     // Small batches (one game at a time; up to kSmallMaxPixels): the 16-channel x 64-pixel-block kernel spreads them over the chip
     // instead of filling a few 256-pixel tiles. Same operations in the same order: bit-identical results (cczero_conv_small.h).
     // flags bit 4 forces it, bit 5 forces the tile kernel (A/B runs, tests).
@@ -785,6 +802,19 @@ static int conv3x3_launch(const char *who, void *stream, const void *x_dev, cons
                                (const float *)bias_f32_dev, (const _Float16 *)residual_dev, (_Float16 *)y_dev, (int)n_pixels, (int)(relu & 3), cin);
         else
             hipLaunchKernelGGL(k_conv3x3_v3<false>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev,
+                               (const float *)bias_f32_dev, (const _Float16 *)nullptr, (_Float16 *)y_dev, (int)n_pixels, (int)(relu & 3), cin);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+#endif
+#ifdef CCZ_CONV4
+    if (relu & 128) { // bit 6: rows in the group-of-16 layout (profiles/experiments/cczero_conv4.h)
+        if (n_pixels % 1440) return fail(-1, "%s: the group-of-16 layout needs a multiple of 16 boards", who);
+        if (residual_dev)
+            hipLaunchKernelGGL(k_conv3x3_v4<true>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev,
+                               (const float *)bias_f32_dev, (const _Float16 *)residual_dev, (_Float16 *)y_dev, (int)n_pixels, (int)(relu & 3), cin);
+        else
+            hipLaunchKernelGGL(k_conv3x3_v4<false>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev,
                                (const float *)bias_f32_dev, (const _Float16 *)nullptr, (_Float16 *)y_dev, (int)n_pixels, (int)(relu & 3), cin);
         HIP_TRY(hipGetLastError());
         return 0;
@@ -834,7 +864,18 @@ int ccz_pack_live_planes_rows_f16(void *stream, const void *leaf_dev, void *x64_
     if ((uintptr_t)x64_dev & 15) return fail(-1, "ccz_pack_live_planes_rows_f16: output must be 16-byte aligned");
     if (n_boards == 0) return 0;
     hipLaunchKernelGGL(k_pack_live_planes, dim3((unsigned)n_boards), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)leaf_dev, (half8_t *)x64_dev, (int)n_boards,
-                       (const int *)rows_dev, (const int *)n_rows_dev);
+                       (const int *)rows_dev, (const int *)n_rows_dev, 0);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ccz_pack_live_planes_g16_f16(void *stream, const void *leaf_dev, void *x64_dev, int32_t n_boards, const int32_t *rows_dev, const int32_t *n_rows_dev)
+{
+    if (!leaf_dev || !x64_dev || n_boards < 0 || (!rows_dev) != (!n_rows_dev)) return fail(-1, "ccz_pack_live_planes_g16_f16: bad arguments");
+    if ((uintptr_t)x64_dev & 15) return fail(-1, "ccz_pack_live_planes_g16_f16: output must be 16-byte aligned");
+    if (n_boards == 0) return 0;
+    hipLaunchKernelGGL(k_pack_live_planes, dim3((unsigned)n_boards), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)leaf_dev, (half8_t *)x64_dev, (int)n_boards,
+                       (const int *)rows_dev, (const int *)n_rows_dev, 1);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -845,7 +886,7 @@ int ccz_pack_live_planes_f16(void *stream, const void *leaf_dev, void *x64_dev, 
     if ((uintptr_t)x64_dev & 15) return fail(-1, "ccz_pack_live_planes_f16: output must be 16-byte aligned");
     if (n_boards == 0) return 0;
     hipLaunchKernelGGL(k_pack_live_planes, dim3((unsigned)n_boards), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)leaf_dev, (half8_t *)x64_dev, (int)n_boards,
-                       (const int *)nullptr, (const int *)nullptr);
+                       (const int *)nullptr, (const int *)nullptr, 0);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -13,7 +13,8 @@
 //     a 128 x 64 accumulator block per wave = 8 x 4 tiles of v_mfma_f32_16x16x32_f16 (128 VGPRs). The 16x16x32
 //     shape, not 32x32x16: this loop is power-limited and the chip holds a higher clock on it at equal cycles per
 //     FLOP (MI355X_MICROARCH.md, DVFS give-back item 7); measured -6.6 % time for the same tile and pipeline.
-//   * K order = 4 input-channel chunks of 64 (outer) x 9 taps x 2 halves of 32 (inner) = 72 half-steps; one
+//   * K order = 4 input-channel chunks of 64 (outer) x 2 halves of 32 x 9 taps (inner) = 72 half-steps, i.e. chunks of 32
+//     input channels x 9 taps: the order all three convolution kernels add in (cczero_conv_g16.h, cczero_conv_small.h). One
 //     half-step is ONE k-step of the MFMA: 8 weight fragments (lane l: row l & 15, k-chunk l >> 4 of a 64-byte
 //     weight row), 4 pixel fragments (pixel l & 15, k-chunk 4*KH + (l >> 4) of the 128-byte slab row), 32 MFMAs.
 //     The activation slab of a chunk (the tile's 256 pixels + a 10-pixel halo either side, 64 channels) is
@@ -179,7 +180,6 @@ template <int U>
 __device__ __forceinline__ void cv_halfstep(const CvCtx &c, cv_f32x4 (&acc)[8][4], int chunk, int &ring_rd, int &ring_wr, CvTap &tap,
                                               cv_half8 (&alo)[4], cv_half8 (&ahi)[4], cv_half8 (&bcur)[4], cv_half8 (&bnxt)[4])
 {
-    constexpr int KH = U & 1;
     unsigned char *const lds = c.lds;
 
     constexpr int pass = cv_act_pass(U);
@@ -190,7 +190,7 @@ __device__ __forceinline__ void cv_halfstep(const CvCtx &c, cv_f32x4 (&acc)[8][4
     if (!CV_DBG(c, 1)) {
         constexpr int U2 = (U + kCvAhead) % 18;
         const int chunk2 = (chunk + (U + kCvAhead >= 18 ? 1 : 0)) & c.cmask;
-        const _Float16 *s = c.wsrc + (U2 >> 1) * c.cin + chunk2 * 64 + (U2 & 1) * 32;
+        const _Float16 *s = c.wsrc + (U2 % 9) * c.cin + chunk2 * 64 + (U2 / 9) * 32;
         unsigned char *d = lds + ring_wr * kCvWBytes + c.wave_dst;
         cv_glds16(s, d);
         cv_glds16(s + 128l * (9 * c.cin), d + 8192);
@@ -209,9 +209,9 @@ __device__ __forceinline__ void cv_halfstep(const CvCtx &c, cv_f32x4 (&acc)[8][4
     if (!CV_DBG(c, 32)) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
-    if constexpr (KH == 1) tap = cv_tap<(Un >> 1)>(c, kCvAOff + ((chunk + (U == 17 ? 1 : 0)) & 1) * kCvABytes);
+    tap = cv_tap<(Un % 9)>(c, kCvAOff + ((chunk + (U == 17 ? 1 : 0)) & 1) * kCvABytes);
     cv_read_w<0>(c, ring_rd, alo);
-    cv_read_x<(Un >> 1), (Un & 1)>(c, tap, bnxt);
+    cv_read_x<(Un % 9), (Un / 9)>(c, tap, bnxt);
     cv_mfma16<1>(c, acc, ahi, bcur);
 }
 
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256(const _Float16 *__restrict
     for (int it = 0; it < 5; ++it) cv_glds16(X + c.xsrc[it], lds + kCvAOff + (it < 4 ? it * 64 : 224) * 128 + c.wave_dst);
 #pragma unroll
     for (int u = 0; u < kCvAhead; ++u) {
-        const _Float16 *s = c.wsrc + (u >> 1) * cin + (u & 1) * 32;
+        const _Float16 *s = c.wsrc + (u % 9) * cin + (u / 9) * 32;
         unsigned char *d = lds + u * kCvWBytes + c.wave_dst;
         cv_glds16(s, d);
         cv_glds16(s + 128l * (9 * cin), d + 8192);

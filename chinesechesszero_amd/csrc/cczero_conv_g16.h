@@ -1,0 +1,320 @@
+// cczero_conv_g16.h -- the tower convolution for LARGE batches: group-of-16 activation layout, whole-rank tiles.
+//
+//   y[p, co] = relu( bias[co] + sum_{tap, ci} w[co, tap, ci] * x[p + 9*dy + dx, ci]  [+ res[p, co]] )
+//
+// (reference net.py:20-43: conv3x3 -> BN -> [+x] -> ReLU with BN folded into w / bias.) k_conv3x3_c256 (cczero_conv.h) works on
+// NHWC rows in board order; 110 of the 810 (pixel, tap) pairs of a 10 x 9 board point off the board and it multiplies a zero row
+// for them, because 16 consecutive pixels of ONE board never have the same tap off the board. This kernel changes what the
+// 16 columns of an MFMA block are:
+//
+//   * layout "G16" (CCZ_CONV_G16): activation row = (g * 90 + pos) * 16 + j for board 16 g + j -- 16 consecutive rows = one
+//     board position ("cell") of 16 boards = one 16-column MFMA block: a tap is on the board for all 16 columns or for none.
+//   * tile = 2 whole ranks of one 16-board group = 18 cells = 288 rows x all 256 output channels; 5 tiles per group,
+//     4096 boards = 1280 tiles = 5.0 rounds on 256 CUs (k_conv3x3_c256: 1440 tiles of 256 rows = 5.6 rounds).
+//   * 8 waves = 4 (64 output channels) x 2 (one rank = 9 cells each): 4 x 9 accumulator tiles per wave (144 VGPRs). The file
+//     of a cell is a compile-time constant of the accumulator tile: a tap with dx = -1 skips cell 0, dx = +1 skips cell 8 --
+//     32 instead of 36 MFMAs in six of nine taps, the same for every wave, so nothing of it is lost at the barrier (-7.4 %
+//     MFMAs). The slab rows of the ranks above rank 0 and below rank 9 are zeroed once per chunk by the threads that staged
+//     them, so dy needs no test. No per-lane validity flags, no v_cndmask, no per-tap address arithmetic: every LDS address
+//     in the loop is a lane constant + an immediate.
+//   * K order = chunks of 32 input channels x 9 taps (one MFMA k-step each; all three convolution kernels add in this order,
+//     so their results are the same values -- up to the sign of a zero, where this one skips a product of zeros): 72
+//     half-steps per tower layer, one weight half-tile (256 output channels x 32 k, 16 KB) per half-step through a ring of
+//     five (three ahead, one barrier per half-step, LDS-DMA with counted vmcnt, as in k_conv3x3_c256). The slab of a chunk
+//     = the tile's 2 ranks + one rank either side = 36 cells = 576 rows of 64 B, double-buffered; ring + slabs = 152 KB.
+//   * pixel fragments are refilled in place: the nine fragments of the NEXT tap are requested one by one, each right after
+//     the MFMAs that consumed its register -- a whole half-step ahead of their use, no second register set. The order is
+//     pinned (one scheduling region per cell): left to the scheduler the refills move up and the kernel spills.
+//
+// Measured (profiles/r03_conv_g16.json, 4096 boards, one layer in isolation, interleaved with k_conv3x3_c256 on one device):
+// 338-348 us against 355-363 us. The loop is power-limited like its predecessor's: the gain is about the
+// energy of the MFMAs no longer issued; 3 / 5 / 7 cells in front of the barrier and the weight DMA behind it are all within noise.
+#pragma once
+#include "cczero_conv.h"
+
+namespace ccz {
+
+constexpr int kG5Rows = 288;                               // rows per tile (18 cells x 16 boards)
+constexpr int kG5SlabRows = 576;                           // 36 cells
+constexpr int kG5SlabBytes = kG5SlabRows * 64;             // 36,864 B per 32-channel chunk
+constexpr int kG5WBytes = 256 * 64;                        // one half-step of weights
+constexpr int kG5Ring = 5, kG5Ahead = 3;
+constexpr int kG5AOff = kG5Ring * kG5WBytes;               // LDS: [weight ring | slab 0 | slab 1]
+constexpr int kG5Dump = kG5AOff + 2 * kG5SlabBytes;        // 8 x 1 KB: where a wave's zero stores go when it has no row to zero
+constexpr int kG5Lds = kG5Dump + 8 * 1024;                 // 163,840 B = all of it
+constexpr int kG5ERow = 528;                               // epilogue image: bytes per row (512 + pad)
+static_assert(kG5Rows * kG5ERow <= kG5Dump, "epilogue image must fit the operand buffers");
+
+struct G5Ctx {
+    unsigned char *lds;
+    const _Float16 *X, *W;   // uniform bases: every DMA is base (scalar) + 32-bit element offset (one VGPR)
+    unsigned xoff[5];        // per staging pass: this thread's 16-byte source in X (chunk 0), row clamped into the tensor
+    unsigned woff;           // this thread's 16-byte weight source in W (row pass 0, tap 0, chunk 0)
+    int zo[4], zd[4];        // SCALAR: where this wave's zero stores go for slab 0 (pass 0, 1, 3, 4) and the step to slab 1 (0 for the dump area)
+    int wave_dst;            // w * 1024
+    int lane16;              // (lane & 63) * 16
+    int wave_dst4;           // LDS offset of this wave's piece in staging pass 4 (waves 4-7 repeat their pass-3 piece)
+    int a_off;               // weight fragment offset inside a ring slot (tile 0; tile i: + 1024 i)
+    int vb[2];               // this lane's pixel-fragment base in slab 0 / 1 (cell 0 of the wave's rank at tap offset 0 = + 9 * 1024)
+    int cin, cmask;          // input channels; number of 32-channel chunks - 1
+};
+
+__host__ __device__ constexpr bool g5_slab_tap(int t) { return t >= 1 && t <= 5; }
+// DMA loads younger than the weight half-tile the NEXT half-step reads (issue order per half-step: slab piece, 2 weight loads)
+constexpr int kG5Split = 7; // cells in front of the barrier (3 / 5 / 7 and the weight DMA behind the barrier: 344-351 us, noise)
+__host__ __device__ constexpr int g5_vmcnt(int t) { return 4 + (g5_slab_tap(t) ? 1 : 0) + (g5_slab_tap(t - 1) ? 1 : 0); }
+
+template <int T, int N> __host__ __device__ constexpr bool g5_on_board() // is tap T of the cell with file N on the board (dx only)
+{
+    return !((T % 3 == 0 && N == 0) || (T % 3 == 2 && N == 8));
+}
+
+// The rank above rank 0 (tiles with k = 0) and the rank below rank 9 (k = 4) do not exist: their slab rows were staged from
+// clamped addresses (the DMA count stays static) and are overwritten with zeros by the thread that staged them, after its DMA has
+// landed and before the barrier that publishes the slab. Rows 0..143 / 432..575 = whole 16-row pieces, so the tests are
+// wave-uniform -- and there are no tests in the loop: the four stores always execute, a wave that has nothing to zero aims
+// them at its 1 KB dump area behind the slabs (a branch here splits the loop body and costs the register allocation 90 spills).
+__device__ __forceinline__ void g5_zero_ranks(const G5Ctx &c, int buf)
+{
+    int l16 = c.lane16, zero = 0;
+    asm volatile("" : "+v"(l16), "+v"(zero)); // formed here: as loop invariants the four addresses and the zero vector hold 8 registers
+    typedef int g5_int4 __attribute__((ext_vector_type(4)));
+    const g5_int4 z = {zero, zero, zero, zero};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *(g5_int4 *)(c.lds + (l16 + (c.zo[j] + buf * c.zd[j]))) = z;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// One half-step = tap T of a 32-channel chunk; J = its index inside the unrolled pair of chunks (parity of the A register
+// set = J & 1, slab buffer = J / 9).
+template <int J>
+__device__ __forceinline__ void g5_step(const G5Ctx &c, cv_f32x4 (&acc)[4][9], int chunk, int &ring_rd, int &ring_wr,
+                                         cv_half8 (&a0)[4], cv_half8 (&a1)[4], cv_half8 (&b)[9])
+{
+    constexpr int T = J % 9, BUF = J / 9;
+    constexpr int Tn = (T + 1) % 9, BUFn = (T == 8) ? 1 - BUF : BUF;
+    constexpr int deltan = 9 * (Tn / 3 - 1) + (Tn % 3 - 1);
+    cv_half8 (&acur)[4] = (J & 1) ? a1 : a0;
+    cv_half8 (&anxt)[4] = (J & 1) ? a0 : a1;
+    unsigned char *const lds = c.lds;
+
+    // the order below is pinned (one scheduling region per cell): a fragment register is refilled right AFTER the MFMAs that read
+    // it -- left to the scheduler the refills move up and every fragment needs a second register
+#define G5_CELL(N)                                                                                                        \
+    {                                                                                                                     \
+        if constexpr (g5_on_board<T, N>()) {                                                                              \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
+                acc[i][N] = __builtin_amdgcn_mfma_f32_16x16x32_f16(acur[i], b[N], acc[i][N], 0, 0, 0);                    \
+        }                                                                                                                 \
+        if constexpr (g5_on_board<Tn, N>())                                                                               \
+            b[N] = *(const cv_half8 *)(lds + c.vb[BUFn] + (9 + N + deltan) * 1024);                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                                \
+    }
+#define G5_CELLS(LO, HI)                                                                                                  \
+    if constexpr (LO <= 0 && 0 < HI) G5_CELL(0) if constexpr (LO <= 1 && 1 < HI) G5_CELL(1) if constexpr (LO <= 2 && 2 < HI) G5_CELL(2) \
+    if constexpr (LO <= 3 && 3 < HI) G5_CELL(3) if constexpr (LO <= 4 && 4 < HI) G5_CELL(4) if constexpr (LO <= 5 && 5 < HI) G5_CELL(5) \
+    if constexpr (LO <= 6 && 6 < HI) G5_CELL(6) if constexpr (LO <= 7 && 7 < HI) G5_CELL(7) if constexpr (LO <= 8 && 8 < HI) G5_CELL(8)
+    constexpr int T2 = (T + kG5Ahead) % 9;
+    const int chunk2 = (chunk + (T + kG5Ahead >= 9 ? 1 : 0)) & c.cmask;
+    G5_CELLS(0, 1)
+    if constexpr (g5_slab_tap(T)) { // the next chunk's slab: 5 pieces per thread, in taps 1..5
+        constexpr int pass = T - 1;
+        const int nxt = (chunk + 1) & c.cmask; // past the last chunk: re-stage chunk 0 into the free buffer (keeps every count static)
+        cv_glds16(c.X + (c.xoff[pass] + (unsigned)(nxt * 32)), lds + kG5AOff + (1 - BUF) * kG5SlabBytes + (pass < 4 ? pass * 8192 + c.wave_dst : c.wave_dst4));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    G5_CELLS(1, 2)
+    {
+        unsigned wo = c.woff;
+        asm volatile("" : "+v"(wo)); // the address is formed here, per half-step: hoisted for 9 taps x 2 pieces it costs 36 registers
+        const unsigned o = wo + (unsigned)(T2 * c.cin + chunk2 * 32);
+        unsigned char *const d = lds + ring_wr * kG5WBytes + c.wave_dst;
+        cv_glds16(c.W + o, d);
+        __builtin_amdgcn_sched_barrier(0);
+        G5_CELLS(2, 3)
+        cv_glds16(c.W + (o + (unsigned)(128 * 9 * c.cin)), d + 8192);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    G5_CELLS(3, kG5Split)
+
+    ring_rd = ring_rd + 1 == kG5Ring ? 0 : ring_rd + 1;
+    cv_wait_vm<g5_vmcnt(T)>();
+    if constexpr (T == 7) g5_zero_ranks(c, 1 - BUF); // this thread's slab pieces of the next chunk have landed (all but the youngest weight loads)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    {
+        const unsigned char *wa = lds + (ring_rd * kG5WBytes + c.a_off);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) anxt[i] = *(const cv_half8 *)(wa + i * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    G5_CELLS(kG5Split, 9)
+    ring_wr = ring_wr + 1 == kG5Ring ? 0 : ring_wr + 1;
+#undef G5_CELLS
+#undef G5_CELL
+}
+
+template <bool RES>
+__global__ __launch_bounds__(512) void k_conv3x3_g16(const _Float16 *__restrict__ X, const _Float16 *__restrict__ W,
+                                                         const float *__restrict__ bias, const _Float16 *R,
+                                                         _Float16 *Y, int M, int relu, int cin, const int *live_rows, int row0)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kG5Lds];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q4 = lane >> 4;
+    const int wm = w & 3, wn = w >> 2; // the two waves of a SIMD share their weight fragments' rows
+    int tiles = gridDim.x;
+    if (live_rows) {
+        // Planned evaluator boundary (ccz_eval_plan): only the first *live_rows boards hold rows to compute, a number that stays
+        // on the device. Their 16-board groups are cut into n_parts EQUAL ranges; this launch is range `part` of them (the argument
+        // carries part | n_parts << 16) and finds its groups itself. The grid is sized for the largest possible range;
+        // workgroups beyond the live tiles leave at once.
+        const int part = row0 & 0xffff, n_parts = row0 >> 16;
+        const int G = (*live_rows + 15) >> 4;
+        const int per = (G + n_parts - 1) / n_parts;
+        const int first = part * per;
+        int live = G - first;
+        live = live < 0 ? 0 : (live > per ? per : live);
+        live = live > M / 1440 ? M / 1440 : live;
+        M = live * 1440;
+        tiles = live * 5;
+        if ((int)blockIdx.x >= tiles) return;
+        const long off = (long)first * 1440 * kCvC;
+        X += (long)first * 1440 * cin;
+        Y += off;
+        if (RES) R += off;
+    }
+    // flags bit 1: tiles in descending order (the tiles written last by the previous layer are then read first)
+    const int tile = __builtin_amdgcn_readfirstlane((relu & 2) ? tiles - 1 - blockIdx.x : blockIdx.x);
+    const int k = tile % 5;                  // ranks 2k, 2k + 1 of the tile's group
+    const long p0 = (long)tile * kG5Rows;    // = (group * 90 + 18 k) * 16
+    relu &= 1;
+
+    G5Ctx c;
+    c.lds = lds;
+    c.X = X;
+    c.W = W;
+    {
+        const bool z[4] = {k == 0, k == 0 && w == 0, k == 4 && w >= 3, k == 4 && w < 4}; // passes 0, 1, 3, 4
+        const int pass[4] = {0, 1, 3, 4};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            c.zo[j] = __builtin_amdgcn_readfirstlane(z[j] ? kG5AOff + pass[j] * 8192 + w * 1024 : kG5Dump + w * 1024);
+            c.zd[j] = __builtin_amdgcn_readfirstlane(z[j] ? kG5SlabBytes : 0);
+        }
+    }
+    c.wave_dst = w * 1024;
+    c.lane16 = lane * 16;
+    c.wave_dst4 = (w < 4 ? 4 : 3) * 8192 + w * 1024;
+    c.cin = cin;
+    c.cmask = (cin >> 5) - 1;
+    {
+        // slab row sr (0..575) = tensor row p0 - 144 + sr: rank 2k - 1 + sr / 144 of the group; 64-byte rows, position pos of
+        // row sr holds source chunk pos ^ f(sr), f = (-(sr >> 2)) & 3 (conflict-free for the 16 rows x 4 chunks one ds_read_b128
+        // of this MFMA shape covers)
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+            const int piece = (it < 4 || w < 4) ? it * 512 + tid : 3 * 512 + tid; // waves 4-7 repeat pass 3 (same bytes, same place)
+            const int sr = piece >> 2, pos = piece & 3;
+            const int schunk = pos ^ ((0 - (sr >> 2)) & 3);
+            long p = p0 - 144 + sr;
+            p = p < 0 ? 0 : (p > (long)M - 1 ? (long)M - 1 : p);
+            c.xoff[it] = (unsigned)(p * cin + schunk * 8);
+        }
+        const int wrow = tid >> 2, wpos = tid & 3;
+        c.woff = (unsigned)(wrow * (9 * cin) + ((wpos ^ ((0 - (wrow >> 2)) & 3)) * 8));
+    }
+    // ---- prologue: slab of chunk 0, weight half-tiles 0..2; the per-lane setup below runs while the DMA is in flight
+#pragma unroll
+    for (int it = 0; it < 5; ++it) cv_glds16(X + c.xoff[it], lds + kG5AOff + (it < 4 ? it * 8192 + c.wave_dst : c.wave_dst4));
+#pragma unroll
+    for (int u = 0; u < kG5Ahead; ++u) {
+        const unsigned o = c.woff + (unsigned)(u * cin);
+        unsigned char *d = lds + u * kG5WBytes + c.wave_dst;
+        cv_glds16(W + o, d);
+        cv_glds16(W + (o + (unsigned)(128 * 9 * cin)), d + 8192);
+    }
+    const int lane1 = r * 64 + ((q4 ^ ((0 - (r >> 2)) & 3)) << 4);
+    c.a_off = wm * 4096 + lane1;                               // rows 64 wm + 16 i + r of the half-tile
+    c.vb[0] = kG5AOff + wn * 9 * 1024 + lane1;                 // slab cell 9 wn + n + 9 + delta, row r of it
+    c.vb[1] = c.vb[0] + kG5SlabBytes;
+
+    // the accumulators start at the bias
+    cv_f32x4 acc[4][9];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 bv = *(const float4 *)(bias + wm * 64 + i * 16 + 4 * q4);
+#pragma unroll
+        for (int n = 0; n < 9; ++n) {
+            acc[i][n][0] = bv.x; acc[i][n][1] = bv.y; acc[i][n][2] = bv.z; acc[i][n][3] = bv.w;
+        }
+    }
+
+    cv_wait_vm<4>();
+    g5_zero_ranks(c, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    int ring_rd = 0, ring_wr = kG5Ahead;
+    cv_half8 a0[4], a1[4], b[9];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a0[i] = *(const cv_half8 *)(lds + c.a_off + i * 1024);
+#pragma unroll
+    for (int n = 1; n < 9; ++n) b[n] = *(const cv_half8 *)(lds + c.vb[0] + (9 + n - 10) * 1024); // tap 0: delta = -10, cell 0 is off the board
+    b[0] = b[1];
+    for (int chunk = 0; chunk <= c.cmask; chunk += 2) {
+#define G5_S(j) g5_step<j>(c, acc, chunk + (j) / 9, ring_rd, ring_wr, a0, a1, b)
+        G5_S(0); G5_S(1); G5_S(2); G5_S(3); G5_S(4); G5_S(5); G5_S(6); G5_S(7); G5_S(8);
+        G5_S(9); G5_S(10); G5_S(11); G5_S(12); G5_S(13); G5_S(14); G5_S(15); G5_S(16); G5_S(17);
+#undef G5_S
+    }
+    cv_wait_vm<0>(); // the wrapped-around DMA loads must land before the LDS is reused / released
+
+    // ---- epilogue: every wave writes its 64 channels x 144 rows into the [row][channel] image in LDS; then wave w owns
+    // rows 36 w .. 36 w + 35 and moves whole 512-byte rows (residual in, output out)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier(); // every wave is done reading the slabs and the ring
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int col = wm * 64 + i * 16 + 4 * q4;
+#pragma unroll
+        for (int n = 0; n < 9; ++n) {
+            cv_half4 o;
+            o[0] = (_Float16)acc[i][n][0];
+            o[1] = (_Float16)acc[i][n][1];
+            o[2] = (_Float16)acc[i][n][2];
+            o[3] = (_Float16)acc[i][n][3];
+            *(cv_half4 *)(lds + ((wn * 9 + n) * 16 + r) * kG5ERow + col * 2) = o;
+        }
+    }
+    const int prow = lane >> 5, piece = lane & 31;
+    const long pbase = p0 + w * 36 + prow;
+    cv_half8 rv[18];
+    if (RES) {
+#pragma unroll
+        for (int it = 0; it < 18; ++it) rv[it] = *(const cv_half8 *)(R + (pbase + it * 2) * kCvC + piece * 8);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const cv_half8 zero = (cv_half8)(_Float16)0;
+        const unsigned char *eb = lds + (w * 36 + prow) * kG5ERow + piece * 16;
+#pragma unroll
+        for (int it = 0; it < 18; ++it) {
+            cv_half8 v = *(const cv_half8 *)(eb + it * 2 * kG5ERow);
+            if (RES) v = v + rv[it];
+            if (relu) v = __builtin_elementwise_max(v, zero);
+            *(cv_half8 *)(Y + (pbase + it * 2) * kCvC + piece * 8) = v;
+        }
+    }
+}
+
+} // namespace ccz

@@ -9,7 +9,7 @@
 //   * one workgroup = 4 waves = a 16-output-channel x 64-pixel block, one 16-pixel tile per wave: 2 x 16 = 32 workgroups for
 //     one board, every one on its own CU.
 //   * the same MFMA (v_mfma_f32_16x16x32_f16), the same fragment composition (weights = A operand: row lane & 15, k-chunk
-//     lane >> 4; pixels = B operand) and the same K order (input-channel chunks of 64 x 9 taps x 2 halves of 32, accumulators
+//     lane >> 4; pixels = B operand) and the same K order (input-channel chunks of 32 x 9 taps, accumulators
 //     starting at the bias, fp16 rounding before the residual add) as k_conv3x3_c256: every output element is produced by the
 //     same sequence of operations on the same operands, so the result is BIT-IDENTICAL to the tile kernel's -- a board's tower
 //     activations do not depend on the size of the batch it is evaluated in. (That rules out splitting K over waves: the
@@ -58,8 +58,8 @@ __global__ __launch_bounds__(256) void k_conv3x3_small(const _Float16 *__restric
         for (int j = 0; j < kWIters; ++j) {
             const int i = j * 256 + tid;
             if (i < n_half * 64) {
-                const int h = i >> 6, l = i & 63, chunk = h / 18, u = h - chunk * 18;
-                v[j] = *(const cv_half8 *)(W + (long)(co0 + (l & 15)) * (9 * cin) + (u >> 1) * cin + chunk * 64 + (u & 1) * 32 + (l >> 4) * 8);
+                const int h = i >> 6, l = i & 63, c32 = h / 9, tap = h - c32 * 9;
+                v[j] = *(const cv_half8 *)(W + (long)(co0 + (l & 15)) * (9 * cin) + tap * cin + c32 * 32 + (l >> 4) * 8);
             }
         }
         (void)kW;
@@ -117,11 +117,11 @@ __global__ __launch_bounds__(256) void k_conv3x3_small(const _Float16 *__restric
     __syncthreads();
     if (p0 + wv * 16 >= M) return; // this wave's pixel tile lies past the tensor (it helped with the staging)
 
-    // ---- K loop from LDS: half-step h = (chunk, tap, half); the fragments of h + 1 are requested before the MFMA of h
+    // ---- K loop from LDS: half-step h = (chunk of 32 input channels, tap); the fragments of h + 1 are requested before the MFMA of h
     auto frag_b = [&](int h) {
-        const int chunk = h / 18, u = h - chunk * 18, tap = u >> 1, kh = u & 1;
+        const int c32 = h / 9, tap = h - c32 * 9;
         const int delta = 9 * (tap / 3 - 1) + (tap % 3 - 1);
-        const int c = chunk * 8 + kh * 4 + q4; // 16-byte chunk of this lane's k-range inside the slab row
+        const int c = c32 * 4 + q4; // 16-byte chunk of this lane's k-range inside the slab row
         const int row = kCvHalo + wv * 16 + r + delta;
         const bool ok = (vmask >> tap) & 1u;
         const int off = ok ? slab_off + row * row_bytes + (((c & ~swz) | ((c ^ row) & swz)) << 4) : zero_off;

@@ -31,8 +31,9 @@ __global__ __launch_bounds__(256) void k_bias_act(half8_t *__restrict__ y, const
 // search path (groups 7, 15, 16 = planes 49..55 and 105..118, net.py:160-173): pack them as NHWC rows of 64 channels
 // (21 live + 43 zeros), the stem input of the tower convolution kernel. One workgroup per board, 16 B per lane.
 // rows != nullptr (planned evaluator boundary, ccz_eval_plan): output row i is board rows[i], for i < *n_rows only.
+// g16: output rows in the group-of-16 layout (row (b / 16 * 90 + p) * 16 + b % 16, cczero_conv_g16.h) instead of b * 90 + p.
 __global__ __launch_bounds__(256) void k_pack_live_planes(const _Float16 *__restrict__ leaf, half8_t *__restrict__ out, int n_boards,
-                                                          const int *__restrict__ rows, const int *__restrict__ n_rows)
+                                                          const int *__restrict__ rows, const int *__restrict__ n_rows, int g16)
 {
     const long b = blockIdx.x;
     long sb = b;
@@ -51,7 +52,8 @@ __global__ __launch_bounds__(256) void k_pack_live_planes(const _Float16 *__rest
                 if (ch < 21) v[e] = src[(ch < 7 ? 49 + ch : 98 + ch) * 90 + p];
             }
         }
-        out[(b * 90 + p) * 8 + cpos] = v;
+        const long row = g16 ? ((b >> 4) * 90 + p) * 16 + (b & 15) : b * 90 + p;
+        out[row * 8 + cpos] = v;
     }
 }
 

@@ -164,10 +164,17 @@ class InferenceNet(nn.Module):
         return bool(x.is_cuda and x.dtype == torch.float16 and x.shape[1] == 256 and x.shape[0] >= self.FUSED_MIN_BOARDS
                     and x.is_contiguous(memory_format=torch.channels_last))
 
+    G16_MIN_BOARDS = 65  # batches above the small kernel's range run in the group-of-16 row layout (cczero_conv_g16.h: whole-rank
+    # tiles, off-board taps skipped), padded to a multiple of 16 boards; CCZ_CONV_LAYOUT=nhwc keeps the board-major rows and the
+    # 256-pixel tile kernel for A/B runs. Same values either way (all three kernels add in the same order).
+
+    def _g16(self, B) -> bool:
+        return B >= self.G16_MIN_BOARDS and os.environ.get("CCZ_CONV_LAYOUT", "g16") != "nhwc" and not self._force_flag()
+
     TOWER_GROUP_BOARDS = 2048  # boards per sequential group (working set of a group fits the Infinity Cache); env CCZ_TOWER_GROUPS
     TOWER_CHAINS = 2  # independent board ranges run as concurrent launch chains (one HIP stream each); env CCZ_TOWER_CHAINS (<= 8)
 
-    def _tower_fused(self, x, plan=None):
+    def _tower_fused(self, x, plan=None, g16=None):
         """40 residual blocks = 80 launches of one kernel: conv3x3 + bias [+ x] + ReLU each (reference net.py:20-43).
         ``plan`` = (rows, n_rows) of the planned evaluator boundary: only the first ``n_rows`` (a device value) boards of ``x``
         are live; every launch skips the tiles past them (``ccz_conv3x3_c256_f16_live``).
@@ -181,6 +188,8 @@ class InferenceNet(nn.Module):
         import ctypes as C
         from . import _lib
         L = _lib.lib()
+        if g16 is None:   # x as _stem_fused returned it for a batch of this size (padded to whole groups of 16 boards)
+            g16 = self._g16(x.shape[0]) and x.shape[0] % 16 == 0
         y = torch.empty_like(x)
         # groups of TOWER_GROUP_BOARDS boards go through all 80 layers one after the other: the two activation buffers of a
         # group (2 x 94 MB at 2048 boards) then stay inside the 256 MB Infinity Cache from layer to layer
@@ -190,14 +199,14 @@ class InferenceNet(nn.Module):
         if torch.cuda.is_current_stream_capturing():
             groups = 1
         if plan is not None:
-            self._tower_planned(L, C, x, y, plan, groups)
+            self._tower_planned(L, C, x, y, plan, groups, g16)
             return x
         gstep = -(-(-(-Bt // groups)) // 128) * 128 if groups > 1 else Bt
         for g0 in range(0, Bt, gstep):
-            self._tower_range(L, C, x, y, g0, min(Bt, g0 + gstep))
+            self._tower_range(L, C, x, y, g0, min(Bt, g0 + gstep), g16)
         return x
 
-    def _tower_planned(self, L, C, x, y, plan, groups):
+    def _tower_planned(self, L, C, x, y, plan, groups, g16=False):
         """The tower on the LIVE rows of a planned batch (``ccz_eval_plan``): the live rows -- a device-side count -- are cut
         into groups x chains EQUAL ranges by the kernel itself (``ccz_conv3x3_c256_f16_live``: part / n_parts), so that the
         concurrent chains of a group stay balanced whatever the live count is. Launch structure as in :meth:`_tower_range`:
@@ -209,7 +218,11 @@ class InferenceNet(nn.Module):
         per_group = -(-B // groups)
         chains = 1 if torch.cuda.is_current_stream_capturing() else max(1, min(want, 8, per_group // 256))
         n_parts = groups * chains
-        cap = -(-(-(-B // n_parts)) // 8) * 8 * 90           # pixels of the largest range a launch may get
+        if g16:
+            cap = -(-(B // 16) // n_parts) * 1440            # whole 16-board groups (B is padded to a multiple of 16)
+        else:
+            cap = -(-(-(-B // n_parts)) // 8) * 8 * 90       # pixels of the largest range a launch may get
+        lay = _lib.CONV_G16 if g16 else 0
         if chains > 1:
             pool = getattr(self, "_chain_streams", None)
             if pool is None or pool[0] != x.device or len(pool[1]) < chains - 1:
@@ -228,15 +241,15 @@ class InferenceNet(nn.Module):
             for i in range(0, len(self.ws), 2):
                 w1, b1_, w2, b2_ = (C.c_void_p(t.data_ptr()) for t in (self.ws[i], self.bs32[i], self.ws[i + 1], self.bs32[i + 1]))
                 for k, st in enumerate(streams):
-                    _lib.check(L.ccz_conv3x3_c256_f16_live(C.c_void_p(st.cuda_stream), xp, w1, b1_, None, yp, cap, 1 | down, live, g * chains + k, n_parts))
+                    _lib.check(L.ccz_conv3x3_c256_f16_live(C.c_void_p(st.cuda_stream), xp, w1, b1_, None, yp, cap, 1 | down | lay, live, g * chains + k, n_parts))
                 for k, st in enumerate(streams):
-                    _lib.check(L.ccz_conv3x3_c256_f16_live(C.c_void_p(st.cuda_stream), yp, w2, b2_, xp, xp, cap, 1, live, g * chains + k, n_parts))
+                    _lib.check(L.ccz_conv3x3_c256_f16_live(C.c_void_p(st.cuda_stream), yp, w2, b2_, xp, xp, cap, 1 | lay, live, g * chains + k, n_parts))
             for st in streams[1:]:
                 join = torch.cuda.Event()
                 join.record(st)
                 cur.wait_event(join)
 
-    def _tower_range(self, L, C, x, y, lo, hi):
+    def _tower_range(self, L, C, x, y, lo, hi, g16=False):
         """Boards [lo, hi) through all 80 layers, as TOWER_CHAINS concurrent launch chains."""
         from . import _lib
         B = hi - lo
@@ -268,7 +281,7 @@ class InferenceNet(nn.Module):
         down = 2 if os.environ.get("CCZ_CONV_ZIGZAG", "1") == "1" else 0
         v2 = 4 if os.environ.get("CCZ_CONV_V2", "0") == "1" else 0  # A/B only: the experimental two-workgroups-per-CU form
         # (cczero_conv2.h, compiled into diagnostic builds with -DCCZ_CONV2; the shipped library ignores the bit)
-        v2 |= self._force_flag()
+        v2 |= self._force_flag() | (_lib.CONV_G16 if g16 else 0)
         for i in range(0, len(self.ws), 2):
             w1, b1_, w2, b2_ = (C.c_void_p(t.data_ptr()) for t in (self.ws[i], self.bs32[i], self.ws[i + 1], self.bs32[i + 1]))
             for _, s, xp, yp, n_pixels, _b0 in chains:
@@ -286,7 +299,7 @@ class InferenceNet(nn.Module):
         whatever the batch size (the library picks by batch size otherwise; the results are bit-identical either way)."""
         return {"small": 16, "tile": 32}.get(os.environ.get("CCZ_CONV_FORCE", ""), 0)
 
-    def _stem_fused(self, leaf_input, plan=None):
+    def _stem_fused(self, leaf_input, plan=None, g16=None):
         """Stem on the same MFMA kernel: pack the 21 live planes as NHWC rows of 64 channels, then one 64-channel chunk of
         the tower convolution (conv3x3 + bias + ReLU). Replaces cat + layout copy + MIOpen convolution + epilogue pass.
         With a ``plan`` the pack GATHERS: output row i is board rows[i], for the live rows only."""
@@ -294,28 +307,48 @@ class InferenceNet(nn.Module):
         from . import _lib
         L = _lib.lib()
         B = leaf_input.shape[0]
+        if g16 is None:
+            g16 = self._g16(B)
         s = C.c_void_p(torch.cuda.current_stream(leaf_input.device).cuda_stream)
+        Bp = -(-B // 16) * 16 if g16 else B          # group-of-16 layout: whole groups; the padding boards hold zeros
+        lay = _lib.CONV_G16 if g16 else 0
         if plan is None:
-            x64 = torch.empty((B, 90, 64), dtype=torch.float16, device=leaf_input.device)
-            y = torch.empty((B, 256, 10, 9), dtype=torch.float16, device=leaf_input.device, memory_format=torch.channels_last)
-            _lib.check(L.ccz_pack_live_planes_f16(s, C.c_void_p(leaf_input.data_ptr()), C.c_void_p(x64.data_ptr()), B))
+            x64 = (torch.zeros if Bp != B else torch.empty)((Bp, 90, 64), dtype=torch.float16, device=leaf_input.device)
+            y = torch.empty((Bp, 256, 10, 9), dtype=torch.float16, device=leaf_input.device, memory_format=torch.channels_last)
+            if g16:
+                _lib.check(L.ccz_pack_live_planes_g16_f16(s, C.c_void_p(leaf_input.data_ptr()), C.c_void_p(x64.data_ptr()), B, None, None))
+            else:
+                _lib.check(L.ccz_pack_live_planes_f16(s, C.c_void_p(leaf_input.data_ptr()), C.c_void_p(x64.data_ptr()), B))
             _lib.check(L.ccz_conv3x3_stem_f16(s, C.c_void_p(x64.data_ptr()), C.c_void_p(self.stem_w64.data_ptr()), C.c_void_p(self.stem_b32.data_ptr()),
-                                              C.c_void_p(y.data_ptr()), B * 90, 1 | self._force_flag()))
+                                              C.c_void_p(y.data_ptr()), Bp * 90, 1 | self._force_flag() | lay))
             return y
         rows, n_rows = plan
         # rows past the live ones are never computed: they must still hold finite numbers for the heads' GEMMs (whose results
         # for those rows nobody reads). Two persistent buffers, zeroed ONCE: whatever a row holds later is an old finite result.
         bufs = self.__dict__.setdefault("_plan_bufs", {})
-        key = (B, leaf_input.device)
+        key = (Bp, leaf_input.device, g16)
         if key not in bufs:
-            bufs[key] = (torch.zeros((B, 90, 64), dtype=torch.float16, device=leaf_input.device),
-                         torch.empty((B, 256, 10, 9), dtype=torch.float16, device=leaf_input.device, memory_format=torch.channels_last).zero_())
+            bufs[key] = (torch.zeros((Bp, 90, 64), dtype=torch.float16, device=leaf_input.device),
+                         torch.empty((Bp, 256, 10, 9), dtype=torch.float16, device=leaf_input.device, memory_format=torch.channels_last).zero_())
         x64, y = bufs[key]
-        _lib.check(L.ccz_pack_live_planes_rows_f16(s, C.c_void_p(leaf_input.data_ptr()), C.c_void_p(x64.data_ptr()), B,
-                                                   C.c_void_p(rows.data_ptr()), C.c_void_p(n_rows.data_ptr())))
+        pack = L.ccz_pack_live_planes_g16_f16 if g16 else L.ccz_pack_live_planes_rows_f16
+        _lib.check(pack(s, C.c_void_p(leaf_input.data_ptr()), C.c_void_p(x64.data_ptr()), B, C.c_void_p(rows.data_ptr()), C.c_void_p(n_rows.data_ptr())))
         _lib.check(L.ccz_conv3x3_stem_f16_live(s, C.c_void_p(x64.data_ptr()), C.c_void_p(self.stem_w64.data_ptr()), C.c_void_p(self.stem_b32.data_ptr()),
-                                               C.c_void_p(y.data_ptr()), -(-B // 8) * 8 * 90, 1, C.c_void_p(n_rows.data_ptr()), 0, 1))
+                                               C.c_void_p(y.data_ptr()), Bp * 90 if g16 else -(-B // 8) * 8 * 90, 1 | lay, C.c_void_p(n_rows.data_ptr()), 0, 1))
         return y
+
+    @torch.no_grad()
+    def tower_activations(self, leaf_input):
+        """Stem + tower output as a [B, 256, 10, 9] channels-last tensor in BOARD order, whatever row layout the kernels ran in
+        (tests and probes; the evaluator itself feeds the heads in memory order)."""
+        B = leaf_input.shape[0]
+        g16 = self._g16(B)
+        x = self._tower_fused(self._stem_fused(leaf_input, None, g16), None, g16)
+        if not g16:
+            return x
+        Bp, Cn = x.shape[0], x.shape[1]
+        rows = x.permute(0, 2, 3, 1).reshape(Bp // 16, 90, 16, Cn).permute(0, 2, 1, 3).reshape(Bp, 10, 9, Cn)[:B]
+        return rows.permute(0, 3, 1, 2)
 
     @torch.no_grad()
     def forward(self, leaf_input: torch.Tensor, return_logits: bool = False, plan=None):
@@ -330,8 +363,14 @@ class InferenceNet(nn.Module):
             leaf_input = leaf_input.index_select(0, plan[0].long().clamp_(0, B - 1))
             plan = None
         tower_done = False
+        g16 = False   # True: x holds its rows in the group-of-16 layout (and ceil(B / 16) * 16 boards)
         if plan is not None:
-            x = self._tower_fused(self._stem_fused(leaf_input, plan), plan)
+            g16 = self._g16(B)
+            x = self._tower_fused(self._stem_fused(leaf_input, plan, g16), plan, g16)
+            tower_done = True
+        elif fused_ok and self._g16(B):
+            g16 = True
+            x = self._tower_fused(self._stem_fused(leaf_input, None, True), None, True)
             tower_done = True
         elif (hasattr(self, "stem_w64") and leaf_input.is_cuda and leaf_input.dtype == torch.float16 and leaf_input.is_contiguous()
                 and B >= self.FUSED_MIN_BOARDS and self.dtype == torch.float16 and os.environ.get("CCZ_FUSED_CONV", "1") != "0"
@@ -359,8 +398,13 @@ class InferenceNet(nn.Module):
             for i in range(0, len(self.ws), 2):
                 y = self._epilogue(F.conv2d(x, self.ws[i], None, padding=1), self.bs[i])
                 x = self._epilogue(F.conv2d(y, self.ws[i + 1], None, padding=1), self.bs[i + 1], x)
-        rows = x.permute(0, 2, 3, 1).reshape(B * 90, x.shape[1])   # a view of the NHWC activations: one row per pixel
-        h = F.relu_(torch.addmm(self.head_b, rows, self.head_wT)).view(B, 90, PLAYS + PIECES)
+        Bx = x.shape[0]
+        rows = x.permute(0, 2, 3, 1).reshape(Bx * 90, x.shape[1])   # a view of the activations in memory order: one row per pixel
+        h = F.relu_(torch.addmm(self.head_b, rows, self.head_wT))
+        if g16:  # rows (g * 90 + pos) * 16 + j -> board 16 g + j, pixel pos (a copy of B x 90 x 24 values)
+            h = h.view(Bx // 16, 90, 16, PLAYS + PIECES).permute(0, 2, 1, 3).reshape(Bx, 90, PLAYS + PIECES)[:B]
+        else:
+            h = h.view(B, 90, PLAYS + PIECES)
         pol = h[:, :, :PLAYS].reshape(B, 90 * PLAYS)       # (pixel, channel) order: the FC weights' columns are permuted to match
         val = h[:, :, PLAYS:].reshape(B, 90 * PIECES)
         logits = F.linear(pol, self.policy_fc_w, self.policy_fc_b)

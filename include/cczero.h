@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define CCZ_ABI_VERSION 3
+#define CCZ_ABI_VERSION 4
 #define CCZ_NSQ 90
 #define CCZ_SQ_STRIDE 96            /* mailbox row stride in bytes (90 squares + 6 pad)         */
 #define CCZ_NMOVES 2086             /* action space, reference tools.py:172-272                 */
@@ -338,13 +338,23 @@ int ccz_bias_act_f16(void *stream, void *y_dev, const void *bias_dev, const void
 /* A whole tower convolution in one kernel (MFMA implicit GEMM, hand-written for gfx950): 3x3, padding 1,
  * 256 -> 256 channels over boards of 10 x 9, NHWC fp16 in and out, fp32 accumulate:
  *   y[p, co] = act( bias[co] + sum_{ky,kx,ci} w[co, ky, kx, ci] * x[p + 9*(ky-1) + (kx-1), ci] [+ residual[p, co]] )
- * with taps that leave the board contributing zero; relu is a flag word: bit 0 = apply ReLU, bit 1 = process the
- * pixel tiles in descending order (same results; alternating the order from layer to layer reads first what the
- * previous layer wrote last) (reference net.py:20-43,
+ * with taps that leave the board contributing zero; relu is a flag word (CCZ_CONV_*): bit 0 = apply ReLU, bit 1 = process
+ * the pixel tiles in descending order (same results; alternating the order from layer to layer reads first what the
+ * previous layer wrote last), bit 6 = the activations are in the group-of-16 row layout (below) (reference net.py:20-43,
  * ResBlock conv -> BN(folded) -> [+x] -> ReLU; replaces F.conv2d + ccz_bias_act_f16 for these layers).
  * x, y, residual: [n_pixels, 256] fp16 (n_pixels = boards * 90); w: [256, 3, 3, 256] fp16 (the memory of a
  * channels-last [co, ci, 3, 3] tensor); bias: float32 [256]. y may alias residual, not x. At most 93,206 boards
- * per call (32-bit element offsets). */
+ * per call (32-bit element offsets).
+ * Row layouts. Default: NHWC, row = board * 90 + pos (pos = rank * 9 + file). CCZ_CONV_G16: row = (g * 90 + pos) * 16 + j
+ * for board 16 g + j (n_pixels must then be a multiple of 1440 = 16 boards): sixteen consecutive rows are ONE board position
+ * of sixteen boards, which lets the kernel skip the taps that leave the board instead of multiplying zeros, on tiles of two
+ * whole ranks (csrc/cczero_conv_g16.h: the form the evaluator uses for batches above 64 boards). All kernels behind these entry
+ * points add their products in the same order: a board's result is the same in either layout and at any batch size. */
+#define CCZ_CONV_RELU 1
+#define CCZ_CONV_DESCENDING 2
+#define CCZ_CONV_FORCE_SMALL 16 /* A/B runs and tests: k_conv3x3_small whatever the batch size (default layout only) */
+#define CCZ_CONV_FORCE_TILE 32  /* A/B runs and tests: the 256-pixel tile kernel whatever the batch size (default layout only) */
+#define CCZ_CONV_G16 64
 int ccz_conv3x3_c256_f16(void *stream, const void *x_dev, const void *w_dev, const void *bias_f32_dev,
                          const void *residual_dev, void *y_dev, int64_t n_pixels, int32_t relu);
 
@@ -358,14 +368,18 @@ int ccz_conv3x3_stem_f16(void *stream, const void *x64_dev, const void *w_dev, c
  * -> NHWC rows of 64 channels: planes 49..55 (group 7), 105..118 (groups 15, 16), then zeros (net.py:160-173 leaves
  * every other group zero on the search path). */
 int ccz_pack_live_planes_f16(void *stream, const void *leaf_dev, void *x64_dev, int32_t n_boards);
+/* The same into the CCZ_CONV_G16 row layout; x64 must hold ceil(n_boards / 16) * 1440 rows (the rows of the boards that pad the
+ * last group are left alone). rows_dev / n_rows_dev as for ccz_pack_live_planes_rows_f16 below, or both NULL. */
+int ccz_pack_live_planes_g16_f16(void *stream, const void *leaf_dev, void *x64_dev, int32_t n_boards,
+                                 const int32_t *rows_dev, const int32_t *n_rows_dev);
 
 /* The same three for the planned evaluator boundary (ccz_eval_plan): the number of rows to compute is a DEVICE value, so that
  * no host sync stands between the plan and the evaluator. ccz_pack_live_planes_rows_f16: output row i = board rows_dev[i] for
  * i < *n_rows_dev (the rest is left alone). The *_live convolutions take the pointers of the WHOLE batch: the first *live_rows_dev
- * boards are live and are cut into n_parts equal ranges (multiples of 8 boards) of which this launch computes range `part` -- so
- * that concurrent launch chains stay balanced whatever the live count is; n_pixels = the largest range a launch may get
- * (ceil(boards / n_parts) rounded up to 8 boards, x 90): the grid is sized for it, tiles past the live rows exit at once, the
- * last live tile may be partial. */
+ * boards are live and are cut into n_parts equal ranges (multiples of 8 boards; of 16 with CCZ_CONV_G16) of which this launch
+ * computes range `part` -- so that concurrent launch chains stay balanced whatever the live count is; n_pixels = the largest
+ * range a launch may get (ceil(boards / n_parts) rounded up to 8 (16) boards, x 90): the grid is sized for it, tiles past the
+ * live rows exit at once, the last live tile may be partial. */
 int ccz_pack_live_planes_rows_f16(void *stream, const void *leaf_dev, void *x64_dev, int32_t n_boards,
                                   const int32_t *rows_dev, const int32_t *n_rows_dev);
 int ccz_conv3x3_c256_f16_live(void *stream, const void *x_dev, const void *w_dev, const void *bias_f32_dev,

@@ -34,12 +34,15 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--res", type=int, default=1)
+    ap.add_argument("--relu-input", type=int, default=0, help="1: the input is post-ReLU (half zeros), as inside the tower")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(1)
     cl = torch.channels_last
     B = a.boards
     x = (torch.randn(B, 256, 10, 9, generator=g) * 0.5).to(dev).half().contiguous(memory_format=cl)
+    if a.relu_input:
+        x = torch.relu(x)
     res = (torch.randn(B, 256, 10, 9, generator=g) * 0.5).to(dev).half().contiguous(memory_format=cl)
     w = (torch.randn(256, 256, 3, 3, generator=g) * 0.03).to(dev).half().contiguous(memory_format=cl)
     bias = (torch.randn(256, generator=g) * 0.1).to(dev)
@@ -54,12 +57,30 @@ def main():
     ys = [torch.empty_like(x) for _ in libs]
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+    # flags bit 6: the library's group-of-16 layout (row = (g * 90 + pos) * 16 + j for board 16 g + j); the kernel gets permuted
+    # copies of the same tensors and its output is permuted back before any comparison
+    def to_g16(t):
+        return t.permute(0, 2, 3, 1).reshape(B // 16, 16, 90, 256).permute(0, 2, 1, 3).contiguous()
+
+    def from_g16(t):
+        return t.view(B // 16, 90, 16, 256).permute(0, 2, 1, 3).reshape(B, 10, 9, 256).permute(0, 3, 1, 2)
+
+    g16 = any(fl & 64 for _, _, fl in libs)
+    if g16:
+        xg, rg = to_g16(x), to_g16(res)
+        yg = torch.empty_like(xg)
+
     def run(L, y, fl=1):
-        rc = L.ccz_conv3x3_c256_f16(s, x.data_ptr(), w.data_ptr(), bias.data_ptr(), res.data_ptr() if a.res else None, y.data_ptr(), B * 90, fl)
+        if fl & 64:
+            rc = L.ccz_conv3x3_c256_f16(s, xg.data_ptr(), w.data_ptr(), bias.data_ptr(), rg.data_ptr() if a.res else None, yg.data_ptr(), B * 90, fl)
+        else:
+            rc = L.ccz_conv3x3_c256_f16(s, x.data_ptr(), w.data_ptr(), bias.data_ptr(), res.data_ptr() if a.res else None, y.data_ptr(), B * 90, fl)
         assert rc == 0
 
     for (n, L, fl), y in zip(libs, ys):
         run(L, y, fl)
+        if fl & 64:
+            y.copy_(from_g16(yg))
     torch.cuda.synchronize()
     sample = sorted({0, min(1, B - 1), B // 2, B - 1})
     ref = F.conv2d(x[sample].float(), w.float(), bias, padding=1)

@@ -165,16 +165,16 @@ def test_fused_tower_board_ranges_on_several_streams_equal_one_chain():
     torch.manual_seed(6)
     net = Net(256, 2).to(dev).eval()
     inf = InferenceNet(net).to(dev).eval()
-    B = 600
-    x0 = torch.relu(torch.randn(B, 256, 10, 9, device=dev)).half().contiguous(memory_format=torch.channels_last)
-    outs = []
-    for chains in (1, 8, 3):
-        inf.TOWER_CHAINS = chains
-        inf._chain_streams = None
-        outs.append(inf._tower_fused(x0.clone(memory_format=torch.preserve_format)).clone())
-        torch.cuda.synchronize()
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
-    assert torch.isfinite(outs[0].float()).all() and outs[0].abs().max().item() > 0
+    for B in (600, 608):   # 600 boards: board-major rows, 256-pixel tiles; 608 = 38 groups of 16: the group-of-16 layout
+        x0 = torch.relu(torch.randn(B, 256, 10, 9, device=dev)).half().contiguous(memory_format=torch.channels_last)
+        outs = []
+        for chains in (1, 8, 3):
+            inf.TOWER_CHAINS = chains
+            inf._chain_streams = None
+            outs.append(inf._tower_fused(x0.clone(memory_format=torch.preserve_format)).clone())
+            torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        assert torch.isfinite(outs[0].float()).all() and outs[0].abs().max().item() > 0
 
 
 def test_conv_kernel_full_size_board_permutation_and_sample():
@@ -241,7 +241,7 @@ def test_fused_evaluator_inside_hipgraph_capture_equals_eager():
     leaf = (torch.rand(B, 17, 7, 10, 9, device=dev) > 0.9).half()
 
     def body(x):
-        t = inf._tower_fused(inf._stem_fused(x))
+        t = inf.tower_activations(x)
         p, v = inf(x)
         return t, p, v
     with torch.no_grad():
@@ -261,3 +261,99 @@ def test_fused_evaluator_inside_hipgraph_capture_equals_eager():
         torch.cuda.synchronize()
     assert torch.equal(t_graph, t_eager)
     assert torch.allclose(p_graph, p_eager, atol=2e-3) and torch.allclose(v_graph, v_eager, atol=2e-2)
+
+
+def _to_g16(t):
+    """[B, C, 10, 9] channels-last (rows b * 90 + pos) -> the same bytes reordered to rows (g * 90 + pos) * 16 + j, board 16 g + j"""
+    B, Cn = t.shape[0], t.shape[1]
+    return t.permute(0, 2, 3, 1).reshape(B // 16, 16, 90, Cn).permute(0, 2, 1, 3).contiguous()
+
+
+def _from_g16(t, B):
+    Cn = t.shape[-1]
+    return t.reshape(B // 16, 90, 16, Cn).permute(0, 2, 1, 3).reshape(B, 10, 9, Cn).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("boards", [16, 80, 272])
+def test_group_of_16_kernel_gives_the_tile_kernels_values(boards):
+    """k_conv3x3_g16 (rows in the CCZ_CONV_G16 layout: tiles of two whole ranks of 16 boards, the taps that leave the board
+    skipped instead of multiplied by zero rows) adds the same products in the same order as the 256-pixel tile kernel and
+    k_conv3x3_small: equal values (a skipped product of zeros can only change the sign of a zero), tower and stem shape, with and
+    without residual / ReLU, either tile order, output over the residual; and float32 as the common reference."""
+    from chinesechesszero_amd import _lib
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(500 + boards)
+    cl = torch.channels_last
+    L = _lib.lib()
+    s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    x = torch.relu(torch.randn(boards, 256, 10, 9, generator=g) * 0.7).to(dev).half().contiguous(memory_format=cl)
+    r = (torch.randn(boards, 256, 10, 9, generator=g) * 0.7).to(dev).half().contiguous(memory_format=cl)
+    w = (torch.randn(256, 256, 3, 3, generator=g) * 0.03).to(dev).half().contiguous(memory_format=cl)
+    b = (torch.randn(256, generator=g) * 0.2).to(dev)
+    xg, rg = _to_g16(x), _to_g16(r)
+    ref = F.conv2d(x.float(), w.float(), b, padding=1)
+    for res, relu in ((None, 1), (r, 1), (None, 0), (r, 3)):
+        y_tile = _conv(x, w, b, res, torch.full_like(x, float("nan")), (relu & 1) | _lib.CONV_FORCE_TILE)
+        yg = torch.full_like(xg, float("nan"))
+        _lib.check(L.ccz_conv3x3_c256_f16(s, C.c_void_p(xg.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()),
+                                          C.c_void_p(rg.data_ptr()) if res is not None else None, C.c_void_p(yg.data_ptr()), boards * 90,
+                                          relu | _lib.CONV_G16))
+        got = _from_g16(yg, boards)
+        assert torch.equal(got, y_tile), (boards, res is not None, relu, (got.float() - y_tile.float()).abs().max().item())
+        want = ref if res is None else ref + r.float()
+        if relu & 1:
+            want = F.relu(want)
+        assert (got.float() - want).abs().max().item() < 4e-3 * max(1.0, want.abs().max().item())
+    # output written over the residual (how the tower uses it)
+    yg = rg.clone()
+    _lib.check(L.ccz_conv3x3_c256_f16(s, C.c_void_p(xg.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(yg.data_ptr()),
+                                      C.c_void_p(yg.data_ptr()), boards * 90, 1 | _lib.CONV_G16))
+    assert torch.equal(_from_g16(yg, boards), _conv(x, w, b, r, torch.empty_like(x), 1 | _lib.CONV_FORCE_TILE))
+    # stem shape (64 input channels = two chunks of 32) through the layout-aware pack
+    leaf = (torch.rand(boards, 17, 7, 10, 9, generator=g) > 0.85).to(dev).half()
+    w64 = torch.zeros(256, 3, 3, 64, dtype=torch.float16, device=dev)
+    w64[..., :21] = (torch.randn(256, 3, 3, 21, generator=g) * 0.1).to(dev).half()
+    x64, x64g = torch.empty(boards * 90, 64, dtype=torch.float16, device=dev), torch.full((boards * 90, 64), float("nan"), dtype=torch.float16, device=dev)
+    _lib.check(L.ccz_pack_live_planes_f16(s, C.c_void_p(leaf.data_ptr()), C.c_void_p(x64.data_ptr()), boards))
+    _lib.check(L.ccz_pack_live_planes_g16_f16(s, C.c_void_p(leaf.data_ptr()), C.c_void_p(x64g.data_ptr()), boards, None, None))
+    assert torch.equal(x64g.view(boards // 16, 90, 16, 64).permute(0, 2, 1, 3).reshape(boards * 90, 64), x64)
+    ys = torch.empty(boards * 90, 256, dtype=torch.float16, device=dev)
+    ysg = torch.empty_like(ys)
+    _lib.check(L.ccz_conv3x3_stem_f16(s, C.c_void_p(x64.data_ptr()), C.c_void_p(w64.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(ys.data_ptr()),
+                                      boards * 90, 1 | _lib.CONV_FORCE_TILE))
+    _lib.check(L.ccz_conv3x3_stem_f16(s, C.c_void_p(x64g.data_ptr()), C.c_void_p(w64.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(ysg.data_ptr()),
+                                      boards * 90, 1 | _lib.CONV_G16))
+    assert torch.equal(ysg.view(boards // 16, 90, 16, 256).permute(0, 2, 1, 3).reshape(boards * 90, 256), ys)
+    # not a multiple of 16 boards: refused
+    assert L.ccz_conv3x3_c256_f16(s, C.c_void_p(xg.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), None, C.c_void_p(yg.data_ptr()),
+                                  (boards - 1) * 90, 1 | _lib.CONV_G16) != 0
+
+
+@pytest.mark.parametrize("live,n_parts", [(0, 1), (1, 1), (16, 2), (17, 1), (100, 3), (160, 4)])
+def test_group_of_16_kernel_live_rows(live, n_parts):
+    """The planned boundary in the group-of-16 layout: the first `live` boards (a device value) are cut into n_parts equal ranges
+    of whole groups; the parts together compute exactly the groups that hold live boards, nothing else is written."""
+    from chinesechesszero_amd import _lib
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(900 + live)
+    cl = torch.channels_last
+    L = _lib.lib()
+    s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    boards = 160
+    x = torch.relu(torch.randn(boards, 256, 10, 9, generator=g) * 0.7).to(dev).half().contiguous(memory_format=cl)
+    r = (torch.randn(boards, 256, 10, 9, generator=g) * 0.7).to(dev).half().contiguous(memory_format=cl)
+    w = (torch.randn(256, 256, 3, 3, generator=g) * 0.03).to(dev).half().contiguous(memory_format=cl)
+    b = (torch.randn(256, generator=g) * 0.2).to(dev)
+    xg, rg = _to_g16(x), _to_g16(r)
+    full = torch.empty_like(xg)
+    _lib.check(L.ccz_conv3x3_c256_f16(s, C.c_void_p(xg.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(rg.data_ptr()),
+                                      C.c_void_p(full.data_ptr()), boards * 90, 1 | _lib.CONV_G16))
+    n_live = torch.tensor([live], dtype=torch.int32, device=dev)
+    yg = torch.full_like(xg, float("nan"))
+    cap = -(-(boards // 16) // n_parts) * 1440
+    for part in range(n_parts):
+        _lib.check(L.ccz_conv3x3_c256_f16_live(s, C.c_void_p(xg.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(rg.data_ptr()),
+                                               C.c_void_p(yg.data_ptr()), cap, 1 | _lib.CONV_G16 | (2 if part & 1 else 0), C.c_void_p(n_live.data_ptr()), part, n_parts))
+    groups = -(-live // 16)
+    assert torch.equal(yg[:groups], full[:groups])
+    assert torch.isnan(yg[groups:].float()).all()

@@ -138,7 +138,7 @@ def test_tower_activations_do_not_depend_on_the_batch_size():
     for B in (1, 24, 90, 300):
         xb = x[:B].clone()
         xb[B // 2] = probe[0]
-        t = inf._tower_fused(inf._stem_fused(xb))
+        t = inf.tower_activations(xb)
         outs.append(t[B // 2].clone())
         lg, v = inf(xb, return_logits=True)
         if B == 1:
