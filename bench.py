@@ -590,11 +590,16 @@ def tower_roofline(a, pvn, e, state, B, ev):
     torch.cuda.synchronize()
     t_conv = c0.elapsed_time(c1) * 1e-3 / (len(xs) * 2 * a.blocks)
     conv_flops = 2.0 * B * 90 * 256 * 256 * 9
-    nr = {"bound": "mfma", "kernel": "k_conv3x3_c256 (tower conv3x3 256->256 + bias + residual + ReLU, fp16 in / fp32 acc)",
+    g16 = inf._g16(B) and B % 16 == 0
+    nr = {"bound": "mfma", "kernel": ("k_conv3x3_g16" if g16 else "k_conv3x3_c256") + " (tower conv3x3 256->256 + bias + residual + ReLU, fp16 in / fp32 acc)",
+          "row_layout": "group-of-16 (whole-rank tiles, off-board taps skipped)" if g16 else "nhwc (256-pixel tiles)",
           "achieved": conv_flops / t_conv / 1e12, "peak": MFMA_PEAK_F16 / 1e12, "unit": "TFLOP/s",
           "frac": conv_flops / t_conv / MFMA_PEAK_F16, "traffic": None, "avg_launch_us": t_conv * 1e6,
           "algorithmic_flops_per_launch": conv_flops, "launches_per_step": 2 * a.blocks,
-          "groups": int(os.environ.get("CCZ_TOWER_GROUPS", "0")) or -(-B // inf.TOWER_GROUP_BOARDS),
+          # the algorithmic count is the convention for a padded 3x3 convolution (9 taps for every pixel); the group-of-16 kernel
+          # does not issue the MFMAs of taps with dx off the board (150 of 162 per pair of ranks)
+          "mfma_flops_issued_per_launch": conv_flops * (150.0 / 162.0 if g16 else 1.0),
+          "groups": int(os.environ.get("CCZ_TOWER_GROUPS", "0")) or -(-B // (inf.TOWER_GROUP_BOARDS_G16 if g16 else inf.TOWER_GROUP_BOARDS)),
           "note": "a 'launch' is one layer over the whole batch, issued as groups x chains kernel launches over board ranges "
                   "(groups one after the other, the chains of a group concurrently)"}
     per_group = -(-B // nr["groups"])

@@ -171,6 +171,7 @@ class InferenceNet(nn.Module):
     def _g16(self, B) -> bool:
         return B >= self.G16_MIN_BOARDS and os.environ.get("CCZ_CONV_LAYOUT", "g16") != "nhwc" and not self._force_flag()
 
+    TOWER_GROUP_BOARDS_G16 = 4096
     TOWER_GROUP_BOARDS = 2048  # boards per sequential group (working set of a group fits the Infinity Cache); env CCZ_TOWER_GROUPS
     TOWER_CHAINS = 2  # independent board ranges run as concurrent launch chains (one HIP stream each); env CCZ_TOWER_CHAINS (<= 8)
 
@@ -195,7 +196,9 @@ class InferenceNet(nn.Module):
         # group (2 x 94 MB at 2048 boards) then stay inside the 256 MB Infinity Cache from layer to layer
         # (4096 boards: 1 group 27.55 ms/step, 2 groups 27.19, 3: 28.0, 4: 28.4)
         Bt = x.shape[0]
-        groups = int(os.environ.get("CCZ_TOWER_GROUPS", "0")) or -(-Bt // self.TOWER_GROUP_BOARDS)
+        # (group-of-16 layout, round 3, 4096 boards with the evaluation cache: 1 group x 2 chains 23.54 ms/step, 2 x 2 23.80,
+        # 1 x 1 24.89, 1 x 4 24.42: the cache-residency gain of two groups is gone, the tail-filling of two chains is not)
+        groups = int(os.environ.get("CCZ_TOWER_GROUPS", "0")) or -(-Bt // (self.TOWER_GROUP_BOARDS_G16 if g16 else self.TOWER_GROUP_BOARDS))
         if torch.cuda.is_current_stream_capturing():
             groups = 1
         if plan is not None:
