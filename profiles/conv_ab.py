@@ -57,7 +57,7 @@ def main():
     ys = [torch.empty_like(x) for _ in libs]
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    # flags bit 6: the library's group-of-16 layout (row = (g * 90 + pos) * 16 + j for board 16 g + j); the kernel gets permuted
+    # flags bit 6 (bit 7 in -DCCZ_CONV4 builds): the library's group-of-16 layout (row = (g * 90 + pos) * 16 + j for board 16 g + j); the kernel gets permuted
     # copies of the same tensors and its output is permuted back before any comparison
     def to_g16(t):
         return t.permute(0, 2, 3, 1).reshape(B // 16, 16, 90, 256).permute(0, 2, 1, 3).contiguous()
@@ -65,13 +65,14 @@ def main():
     def from_g16(t):
         return t.view(B // 16, 90, 16, 256).permute(0, 2, 1, 3).reshape(B, 10, 9, 256).permute(0, 3, 1, 2)
 
-    g16 = any(fl & 64 for _, _, fl in libs)
+    G16 = 64 | 128   # bit 6: the shipped group-of-16 kernel; bit 7: the v4 experiment (same layout)
+    g16 = any(fl & G16 for _, _, fl in libs)
     if g16:
         xg, rg = to_g16(x), to_g16(res)
         yg = torch.empty_like(xg)
 
     def run(L, y, fl=1):
-        if fl & 64:
+        if fl & G16:
             rc = L.ccz_conv3x3_c256_f16(s, xg.data_ptr(), w.data_ptr(), bias.data_ptr(), rg.data_ptr() if a.res else None, yg.data_ptr(), B * 90, fl)
         else:
             rc = L.ccz_conv3x3_c256_f16(s, x.data_ptr(), w.data_ptr(), bias.data_ptr(), res.data_ptr() if a.res else None, y.data_ptr(), B * 90, fl)
@@ -79,7 +80,7 @@ def main():
 
     for (n, L, fl), y in zip(libs, ys):
         run(L, y, fl)
-        if fl & 64:
+        if fl & G16:
             y.copy_(from_g16(yg))
     torch.cuda.synchronize()
     sample = sorted({0, min(1, B - 1), B // 2, B - 1})
