@@ -187,8 +187,19 @@ __global__ __launch_bounds__(512) void k_conv3x3_g16(const _Float16 *__restrict_
         Y += off;
         if (RES) R += off;
     }
+    // XCD-aware order: workgroup b runs on XCD b % 8 (round-robin dispatch), and the five tiles of a group read each other's
+    // ranks as halo -- so XCD x takes the x-th CONTIGUOUS eighth of the tiles, in order: a halo rank is then in that XCD's L2
+    // (with tile = b: 398 MB fetched per half-batch launch against 283 MB algorithmic, profiles/pmc_summary.json)
+    int tile;
+    {
+        const int b = blockIdx.x, x = b & 7, per = tiles >> 3, rem = tiles & 7;
+        tile = x * per + (x < rem ? x : rem) + (b >> 3);
+#ifdef G5_NO_XCD_MAP
+        tile = b;
+#endif
+    }
     // flags bit 1: tiles in descending order (the tiles written last by the previous layer are then read first)
-    const int tile = __builtin_amdgcn_readfirstlane((relu & 2) ? tiles - 1 - blockIdx.x : blockIdx.x);
+    tile = __builtin_amdgcn_readfirstlane((relu & 2) ? tiles - 1 - tile : tile);
     const int k = tile % 5;                  // ranks 2k, 2k + 1 of the tile's group
     const long p0 = (long)tile * kG5Rows;    // = (group * 90 + 18 k) * 16
     relu &= 1;
