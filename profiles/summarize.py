@@ -51,6 +51,11 @@ def main():
         except Exception:
             return None
 
+    # both window passes in THIS run: they are compared with each other, not with what an earlier run left in the merged summary
+    both_here = all(find(os.path.join(out_dir, k), "*counter_collection.csv") for k in ("pmc_fetch", "pmc_write"))
+    if both_here:
+        for key in ("k_bar", "d_bar", "warning"):
+            summary.get("k_step", {}).get("window", {}).pop(key, None)
     for kind, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("pmc_cfetch", "FETCH_SIZE"), ("pmc_cwrite", "WRITE_SIZE")):
         cc = find(os.path.join(out_dir, kind), "*counter_collection.csv")
         if not cc:
