@@ -116,13 +116,15 @@ def test_slot_collisions_and_a_tiny_table_change_nothing():
     assert s1["cache_stores"] > 1024          # the table was overwritten many times over
 
 
-def test_real_net_planned_rows_and_cleared_on_new_weights():
+@pytest.mark.parametrize("B", [320, 200])
+def test_real_net_planned_rows_and_cleared_on_new_weights(B):
     """The fused evaluator (k_pack_live_planes gather, stem and tower with device-side live-row counts, heads) on the planned
-    rows: the same search as without a cache; a weight change empties the table."""
+    rows: the same search as without a cache; a weight change empties the table. 320 boards = 20 whole groups of the tower's
+    group-of-16 row layout; 200 boards are padded to 13 groups."""
     from chinesechesszero_amd.net import PolicyValueNet
     from chinesechesszero_amd.selfplay import BatchedSelfPlay
     dev = torch.device("cuda", 0)
-    B, n = 320, 24
+    n = 24
     res = []
     for log2 in (0, 15):
         torch.manual_seed(2)
