@@ -180,3 +180,31 @@ def test_a_boards_evaluation_does_not_depend_on_its_slot_in_the_batch():
     keep[slots] = False
     keep &= keep.flip(0)
     assert torch.equal(lb[keep], la.flip(0)[keep]) and torch.equal(vb[keep], va.flip(0)[keep])
+
+
+def test_both_row_layouts_give_the_same_evaluation(monkeypatch):
+    """The evaluator at full depth (40 x 256) and 4096 rows in the group-of-16 row layout (k_conv3x3_g16: whole-rank tiles, taps off
+    the board skipped) and in board-major rows (k_conv3x3_c256, `CCZ_CONV_LAYOUT=nhwc`): the same logits and values, bit for bit --
+    the kernels add the same products in the same order, and a skipped product of zeros cannot change a sum. Also on the planned
+    (compacted) boundary, and -- tower activations, the heads' GEMMs see another row count there -- with a batch that the
+    group-of-16 layout pads to whole groups (3990 boards)."""
+    from chinesechesszero_amd.net import PolicyValueNet
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(9)
+    pvn = PolicyValueNet(device=dev)
+    pvn.refresh_inference_copy()
+    x = _leaf_batch(4096, 24, seed=21)
+    rows = torch.randperm(4096, device=dev)[:3000].to(torch.int32).contiguous()
+    n_rows = torch.tensor([3000], dtype=torch.int32, device=dev)
+    out = {}
+    for layout in ("g16", "nhwc"):
+        monkeypatch.setenv("CCZ_CONV_LAYOUT", layout)
+        full = pvn.evaluate_leaves_logits(x)
+        part = pvn._infer.tower_activations(x[:3990].contiguous())
+        plan = pvn.evaluate_leaves_logits(x, plan=(rows, n_rows))
+        out[layout] = [t.clone() for t in (*full, part, plan[0][:3000], plan[1][:3000])]
+    for a, b in zip(out["g16"], out["nhwc"]):
+        assert torch.equal(a, b)
+    # the planned rows are the rows of the full batch
+    assert torch.equal(out["g16"][3], out["g16"][0][rows.long()]) and torch.equal(out["g16"][4], out["g16"][1][rows.long()])
+    assert out["g16"][2].shape == (3990, 256, 10, 9)
