@@ -152,7 +152,7 @@ class InferenceNet(nn.Module):
         return F.relu_(y)
 
     FUSED_MIN_BOARDS = 1  # every batch runs on the hand-written convolution: up to 64 boards on k_conv3x3_small (16-channel x
-    # 64-pixel blocks spread over the chip), above that on the 256-pixel tiles of k_conv3x3_c256 -- bit-identical results, so a
+    # 64-pixel blocks spread over the chip), above that on k_conv3x3_g16 (group-of-16 rows, whole-rank tiles) -- the same values, so a
     # board's tower activations do not depend on the batch size. (Round 2 sent batches under 192 boards to MIOpen + an epilogue
     # pass: 12.1 us per tower layer at one board, profiles/r03_single_board.json.)
 
@@ -181,11 +181,12 @@ class InferenceNet(nn.Module):
         are live; every launch skips the tiles past them (``ccz_conv3x3_c256_f16_live``).
 
         Boards are independent, so the batch is cut into ``TOWER_CHAINS`` contiguous board ranges whose 80-launch
-        chains run on separate HIP streams: the tile tail of one chain's layer (1440 tiles on 256 CUs = 5.6 rounds,
-        paid as 6 when every layer waits for the previous one) is filled by the other chain's tiles. In the bench
-        (4096 boards, 80 different weight sets): 1 chain 29.2 ms/step, 2 chains 27.9, 3: 28.0, 4: 28.5, 8: 28.6
-        (same-weights microbench profiles/conv_streams.py: 352 -> 319 -> 311 us per layer for 1 / 2 / 8 chains).
-        Inside a stream capture (hipGraph) one chain is used."""
+        chains run on separate HIP streams: the tile tail of one chain's layer is filled by the other chain's tiles. In the bench
+        (4096 boards, 80 different weight sets; round 2, board-major rows): 1 chain 29.2 ms/step, 2 chains 27.9, 3: 28.0, 4: 28.5,
+        8: 28.6 (same-weights microbench profiles/conv_streams.py: 352 -> 319 -> 311 us per layer for 1 / 2 / 8 chains); round 3,
+        group-of-16 rows with the evaluation cache: 1 chain 24.9, 2 chains 23.5, 3: 23.3-24.0, 4: 24.4 (profiles/r03_conv_g16.json).
+        Inside a stream capture (hipGraph) one chain is used. ``g16``: the rows of ``x`` are in the group-of-16 order
+        (``None``: as :meth:`_stem_fused` lays out a batch of this size)."""
         import ctypes as C
         from . import _lib
         L = _lib.lib()
@@ -397,7 +398,7 @@ class InferenceNet(nn.Module):
                     seen.add(key)
                     from .tools import log
                     log(f"evaluator: batch of {key[0]} boards x {key[1]} channels is off the fused tower kernels "
-                        f"(k_conv3x3_c256 / k_conv3x3_small serve 256-channel towers): MIOpen convolutions + one-pass epilogue")
+                        f"(k_conv3x3_g16 / k_conv3x3_small serve 256-channel towers): MIOpen convolutions + one-pass epilogue")
             for i in range(0, len(self.ws), 2):
                 y = self._epilogue(F.conv2d(x, self.ws[i], None, padding=1), self.bs[i])
                 x = self._epilogue(F.conv2d(y, self.ws[i + 1], None, padding=1), self.bs[i + 1], x)
