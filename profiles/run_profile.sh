@@ -44,6 +44,7 @@ for P in $PASSES; do
     cfetch) pmc cfetch FETCH_SIZE "$CV" $SHORT ;;
     cwrite) pmc cwrite WRITE_SIZE "$CV" $SHORT ;;
     csq) pmc csq "$SQ" "$CV" $SHORT ;;
+    cmfma) pmc cmfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "$CV" $SHORT ;;
     *) echo "unknown pass $P" >> "$LOG"; exit 2 ;;
   esac
   echo "$P pass done $(date +%T)" >> "$LOG"

@@ -110,6 +110,24 @@ def main():
                   sq["wait_inst_any_frac"] = sq.get("SQ_WAIT_INST_ANY", 0.0) / wc
                   sq["active_inst_any_frac"] = sq.get("SQ_ACTIVE_INST_ANY", 0.0) / wc
               summary.setdefault(k, {})["sq_per_launch"] = sq
+    # matrix-pipe and LDS counters of the tower convolution (own pass: the SQ block has 8 counter slots)
+    cc = find(os.path.join(out_dir, "pmc_cmfma"), "*counter_collection.csv")
+    if cc:
+        acc = defaultdict(lambda: [0.0, 0])
+        for r in csv.DictReader(open(cc)):
+            if "k_conv3x3" in r.get("Kernel_Name", ""):
+                a = acc[r.get("Counter_Name")]
+                a[0] += float(r.get("Counter_Value", 0) or 0)
+                a[1] += 1
+        m = {c: v[0] / v[1] for c, v in acc.items() if v[1]}
+        if m.get("SQ_WAVE_CYCLES"):
+            # SQ_VALU_MFMA_BUSY_CYCLES counts cycles (16 per v_mfma_f32_16x16x32_f16), SQ_WAVE_CYCLES quad-cycles summed over the
+            # waves (MI355X_MICROARCH.md, price list); the kernel keeps two waves on every SIMD: the share of a SIMD's resident
+            # time in which its matrix pipe works
+            m["mfma_pipe_use_while_resident"] = m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4.0 * m["SQ_WAVE_CYCLES"] / 2.0)
+        if m.get("SQ_LDS_IDX_ACTIVE"):
+            m["lds_bank_conflict_over_active"] = m.get("SQ_LDS_BANK_CONFLICT", 0.0) / m["SQ_LDS_IDX_ACTIVE"]
+        summary.setdefault("k_conv3x3", {})["mfma_lds_per_launch"] = m
     for k, d in summary.items():
         f = d.get("FETCH_SIZE_raw_per_launch")
         w = d.get("WRITE_SIZE_raw_per_launch")
