@@ -100,6 +100,7 @@ __device__ __forceinline__ void g5_step(const G5Ctx &c, cv_f32x4 (&acc)[4][9], i
 
     // the order below is pinned (one scheduling region per cell): a fragment register is refilled right AFTER the MFMAs that read
     // it -- left to the scheduler the refills move up and every fragment needs a second register
+#ifdef G5_BFRAG_PER_TAP /* A/B: round 3's first form -- nine fragment reads per tap, each register refilled after its MFMAs */
 #define G5_CELL(N)                                                                                                        \
     {                                                                                                                     \
         if constexpr (g5_on_board<T, N>()) {                                                                              \
@@ -110,6 +111,23 @@ __device__ __forceinline__ void g5_step(const G5Ctx &c, cv_f32x4 (&acc)[4][9], i
             b[N] = *(const cv_half8 *)(lds + c.vb[BUFn] + (9 + N + deltan) * 1024);                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                                \
     }
+#else
+    // The three taps of one dy read the SAME nine cells of slab rank (rank + dy): cell N needs cell N + dx. So b[] holds the nine
+    // fragments of that rank for three half-steps (cell N multiplies b[N + dx]; N + dx = -1 and 9 are exactly the skipped,
+    // off-board pairs) and is refilled once per dy, during the dx = +1 tap: b[N] is dead as soon as cell N - 1 has issued its
+    // MFMAs there, so it is reloaded for the next dy right in front of cell N's MFMAs -- 27 fragment reads per chunk instead of 78.
+#define G5_CELL(N)                                                                                                        \
+    {                                                                                                                     \
+        if constexpr (T % 3 == 2)                                                                                         \
+            b[N] = *(const cv_half8 *)(lds + c.vb[BUFn] + (9 + N + 9 * (Tn / 3 - 1)) * 1024);                             \
+        if constexpr (g5_on_board<T, N>()) {                                                                              \
+            constexpr int NB = N + T % 3 - 1;                                                                             \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
+                acc[i][N] = __builtin_amdgcn_mfma_f32_16x16x32_f16(acur[i], b[NB], acc[i][N], 0, 0, 0);                   \
+        }                                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                                \
+    }
+#endif
 #define G5_CELLS(LO, HI)                                                                                                  \
     if constexpr (LO <= 0 && 0 < HI) G5_CELL(0) if constexpr (LO <= 1 && 1 < HI) G5_CELL(1) if constexpr (LO <= 2 && 2 < HI) G5_CELL(2) \
     if constexpr (LO <= 3 && 3 < HI) G5_CELL(3) if constexpr (LO <= 4 && 4 < HI) G5_CELL(4) if constexpr (LO <= 5 && 5 < HI) G5_CELL(5) \
@@ -275,9 +293,14 @@ __global__ __launch_bounds__(512) void k_conv3x3_g16(const _Float16 *__restrict_
     cv_half8 a0[4], a1[4], b[9];
 #pragma unroll
     for (int i = 0; i < 4; ++i) a0[i] = *(const cv_half8 *)(lds + c.a_off + i * 1024);
+#ifdef G5_BFRAG_PER_TAP
 #pragma unroll
     for (int n = 1; n < 9; ++n) b[n] = *(const cv_half8 *)(lds + c.vb[0] + (9 + n - 10) * 1024); // tap 0: delta = -10, cell 0 is off the board
     b[0] = b[1];
+#else
+#pragma unroll
+    for (int n = 0; n < 9; ++n) b[n] = *(const cv_half8 *)(lds + c.vb[0] + (9 + n - 9) * 1024); // the rank above this wave's: dy = -1
+#endif
     for (int chunk = 0; chunk <= c.cmask; chunk += 2) {
 #define G5_S(j) g5_step<j>(c, acc, chunk + (j) / 9, ring_rd, ring_wr, a0, a1, b)
         G5_S(0); G5_S(1); G5_S(2); G5_S(3); G5_S(4); G5_S(5); G5_S(6); G5_S(7); G5_S(8);
