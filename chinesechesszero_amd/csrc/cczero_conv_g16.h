@@ -22,13 +22,19 @@
 //     half-steps per tower layer, one weight half-tile (256 output channels x 32 k, 16 KB) per half-step through a ring of
 //     five (three ahead, one barrier per half-step, LDS-DMA with counted vmcnt, as in k_conv3x3_c256). The slab of a chunk
 //     = the tile's 2 ranks + one rank either side = 36 cells = 576 rows of 64 B, double-buffered; ring + slabs = 152 KB.
-//   * pixel fragments are refilled in place: the nine fragments of the NEXT tap are requested one by one, each right after
-//     the MFMAs that consumed its register -- a whole half-step ahead of their use, no second register set. The order is
-//     pinned (one scheduling region per cell): left to the scheduler the refills move up and the kernel spills.
+//   * pixel fragments: the three taps of one dy read the SAME nine cells of slab rank (rank + dy) -- cell N needs cell N + dx, and
+//     N + dx = -1 / 9 are exactly the skipped pairs -- so the nine fragments of a rank stay in registers for three half-steps and
+//     are refilled once per dy, IN PLACE, during the dx = +1 tap (b[N] is dead as soon as cell N - 1 has issued its MFMAs there):
+//     27 fragment reads per chunk and wave instead of 78, one register set. The order is pinned (one scheduling region per
+//     cell): left to the scheduler the refills move up and the kernel spills.
+//   * XCD-aware tile order: workgroup b runs on XCD b % 8 and the five tiles of a group read each other's ranks as halo, so XCD x
+//     takes the x-th contiguous eighth of the tiles (HBM traffic per launch 398 MB -> 283-288 MB = algorithmic).
 //
-// Measured (profiles/r03_conv_g16.json, 4096 boards, one layer in isolation, interleaved with k_conv3x3_c256 on one device):
-// 338-348 us against 355-363 us. The loop is power-limited like its predecessor's: the gain is about the
-// energy of the MFMAs no longer issued; 3 / 5 / 7 cells in front of the barrier and the weight DMA behind it are all within noise.
+// Measured (profiles/r03_conv_g16.json; 4096 boards, one layer in isolation, interleaved on one device): 310-316 us against
+// 355-363 us for k_conv3x3_c256; in the workload 301 us per layer (58 % of the dense fp16 peak), 22.14 against 23.69 ms per step
+// on one box. The loop is power-limited like its predecessor's (DESIGN.md sections 2 and 10): 3 / 5 / 7 cells in front of the
+// barrier and the weight DMA behind it all measure the same; what paid, step by step, was removing work -- the MFMAs of the
+// off-board taps (-3...-5 %), the halo fetches (-2.4 %), 46 % of the LDS fragment reads (-3 %).
 #pragma once
 #include "cczero_conv.h"
 
