@@ -26,7 +26,7 @@
 // half-tile lead of the weight DMA instead of two changed nothing, and neither did removing the tap masks (-12 VALU per
 // half-step, timing ablation -DC2_NOMASK): the deficit is not instruction issue, so a leaner addressing scheme would not close it.
 #pragma once
-#include "cczero_conv.h"
+#include "../../chinesechesszero_amd/csrc/cczero_conv.h"
 
 namespace ccz {
 
