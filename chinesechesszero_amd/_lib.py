@@ -105,6 +105,7 @@ PROTOTYPES = {
     "ccz_pack_live_planes_f16": (C.c_int, [_P, _P, _P, C.c_int32]),
     "ccz_pack_live_planes_rows_f16": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P]),
     "ccz_pack_live_planes_g16_f16": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P]),
+    "ccz_pack_conv_weights_g16_f16": (C.c_int, [_P, _P, _P, C.c_int32]),
     "ccz_conv3x3_c256_f16_live": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, _P, C.c_int32, C.c_int32]),
     "ccz_conv3x3_stem_f16_live": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int32, _P, C.c_int32, C.c_int32]),
 }

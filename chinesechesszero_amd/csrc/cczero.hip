@@ -808,7 +808,7 @@ static int conv3x3_launch(const char *who, void *stream, const void *x_dev, cons
     }
 #endif
 #ifdef CCZ_CONV4
-    if (relu & 128) { // bit 6: rows in the group-of-16 layout (profiles/experiments/cczero_conv4.h)
+    if (relu & 1024) { // bit 6: rows in the group-of-16 layout (profiles/experiments/cczero_conv4.h)
         if (n_pixels % 1440) return fail(-1, "%s: the group-of-16 layout needs a multiple of 16 boards", who);
         if (residual_dev)
             hipLaunchKernelGGL(k_conv3x3_v4<true>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev,
@@ -865,6 +865,16 @@ int ccz_pack_live_planes_rows_f16(void *stream, const void *leaf_dev, void *x64_
     if (n_boards == 0) return 0;
     hipLaunchKernelGGL(k_pack_live_planes, dim3((unsigned)n_boards), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)leaf_dev, (half8_t *)x64_dev, (int)n_boards,
                        (const int *)rows_dev, (const int *)n_rows_dev, 0);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ccz_pack_conv_weights_g16_f16(void *stream, const void *w_dev, void *wp_dev, int32_t cin)
+{
+    if (!w_dev || !wp_dev || w_dev == wp_dev || (cin != 64 && cin != 256)) return fail(-1, "ccz_pack_conv_weights_g16_f16: bad arguments (cin must be 64 or 256, not in place)");
+    if ((((uintptr_t)w_dev) | ((uintptr_t)wp_dev)) & 15) return fail(-1, "ccz_pack_conv_weights_g16_f16: pointers must be 16-byte aligned");
+    const int n = 256 * 9 * (cin >> 3);
+    hipLaunchKernelGGL(k_pack_conv_weights_g16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const cv_half8 *)w_dev, (cv_half8 *)wp_dev, (int)cin);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -17,6 +17,8 @@
 //     MFMAs). The slab rows of the ranks above rank 0 and below rank 9 are zeroed once per chunk by the threads that staged
 //     them, so dy needs no test. No per-lane validity flags, no v_cndmask, no per-tap address arithmetic: every LDS address
 //     in the loop is a lane constant + an immediate.
+//   * weights come PACKED (k_pack_conv_weights_g16 / ccz_pack_conv_weights_g16_f16, once per weight set): [ci / 32][tap][co][32]
+//     with the LDS swizzle already applied, so that a half-tile is one contiguous 16 KB block.
 //   * K order = chunks of 32 input channels x 9 taps (one MFMA k-step each; all three convolution kernels add in this order,
 //     so their results are the same values -- up to the sign of a zero, where this one skips a product of zeros): 72
 //     half-steps per tower layer, one weight half-tile (256 output channels x 32 k, 16 KB) per half-step through a ring of
@@ -34,7 +36,7 @@
 // 355-363 us for k_conv3x3_c256; in the workload 301 us per layer (58 % of the dense fp16 peak), 22.14 against 23.69 ms per step
 // on one box. The loop is power-limited like its predecessor's (DESIGN.md sections 2 and 10): 3 / 5 / 7 cells in front of the
 // barrier and the weight DMA behind it all measure the same; what paid, step by step, was removing work -- the MFMAs of the
-// off-board taps (-3...-5 %), the halo fetches (-2.4 %), 46 % of the LDS fragment reads (-3 %).
+// off-board taps (-3...-5 %), the halo fetches (-2.4 %), 46 % of the LDS fragment reads (-3 %), the scattered weight reads (-2.2 %).
 #pragma once
 #include "cczero_conv.h"
 
@@ -99,7 +101,7 @@ __device__ __forceinline__ void g5_step(const G5Ctx &c, cv_f32x4 (&acc)[4][9], i
 {
     constexpr int T = J % 9, BUF = J / 9;
     constexpr int Tn = (T + 1) % 9, BUFn = (T == 8) ? 1 - BUF : BUF;
-    constexpr int deltan = 9 * (Tn / 3 - 1) + (Tn % 3 - 1);
+    [[maybe_unused]] constexpr int deltan = 9 * (Tn / 3 - 1) + (Tn % 3 - 1);
     cv_half8 (&acur)[4] = (J & 1) ? a1 : a0;
     cv_half8 (&anxt)[4] = (J & 1) ? a0 : a1;
     unsigned char *const lds = c.lds;
@@ -151,12 +153,13 @@ __device__ __forceinline__ void g5_step(const G5Ctx &c, cv_f32x4 (&acc)[4][9], i
     {
         unsigned wo = c.woff;
         asm volatile("" : "+v"(wo)); // the address is formed here, per half-step: hoisted for 9 taps x 2 pieces it costs 36 registers
-        const unsigned o = wo + (unsigned)(T2 * c.cin + chunk2 * 32);
+        const unsigned o = wo + (unsigned)((T2 + 9 * chunk2) * 8192); // half-tile (chunk2, T2): one contiguous 16 KB block
+        const unsigned o2 = o + 4096u;                                 // its rows 128..255
         unsigned char *const d = lds + ring_wr * kG5WBytes + c.wave_dst;
         cv_glds16(c.W + o, d);
         __builtin_amdgcn_sched_barrier(0);
         G5_CELLS(2, 3)
-        cv_glds16(c.W + (o + (unsigned)(128 * 9 * c.cin)), d + 8192);
+        cv_glds16(c.W + o2, d + 8192);
         __builtin_amdgcn_sched_barrier(0);
     }
     G5_CELLS(3, kG5Split)
@@ -259,18 +262,17 @@ __global__ __launch_bounds__(512) void k_conv3x3_g16(const _Float16 *__restrict_
             p = p < 0 ? 0 : (p > (long)M - 1 ? (long)M - 1 : p);
             c.xoff[it] = (unsigned)(p * cin + schunk * 8);
         }
-        const int wrow = tid >> 2, wpos = tid & 3;
-        c.woff = (unsigned)(wrow * (9 * cin) + ((wpos ^ ((0 - (wrow >> 2)) & 3)) * 8));
+        c.woff = (unsigned)(tid * 8); // packed weights (k_pack_conv_weights_g16): a half-tile is the LDS image itself, read linearly
     }
     // ---- prologue: slab of chunk 0, weight half-tiles 0..2; the per-lane setup below runs while the DMA is in flight
 #pragma unroll
     for (int it = 0; it < 5; ++it) cv_glds16(X + c.xoff[it], lds + kG5AOff + (it < 4 ? it * 8192 + c.wave_dst : c.wave_dst4));
 #pragma unroll
     for (int u = 0; u < kG5Ahead; ++u) {
-        const unsigned o = c.woff + (unsigned)(u * cin);
+        const unsigned o = c.woff + (unsigned)(u * 8192);
         unsigned char *d = lds + u * kG5WBytes + c.wave_dst;
         cv_glds16(W + o, d);
-        cv_glds16(W + (o + (unsigned)(128 * 9 * cin)), d + 8192);
+        cv_glds16(W + (o + 4096u), d + 8192);
     }
     const int lane1 = r * 64 + ((q4 ^ ((0 - (r >> 2)) & 3)) << 4);
     c.a_off = wm * 4096 + lane1;                               // rows 64 wm + 16 i + r of the half-tile
@@ -355,6 +357,21 @@ __global__ __launch_bounds__(512) void k_conv3x3_g16(const _Float16 *__restrict_
             *(cv_half8 *)(Y + (pbase + it * 2) * kCvC + piece * 8) = v;
         }
     }
+}
+
+// Weights for k_conv3x3_g16: [co][tap][ci] (the memory of a channels-last [co, ci, 3, 3] tensor) -> [ci / 32][tap][co][32], each
+// 64-byte row stored with its four 16-byte chunks in the swizzled order the LDS image uses (position pos of row co holds chunk
+// pos ^ ((-(co >> 2)) & 3)): a half-tile (32 input channels of one tap, all 256 output channels) becomes ONE contiguous 16 KB
+// block that the DMA copies linearly -- whole 128-byte lines instead of 256 scattered 64-byte pieces 4.6 KB apart (-2.7 % per
+// layer). One thread per 16-byte piece.
+__global__ __launch_bounds__(256) void k_pack_conv_weights_g16(const cv_half8 *__restrict__ w, cv_half8 *__restrict__ wp, int cin)
+{
+    const int n = 256 * 9 * (cin >> 3);
+    const int i = blockIdx.x * 256 + threadIdx.x;   // destination piece: ((c32 * 9 + tap) * 256 + co) * 4 + pos
+    if (i >= n) return;
+    const int pos = i & 3, co = (i >> 2) & 255, h = i >> 10, tap = h % 9, c32 = h / 9;
+    const int chunk = pos ^ ((0 - (co >> 2)) & 3);
+    wp[i] = w[(co * 9 + tap) * (cin >> 3) + c32 * 4 + chunk];
 }
 
 } // namespace ccz

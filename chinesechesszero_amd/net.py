@@ -79,6 +79,18 @@ def _fold(conv: nn.Conv2d, bn: nn.BatchNorm2d):
     return w, b
 
 
+def pack_conv_weights_g16(w):
+    """[256, 3, 3, cin] (channels-last memory order of a [co, ci, 3, 3] weight) -> [cin / 32, 9, 256, 32] with the four 16-byte
+    chunks of every 64-byte row in the swizzled order of the kernel's LDS image (position pos of row co holds chunk
+    pos ^ ((-(co >> 2)) & 3)): what ``k_conv3x3_g16`` reads as contiguous 16 KB half-tiles (csrc/cczero_conv_g16.h)."""
+    co, cin = w.shape[0], w.shape[-1]
+    w5 = w.reshape(co, 9, cin // 32, 4, 8)
+    f = (-(torch.arange(co, device=w.device) >> 2)) & 3
+    idx = torch.arange(4, device=w.device)[None, :] ^ f[:, None]
+    w5 = torch.gather(w5, 3, idx[:, None, None, :, None].expand(co, 9, cin // 32, 4, 8))
+    return w5.permute(2, 1, 0, 3, 4).contiguous().view(cin // 32, 9, co, 32)
+
+
 class InferenceNet(nn.Module):
     """Inference copy of ``Net`` for the lockstep evaluator: BN folded, fp16, channels-last.
 
@@ -113,6 +125,11 @@ class InferenceNet(nn.Module):
                 bs.append(nn.Parameter(b.to(dtype), requires_grad=False))
         self.ws = nn.ParameterList(ws)
         self.bs = nn.ParameterList(bs)
+        # the same weights packed for k_conv3x3_g16 (contiguous half-tiles; ccz_pack_conv_weights_g16_f16 is the C-side twin)
+        if ws and ws[0].shape[0] == 256 and ws[0].shape[1] == 256:
+            self.ws_g16 = nn.ParameterList([nn.Parameter(pack_conv_weights_g16(w.permute(0, 2, 3, 1)), requires_grad=False) for w in ws])
+        if hasattr(self, "stem_w64"):
+            self.stem_w64_g16 = nn.Parameter(pack_conv_weights_g16(self.stem_w64), requires_grad=False)
         # float32 copies of the tower biases for the fused convolution kernel (bias is added to the fp32 accumulator)
         self.bs32 = nn.ParameterList([nn.Parameter(b.detach().float().clone(), requires_grad=False) for b in bs])
         # both 1x1 head convs as ONE plain GEMM on the NHWC rows: [pixels, C] x [C, 17 policy + 7 value channels]. (As an
@@ -242,8 +259,9 @@ class InferenceNet(nn.Module):
                 fork.record(cur)
                 for st in streams[1:]:
                     st.wait_event(fork)
+            wsrc = self.ws_g16 if g16 else self.ws
             for i in range(0, len(self.ws), 2):
-                w1, b1_, w2, b2_ = (C.c_void_p(t.data_ptr()) for t in (self.ws[i], self.bs32[i], self.ws[i + 1], self.bs32[i + 1]))
+                w1, b1_, w2, b2_ = (C.c_void_p(t.data_ptr()) for t in (wsrc[i], self.bs32[i], wsrc[i + 1], self.bs32[i + 1]))
                 for k, st in enumerate(streams):
                     _lib.check(L.ccz_conv3x3_c256_f16_live(C.c_void_p(st.cuda_stream), xp, w1, b1_, None, yp, cap, 1 | down | lay, live, g * chains + k, n_parts))
                 for k, st in enumerate(streams):
@@ -286,8 +304,9 @@ class InferenceNet(nn.Module):
         v2 = 4 if os.environ.get("CCZ_CONV_V2", "0") == "1" else 0  # A/B only: the experimental two-workgroups-per-CU form
         # (cczero_conv2.h, compiled into diagnostic builds with -DCCZ_CONV2; the shipped library ignores the bit)
         v2 |= self._force_flag() | (_lib.CONV_G16 if g16 else 0)
+        wsrc = self.ws_g16 if g16 else self.ws
         for i in range(0, len(self.ws), 2):
-            w1, b1_, w2, b2_ = (C.c_void_p(t.data_ptr()) for t in (self.ws[i], self.bs32[i], self.ws[i + 1], self.bs32[i + 1]))
+            w1, b1_, w2, b2_ = (C.c_void_p(t.data_ptr()) for t in (wsrc[i], self.bs32[i], wsrc[i + 1], self.bs32[i + 1]))
             for _, s, xp, yp, n_pixels, _b0 in chains:
                 _lib.check(L.ccz_conv3x3_c256_f16(s, xp, w1, b1_, None, yp, n_pixels, 1 | down | v2))
             for _, s, xp, yp, n_pixels, _b0 in chains:
@@ -323,7 +342,7 @@ class InferenceNet(nn.Module):
                 _lib.check(L.ccz_pack_live_planes_g16_f16(s, C.c_void_p(leaf_input.data_ptr()), C.c_void_p(x64.data_ptr()), B, None, None))
             else:
                 _lib.check(L.ccz_pack_live_planes_f16(s, C.c_void_p(leaf_input.data_ptr()), C.c_void_p(x64.data_ptr()), B))
-            _lib.check(L.ccz_conv3x3_stem_f16(s, C.c_void_p(x64.data_ptr()), C.c_void_p(self.stem_w64.data_ptr()), C.c_void_p(self.stem_b32.data_ptr()),
+            _lib.check(L.ccz_conv3x3_stem_f16(s, C.c_void_p(x64.data_ptr()), C.c_void_p((self.stem_w64_g16 if g16 else self.stem_w64).data_ptr()), C.c_void_p(self.stem_b32.data_ptr()),
                                               C.c_void_p(y.data_ptr()), Bp * 90, 1 | self._force_flag() | lay))
             return y
         rows, n_rows = plan
@@ -337,7 +356,7 @@ class InferenceNet(nn.Module):
         x64, y = bufs[key]
         pack = L.ccz_pack_live_planes_g16_f16 if g16 else L.ccz_pack_live_planes_rows_f16
         _lib.check(pack(s, C.c_void_p(leaf_input.data_ptr()), C.c_void_p(x64.data_ptr()), B, C.c_void_p(rows.data_ptr()), C.c_void_p(n_rows.data_ptr())))
-        _lib.check(L.ccz_conv3x3_stem_f16_live(s, C.c_void_p(x64.data_ptr()), C.c_void_p(self.stem_w64.data_ptr()), C.c_void_p(self.stem_b32.data_ptr()),
+        _lib.check(L.ccz_conv3x3_stem_f16_live(s, C.c_void_p(x64.data_ptr()), C.c_void_p((self.stem_w64_g16 if g16 else self.stem_w64).data_ptr()), C.c_void_p(self.stem_b32.data_ptr()),
                                                C.c_void_p(y.data_ptr()), Bp * 90 if g16 else -(-B // 8) * 8 * 90, 1 | lay, C.c_void_p(n_rows.data_ptr()), 0, 1))
         return y
 

@@ -348,8 +348,9 @@ int ccz_bias_act_f16(void *stream, void *y_dev, const void *bias_dev, const void
  * Row layouts. Default: NHWC, row = board * 90 + pos (pos = rank * 9 + file). CCZ_CONV_G16: row = (g * 90 + pos) * 16 + j
  * for board 16 g + j (n_pixels must then be a multiple of 1440 = 16 boards): sixteen consecutive rows are ONE board position
  * of sixteen boards, which lets the kernel skip the taps that leave the board instead of multiplying zeros, on tiles of two
- * whole ranks (csrc/cczero_conv_g16.h: the form the evaluator uses for batches above 64 boards). All kernels behind these entry
- * points add their products in the same order: a board's result is the same in either layout and at any batch size. */
+ * whole ranks (csrc/cczero_conv_g16.h: the form the evaluator uses for batches above 64 boards). With CCZ_CONV_G16 the WEIGHTS
+ * are packed too: w_dev is what ccz_pack_conv_weights_g16_f16 wrote (below). All kernels behind these entry points add their
+ * products in the same order: a board's result is the same in either layout and at any batch size. */
 #define CCZ_CONV_RELU 1
 #define CCZ_CONV_DESCENDING 2
 #define CCZ_CONV_FORCE_SMALL 16 /* A/B runs and tests: k_conv3x3_small whatever the batch size (default layout only) */
@@ -357,6 +358,10 @@ int ccz_bias_act_f16(void *stream, void *y_dev, const void *bias_dev, const void
 #define CCZ_CONV_G16 64
 int ccz_conv3x3_c256_f16(void *stream, const void *x_dev, const void *w_dev, const void *bias_f32_dev,
                          const void *residual_dev, void *y_dev, int64_t n_pixels, int32_t relu);
+/* Weights for the CCZ_CONV_G16 form, once per weight set: w [256, 3, 3, cin] fp16 (cin = 256: tower, 64: stem) ->
+ * wp [cin / 32][9][256][32] fp16, the four 16-byte chunks of every 64-byte row in the order of the kernel's LDS image: a
+ * half-tile (32 input channels of one tap, all output channels) is then one contiguous 16 KB block. Not in place. */
+int ccz_pack_conv_weights_g16_f16(void *stream, const void *w_dev, void *wp_dev, int32_t cin);
 
 /* The stem convolution (reference net.py:59-66,86-88: conv3x3(119 -> 256) -> BN(folded) -> ReLU) with the same kernel,
  * one 64-channel chunk: x64 [n_pixels, 64] fp16 holds the 21 planes that can be non-zero on the search path in

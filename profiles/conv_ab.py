@@ -65,21 +65,25 @@ def main():
     def from_g16(t):
         return t.view(B // 16, 90, 16, 256).permute(0, 2, 1, 3).reshape(B, 10, 9, 256).permute(0, 3, 1, 2)
 
-    G16 = 64 | 128   # bit 6: the shipped group-of-16 kernel; bit 7: the v4 experiment (same layout)
+    G16 = 64 | 1024   # bit 6: the shipped group-of-16 kernel (packed weights); bit 10: the v4 experiment (same row layout, plain weights)
     g16 = any(fl & G16 for _, _, fl in libs)
     if g16:
         xg, rg = to_g16(x), to_g16(res)
         yg = torch.empty_like(xg)
+        import sys
+        sys.path.insert(0, ROOT)
+        from chinesechesszero_amd.net import pack_conv_weights_g16
+        wp = pack_conv_weights_g16(w.permute(0, 2, 3, 1))
 
-    def run(L, y, fl=1):
+    def run(L, y, fl=1, name=""):
         if fl & G16:
-            rc = L.ccz_conv3x3_c256_f16(s, xg.data_ptr(), w.data_ptr(), bias.data_ptr(), rg.data_ptr() if a.res else None, yg.data_ptr(), B * 90, fl)
+            rc = L.ccz_conv3x3_c256_f16(s, xg.data_ptr(), (wp if (fl & 64 and "unpacked" not in name) else w).data_ptr(), bias.data_ptr(), rg.data_ptr() if a.res else None, yg.data_ptr(), B * 90, fl)
         else:
             rc = L.ccz_conv3x3_c256_f16(s, x.data_ptr(), w.data_ptr(), bias.data_ptr(), res.data_ptr() if a.res else None, y.data_ptr(), B * 90, fl)
         assert rc == 0
 
     for (n, L, fl), y in zip(libs, ys):
-        run(L, y, fl)
+        run(L, y, fl, n)
         if fl & G16:
             y.copy_(from_g16(yg))
     torch.cuda.synchronize()
@@ -96,10 +100,10 @@ def main():
     for _ in range(a.rounds):
         for (n, L, fl), y in zip(libs, ys):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            run(L, y, fl)
+            run(L, y, fl, n)
             e0.record()
             for _ in range(a.iters):
-                run(L, y, fl)
+                run(L, y, fl, n)
             e1.record()
             torch.cuda.synchronize()
             times[n].append(e0.elapsed_time(e1) / a.iters * 1e3)

@@ -269,6 +269,17 @@ def _to_g16(t):
     return t.permute(0, 2, 3, 1).reshape(B // 16, 16, 90, Cn).permute(0, 2, 1, 3).contiguous()
 
 
+def _pack_w(w_nhwc, cin):
+    """ccz_pack_conv_weights_g16_f16 on [256, 3, 3, cin] weights; must equal the torch twin the evaluator uses"""
+    from chinesechesszero_amd import _lib
+    from chinesechesszero_amd.net import pack_conv_weights_g16
+    wp = torch.empty(cin // 32, 9, 256, 32, dtype=torch.float16, device=w_nhwc.device)
+    s = C.c_void_p(torch.cuda.current_stream(w_nhwc.device).cuda_stream)
+    _lib.check(_lib.lib().ccz_pack_conv_weights_g16_f16(s, C.c_void_p(w_nhwc.data_ptr()), C.c_void_p(wp.data_ptr()), cin))
+    assert torch.equal(wp, pack_conv_weights_g16(w_nhwc.view(256, 3, 3, cin)))
+    return wp
+
+
 def _from_g16(t, B):
     Cn = t.shape[-1]
     return t.reshape(B // 16, 90, 16, Cn).permute(0, 2, 1, 3).reshape(B, 10, 9, Cn).permute(0, 3, 1, 2)
@@ -291,11 +302,12 @@ def test_group_of_16_kernel_gives_the_tile_kernels_values(boards):
     w = (torch.randn(256, 256, 3, 3, generator=g) * 0.03).to(dev).half().contiguous(memory_format=cl)
     b = (torch.randn(256, generator=g) * 0.2).to(dev)
     xg, rg = _to_g16(x), _to_g16(r)
+    wp = _pack_w(w.permute(0, 2, 3, 1), 256)     # the group-of-16 form takes its weights packed (contiguous half-tiles)
     ref = F.conv2d(x.float(), w.float(), b, padding=1)
     for res, relu in ((None, 1), (r, 1), (None, 0), (r, 3)):
         y_tile = _conv(x, w, b, res, torch.full_like(x, float("nan")), (relu & 1) | _lib.CONV_FORCE_TILE)
         yg = torch.full_like(xg, float("nan"))
-        _lib.check(L.ccz_conv3x3_c256_f16(s, C.c_void_p(xg.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()),
+        _lib.check(L.ccz_conv3x3_c256_f16(s, C.c_void_p(xg.data_ptr()), C.c_void_p(wp.data_ptr()), C.c_void_p(b.data_ptr()),
                                           C.c_void_p(rg.data_ptr()) if res is not None else None, C.c_void_p(yg.data_ptr()), boards * 90,
                                           relu | _lib.CONV_G16))
         got = _from_g16(yg, boards)
@@ -306,7 +318,7 @@ def test_group_of_16_kernel_gives_the_tile_kernels_values(boards):
         assert (got.float() - want).abs().max().item() < 4e-3 * max(1.0, want.abs().max().item())
     # output written over the residual (how the tower uses it)
     yg = rg.clone()
-    _lib.check(L.ccz_conv3x3_c256_f16(s, C.c_void_p(xg.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(yg.data_ptr()),
+    _lib.check(L.ccz_conv3x3_c256_f16(s, C.c_void_p(xg.data_ptr()), C.c_void_p(wp.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(yg.data_ptr()),
                                       C.c_void_p(yg.data_ptr()), boards * 90, 1 | _lib.CONV_G16))
     assert torch.equal(_from_g16(yg, boards), _conv(x, w, b, r, torch.empty_like(x), 1 | _lib.CONV_FORCE_TILE))
     # stem shape (64 input channels = two chunks of 32) through the layout-aware pack
@@ -321,11 +333,11 @@ def test_group_of_16_kernel_gives_the_tile_kernels_values(boards):
     ysg = torch.empty_like(ys)
     _lib.check(L.ccz_conv3x3_stem_f16(s, C.c_void_p(x64.data_ptr()), C.c_void_p(w64.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(ys.data_ptr()),
                                       boards * 90, 1 | _lib.CONV_FORCE_TILE))
-    _lib.check(L.ccz_conv3x3_stem_f16(s, C.c_void_p(x64g.data_ptr()), C.c_void_p(w64.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(ysg.data_ptr()),
+    _lib.check(L.ccz_conv3x3_stem_f16(s, C.c_void_p(x64g.data_ptr()), C.c_void_p(_pack_w(w64, 64).data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(ysg.data_ptr()),
                                       boards * 90, 1 | _lib.CONV_G16))
     assert torch.equal(ysg.view(boards // 16, 90, 16, 256).permute(0, 2, 1, 3).reshape(boards * 90, 256), ys)
     # not a multiple of 16 boards: refused
-    assert L.ccz_conv3x3_c256_f16(s, C.c_void_p(xg.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), None, C.c_void_p(yg.data_ptr()),
+    assert L.ccz_conv3x3_c256_f16(s, C.c_void_p(xg.data_ptr()), C.c_void_p(wp.data_ptr()), C.c_void_p(b.data_ptr()), None, C.c_void_p(yg.data_ptr()),
                                   (boards - 1) * 90, 1 | _lib.CONV_G16) != 0
 
 
@@ -345,6 +357,7 @@ def test_group_of_16_kernel_live_rows(live, n_parts):
     w = (torch.randn(256, 256, 3, 3, generator=g) * 0.03).to(dev).half().contiguous(memory_format=cl)
     b = (torch.randn(256, generator=g) * 0.2).to(dev)
     xg, rg = _to_g16(x), _to_g16(r)
+    w = _pack_w(w.permute(0, 2, 3, 1), 256)
     full = torch.empty_like(xg)
     _lib.check(L.ccz_conv3x3_c256_f16(s, C.c_void_p(xg.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(rg.data_ptr()),
                                       C.c_void_p(full.data_ptr()), boards * 90, 1 | _lib.CONV_G16))
