@@ -58,7 +58,7 @@ struct G5Ctx {
     const _Float16 *X, *W;   // uniform bases: every DMA is base (scalar) + 32-bit element offset (one VGPR)
     unsigned xoff[5];        // per staging pass: this thread's 16-byte source in X (chunk 0), row clamped into the tensor
     unsigned woff;           // this thread's 16-byte weight source in W (row pass 0, tap 0, chunk 0)
-    int zo[4], zd[4];        // SCALAR: where this wave's zero stores go for slab 0 (pass 0, 1, 3, 4) and the step to slab 1 (0 for the dump area)
+    int zo[2], zd[2];        // SCALAR: where this wave's two zero stores go for slab 0, and the step to slab 1 (0 for the dump area)
     int wave_dst;            // w * 1024
     int lane16;              // (lane & 63) * 16
     int wave_dst4;           // LDS offset of this wave's piece in staging pass 4 (waves 4-7 repeat their pass-3 piece)
@@ -80,7 +80,7 @@ template <int T, int N> __host__ __device__ constexpr bool g5_on_board() // is t
 // The rank above rank 0 (tiles with k = 0) and the rank below rank 9 (k = 4) do not exist: their slab rows were staged from
 // clamped addresses (the DMA count stays static) and are overwritten with zeros by the thread that staged them, after its DMA has
 // landed and before the barrier that publishes the slab. Rows 0..143 / 432..575 = whole 16-row pieces, so the tests are
-// wave-uniform -- and there are no tests in the loop: the four stores always execute, a wave that has nothing to zero aims
+// wave-uniform -- and there are no tests in the loop: the two stores always execute, a wave that has nothing to zero aims
 // them at its 1 KB dump area behind the slabs (a branch here splits the loop body and costs the register allocation 90 spills).
 __device__ __forceinline__ void g5_zero_ranks(const G5Ctx &c, int buf)
 {
@@ -89,7 +89,7 @@ __device__ __forceinline__ void g5_zero_ranks(const G5Ctx &c, int buf)
     typedef int g5_int4 __attribute__((ext_vector_type(4)));
     const g5_int4 z = {zero, zero, zero, zero};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *(g5_int4 *)(c.lds + (l16 + (c.zo[j] + buf * c.zd[j]))) = z;
+    for (int j = 0; j < 2; ++j) *(g5_int4 *)(c.lds + (l16 + (c.zo[j] + buf * c.zd[j]))) = z;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
@@ -236,12 +236,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_g16(const _Float16 *__restrict_
     c.X = X;
     c.W = W;
     {
-        const bool z[4] = {k == 0, k == 0 && w == 0, k == 4 && w >= 3, k == 4 && w < 4}; // passes 0, 1, 3, 4
-        const int pass[4] = {0, 1, 3, 4};
+        // rows 0..143 (k = 0) = pass 0 of every wave + pass 1 of wave 0; rows 432..575 (k = 4) = pass 3 of waves 3..7 + pass 4 of
+        // waves 0..3: two stores per wave cover either (wave 0 resp. wave 3 need both of theirs); anything else goes to the dump area
+        const int piece[2] = {k == 0 ? 0 : k == 4 ? (w >= 3 ? 3 : 4) : -1, (k == 0 && w == 0) ? 1 : (k == 4 && w == 3) ? 4 : -1};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            c.zo[j] = __builtin_amdgcn_readfirstlane(z[j] ? kG5AOff + pass[j] * 8192 + w * 1024 : kG5Dump + w * 1024);
-            c.zd[j] = __builtin_amdgcn_readfirstlane(z[j] ? kG5SlabBytes : 0);
+        for (int j = 0; j < 2; ++j) {
+            c.zo[j] = __builtin_amdgcn_readfirstlane(piece[j] >= 0 ? kG5AOff + piece[j] * 8192 + w * 1024 : kG5Dump + w * 1024);
+            c.zd[j] = __builtin_amdgcn_readfirstlane(piece[j] >= 0 ? kG5SlabBytes : 0);
         }
     }
     c.wave_dst = w * 1024;
