@@ -36,7 +36,10 @@
 // 355-363 us for k_conv3x3_c256; in the workload 301 us per layer (58 % of the dense fp16 peak), 22.14 against 23.69 ms per step
 // on one box. The loop is power-limited like its predecessor's (DESIGN.md sections 2 and 10): 3 / 5 / 7 cells in front of the
 // barrier and the weight DMA behind it all measure the same; what paid, step by step, was removing work -- the MFMAs of the
-// off-board taps (-3...-5 %), the halo fetches (-2.4 %), 46 % of the LDS fragment reads (-3 %), the scattered weight reads (-2.2 %).
+// off-board taps (-3...-5 %), the halo fetches (-2.4 %), 46 % of the LDS fragment reads (-3 %), the scattered weight reads (-2.2 %),
+// half of the zero stores (-0.9 %). Not everything that removes LDS traffic pays: an epilogue straight from registers (v_permlane16_swap
+// pairs two tiles so that a lane stores 16 contiguous bytes; no LDS image, no barrier) is bit-identical and 5 % slower -- its stores
+// are sixteen 64-byte segments per instruction instead of whole 512-byte rows.
 #pragma once
 #include "cczero_conv.h"
 
