@@ -169,7 +169,7 @@ class InferenceNet(nn.Module):
         return F.relu_(y)
 
     FUSED_MIN_BOARDS = 1  # every batch runs on the hand-written convolution: up to 64 boards on k_conv3x3_small (16-channel x
-    # 64-pixel blocks spread over the chip), above that on k_conv3x3_g16 (group-of-16 rows, whole-rank tiles) -- the same values, so a
+    # 64-pixel blocks spread over the chip), above that on k_conv3x3_c256 (256-pixel tiles) and, from 640 boards, k_conv3x3_g16 (group-of-16 rows) -- the same values, so a
     # board's tower activations do not depend on the batch size. (Round 2 sent batches under 192 boards to MIOpen + an epilogue
     # pass: 12.1 us per tower layer at one board, profiles/r03_single_board.json.)
 
@@ -181,12 +181,18 @@ class InferenceNet(nn.Module):
         return bool(x.is_cuda and x.dtype == torch.float16 and x.shape[1] == 256 and x.shape[0] >= self.FUSED_MIN_BOARDS
                     and x.is_contiguous(memory_format=torch.channels_last))
 
-    G16_MIN_BOARDS = 65  # batches above the small kernel's range run in the group-of-16 row layout (cczero_conv_g16.h: whole-rank
-    # tiles, off-board taps skipped), padded to a multiple of 16 boards; CCZ_CONV_LAYOUT=nhwc keeps the board-major rows and the
-    # 256-pixel tile kernel for A/B runs. Same values either way (all three kernels add in the same order).
+    G16_MIN_BOARDS = 640  # batches from here on run in the group-of-16 row layout (cczero_conv_g16.h: whole-rank tiles, off-board taps
+    # skipped), padded to a multiple of 16 boards; below it (a single under-filled round of tiles: latency, not throughput) the
+    # 256-pixel tile kernel's smaller tiles are 1-2 % quicker (128 / 256 / 512 boards: 3.74 / 3.78 / 3.94 against 3.81 / 3.82 /
+    # 3.97 ms per step; 1024 boards: 6.0 against 6.4). ``CCZ_CONV_LAYOUT=nhwc`` keeps the board-major rows at every size,
+    # ``CCZ_CONV_LAYOUT=g16`` uses the group-of-16 layout from 65 boards on (A/B runs, tests). Same values either way (all three
+    # kernels add in the same order).
 
     def _g16(self, B) -> bool:
-        return B >= self.G16_MIN_BOARDS and os.environ.get("CCZ_CONV_LAYOUT", "g16") != "nhwc" and not self._force_flag()
+        mode = os.environ.get("CCZ_CONV_LAYOUT", "auto")
+        if mode == "nhwc" or self._force_flag():
+            return False
+        return B >= (65 if mode == "g16" else self.G16_MIN_BOARDS)
 
     TOWER_GROUP_BOARDS_G16 = 4096
     TOWER_GROUP_BOARDS = 2048  # boards per sequential group (working set of a group fits the Infinity Cache); env CCZ_TOWER_GROUPS

@@ -348,7 +348,7 @@ int ccz_bias_act_f16(void *stream, void *y_dev, const void *bias_dev, const void
  * Row layouts. Default: NHWC, row = board * 90 + pos (pos = rank * 9 + file). CCZ_CONV_G16: row = (g * 90 + pos) * 16 + j
  * for board 16 g + j (n_pixels must then be a multiple of 1440 = 16 boards): sixteen consecutive rows are ONE board position
  * of sixteen boards, which lets the kernel skip the taps that leave the board instead of multiplying zeros, on tiles of two
- * whole ranks (csrc/cczero_conv_g16.h: the form the evaluator uses for batches above 64 boards). With CCZ_CONV_G16 the WEIGHTS
+ * whole ranks (csrc/cczero_conv_g16.h: the form the evaluator uses from 640 boards on). With CCZ_CONV_G16 the WEIGHTS
  * are packed too: w_dev is what ccz_pack_conv_weights_g16_f16 wrote (below). All kernels behind these entry points add their
  * products in the same order: a board's result is the same in either layout and at any batch size. */
 #define CCZ_CONV_RELU 1

@@ -157,7 +157,7 @@ def test_fused_tower_matches_reference_architecture_and_miopen_path(monkeypatch)
     assert inf._use_fused_tower(torch.empty(8, 256, 10, 9, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last))
 
 
-def test_fused_tower_board_ranges_on_several_streams_equal_one_chain():
+def test_fused_tower_board_ranges_on_several_streams_equal_one_chain(monkeypatch):
     """The tower cuts the batch into independent board ranges on separate HIP streams (net.py _tower_fused): same bits as
     one chain, whatever the cut (a board's arithmetic does not depend on which tile it falls in)."""
     from chinesechesszero_amd.net import InferenceNet, Net
@@ -165,7 +165,8 @@ def test_fused_tower_board_ranges_on_several_streams_equal_one_chain():
     torch.manual_seed(6)
     net = Net(256, 2).to(dev).eval()
     inf = InferenceNet(net).to(dev).eval()
-    for B in (600, 608):   # 600 boards: board-major rows, 256-pixel tiles; 608 = 38 groups of 16: the group-of-16 layout
+    for B in (600, 608):   # 600 boards: board-major rows, 256-pixel tiles; 608 = 38 groups of 16: the group-of-16 layout (forced)
+        monkeypatch.setenv("CCZ_CONV_LAYOUT", "g16" if B == 608 else "auto")
         x0 = torch.relu(torch.randn(B, 256, 10, 9, device=dev)).half().contiguous(memory_format=torch.channels_last)
         outs = []
         for chains in (1, 8, 3):

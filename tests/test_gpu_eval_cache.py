@@ -116,11 +116,12 @@ def test_slot_collisions_and_a_tiny_table_change_nothing():
     assert s1["cache_stores"] > 1024          # the table was overwritten many times over
 
 
-@pytest.mark.parametrize("B", [320, 200])
-def test_real_net_planned_rows_and_cleared_on_new_weights(B):
+@pytest.mark.parametrize("B,layout", [(320, "auto"), (320, "g16"), (200, "g16")])
+def test_real_net_planned_rows_and_cleared_on_new_weights(B, layout, monkeypatch):
     """The fused evaluator (k_pack_live_planes gather, stem and tower with device-side live-row counts, heads) on the planned
-    rows: the same search as without a cache; a weight change empties the table. 320 boards = 20 whole groups of the tower's
-    group-of-16 row layout; 200 boards are padded to 13 groups."""
+    rows: the same search as without a cache; a weight change empties the table. Board-major rows (what 320 boards get by
+    default) and, forced, the group-of-16 row layout: 320 boards = 20 whole groups, 200 boards are padded to 13 groups."""
+    monkeypatch.setenv("CCZ_CONV_LAYOUT", layout)
     from chinesechesszero_amd.net import PolicyValueNet
     from chinesechesszero_amd.selfplay import BatchedSelfPlay
     dev = torch.device("cuda", 0)

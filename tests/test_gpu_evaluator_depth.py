@@ -124,18 +124,22 @@ def test_shapes_off_the_fused_path_are_logged(caplog):
     assert not [r for r in caplog.records if "fused" in r.getMessage()]      # 64 boards and ONE board: both on the fused kernels
 
 
-def test_tower_activations_do_not_depend_on_the_batch_size():
-    """One board evaluated alone and in a batch of 24 (k_conv3x3_small), of 90 and of 300 (the 256-pixel tile kernel): the stem + tower output of that board is the same, bit for bit -- the small-batch kernel performs the tile
-    kernel's operations in the tile kernel's order. (The heads are GEMMs of torch and may pick another kernel per batch size:
-    logits agree to float16 round-off, not bit for bit.)"""
+def test_tower_activations_do_not_depend_on_the_batch_size(monkeypatch):
+    """One board evaluated alone and in a batch of 24 (k_conv3x3_small), of 90 and of 300 (the 256-pixel tile kernel), of 700 (the
+    group-of-16 kernel, from 640 boards on) and -- layout forced -- of 90 and 300 on the group-of-16 kernel (padded to whole
+    groups): the stem + tower output of that board is the same, bit for bit -- all three kernels add the same products in the same
+    order. (The heads are GEMMs of torch and may pick another kernel per batch size: logits agree to float16 round-off, not bit
+    for bit.)"""
     from chinesechesszero_amd.net import InferenceNet, Net
     dev = torch.device("cuda", 0)
     torch.manual_seed(3)
     inf = InferenceNet(Net(256, 6).to(dev).eval()).to(dev).eval()
-    x = _leaf_batch(300, 16, seed=5)
+    x = _leaf_batch(700, 16, seed=5)
     probe = x[123:124].clone()
     outs = []
-    for B in (1, 24, 90, 300):
+    for B, layout in ((1, "auto"), (24, "auto"), (90, "auto"), (300, "auto"), (700, "auto"), (90, "g16"), (300, "g16")):
+        monkeypatch.setenv("CCZ_CONV_LAYOUT", layout)
+        assert inf._g16(B) == (B >= 640 or (layout == "g16" and B > 64))
         xb = x[:B].clone()
         xb[B // 2] = probe[0]
         t = inf.tower_activations(xb)
