@@ -184,7 +184,7 @@ class InferenceNet(nn.Module):
     G16_MIN_BOARDS = 640  # batches from here on run in the group-of-16 row layout (cczero_conv_g16.h: whole-rank tiles, off-board taps
     # skipped), padded to a multiple of 16 boards; below it (a single under-filled round of tiles: latency, not throughput) the
     # 256-pixel tile kernel's smaller tiles are 1-2 % quicker (128 / 256 / 512 boards: 3.74 / 3.78 / 3.94 against 3.81 / 3.82 /
-    # 3.97 ms per step; 1024 boards: 6.0 against 6.4). ``CCZ_CONV_LAYOUT=nhwc`` keeps the board-major rows at every size,
+    # 3.97 ms per step; from 640 boards on the group-of-16 kernel wins: 640 / 768 / 1024 boards 4.15 / 4.58 / 6.0 against 4.34 / 4.94 / 6.4). ``CCZ_CONV_LAYOUT=nhwc`` keeps the board-major rows at every size,
     # ``CCZ_CONV_LAYOUT=g16`` uses the group-of-16 layout from 65 boards on (A/B runs, tests). Same values either way (all three
     # kernels add in the same order).
 
