@@ -22,13 +22,14 @@ MASK_WORDS = 66
 PLANES = 10710
 REC_BYTES, REC_HDR, REC_IDS, REC_PI = 880, 96, 112, 368  # compact ply record (include/cczero.h CCZ_REC_*)
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 CONV_RELU, CONV_DESCENDING, CONV_FORCE_SMALL, CONV_FORCE_TILE, CONV_G16 = 1, 2, 16, 32, 64  # CCZ_CONV_* flag bits
 RULE_PERPETUAL_CHECK = 1
 RULE_PAWN_MOVE_RESETS_CLOCK = 2
 FLAG_REFERENCE_QUIRKS = 1
 FLAG_NO_MIRROR = 2
 FLAG_VALUE_F16 = 4
+FLAG_CACHE_VERIFY = 8
 LEAF_EXPAND, LEAF_DRAW, LEAF_LOSS, LEAF_SKIP = 0, 1, 2, 3
 
 ERR_BITS = {1: "node pool exhausted (raise max_nodes)", 2: "selection path deeper than max_depth", 64: "history chain overflow (> 128 positions since the last capture)",
@@ -59,6 +60,7 @@ class Stats(C.Structure):
         ("expansions", C.c_int64), ("terminal_leaves", C.c_int64), ("error_flags", C.c_int32), ("reserved", C.c_int32),
         ("hbm_bytes", C.c_int64), ("pruned_subtrees", C.c_int64),
         ("cache_probes", C.c_int64), ("cache_hits", C.c_int64), ("cache_shared_rows", C.c_int64), ("cache_stores", C.c_int64),
+        ("cache_verified", C.c_int64), ("cache_verify_mismatches", C.c_int64),
     ]
 
 
@@ -91,6 +93,7 @@ PROTOTYPES = {
     "ccz_game_status": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "ccz_root_positions": (C.c_int, [_P, _P, _P]),
     "ccz_leaf_info": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "ccz_leaf_priors": (C.c_int, [_P, _P, _P, _P]),
     "ccz_leaf_keys": (C.c_int, [_P, _P, _P, _P]),
     "ccz_harvest_rows": (C.c_int, [_P, _P, C.POINTER(C.c_int64)]),
     "ccz_harvest": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),

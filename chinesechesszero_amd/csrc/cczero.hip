@@ -154,6 +154,8 @@ int ccz_create(const ccz_config *cfg, ccz_engine **out)
     d.seed = cfg->seed;
     d.board_id_base = cfg->board_id_base;
     // ---- run-time rule tables (ABI 2)
+    if ((cfg->flags & CCZ_FLAG_CACHE_VERIFY) && !cfg->eval_cache_log2) { delete e; return fail(-1, "ccz_create: CCZ_FLAG_CACHE_VERIFY without an evaluation cache (eval_cache_log2)"); }
+    if (cfg->flags & ~(CCZ_FLAG_REFERENCE_QUIRKS | CCZ_FLAG_NO_MIRROR | CCZ_FLAG_VALUE_F16 | CCZ_FLAG_CACHE_VERIFY)) { delete e; return fail(-1, "ccz_create: unknown flags 0x%x", cfg->flags); }
     if (cfg->eval_cache_log2 && (cfg->eval_cache_log2 < 10 || cfg->eval_cache_log2 > 28)) { delete e; return fail(-1, "ccz_create: eval_cache_log2 must be 0 (no cache) or 10..28"); }
     if (cfg->rule_flags & ~(CCZ_RULE_PERPETUAL_CHECK | CCZ_RULE_PAWN_MOVE_RESETS_CLOCK)) { delete e; return fail(-1, "ccz_create: unknown rule_flags 0x%x", cfg->rule_flags); }
     d.rule_flags = cfg->rule_flags;
@@ -216,6 +218,7 @@ int ccz_create(const ccz_config *cfg, ccz_engine **out)
         ALLOC(d.cslot, B);
         ALLOC(d.cstate, B);
         ALLOC(d.cins, B);
+        ALLOC(d.cver, B);
         ALLOC(d.crep, B);
         ALLOC(d.row_of, B);
         ALLOC(d.vleaf, B);
@@ -529,6 +532,18 @@ int ccz_leaf_info(ccz_engine *e, void *stream, uint8_t *status_host, int32_t *k_
     return 0;
 }
 
+int ccz_leaf_priors(ccz_engine *e, void *stream, float *prior_host, float *value_host)
+{
+    NEED(e);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t B = (size_t)e->d.B;
+    if (value_host && !e->d.cache) return fail(-1, "ccz_leaf_priors: engine-owned leaf values exist only with an evaluation cache (pass value_host = NULL)");
+    if (prior_host) HIP_TRY(hipMemcpyAsync(prior_host, e->d.prior128, B * kMaxLegal * 4, hipMemcpyDeviceToHost, s));
+    if (value_host) HIP_TRY(hipMemcpyAsync(value_host, e->d.vleaf, B * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
 int ccz_leaf_keys(ccz_engine *e, void *stream, uint64_t *keys_dev, uint8_t *status_dev)
 {
     NEED(e);
@@ -693,6 +708,8 @@ int ccz_get_stats(ccz_engine *e, void *stream, ccz_stats *out)
         out->cache_hits += (int64_t)b.cache_hits;
         out->cache_shared_rows += (int64_t)b.cache_shared;
         out->cache_stores += (int64_t)b.cache_stores;
+        out->cache_verified += (int64_t)b.cache_verified;
+        out->cache_verify_mismatches += (int64_t)b.cache_mismatch;
         if (b.nodes_peak > out->nodes_peak) out->nodes_peak = b.nodes_peak;
         if (b.depth_peak > out->depth_peak) out->depth_peak = b.depth_peak;
     }

@@ -51,7 +51,8 @@ struct __align__(8) BoardMeta {
 struct __align__(16) CacheEntry {
     uint64_t key;   // 0 = empty
     float v;
-    uint32_t k;     // number of legal moves (checked on a hit)
+    uint32_t k;     // bits 0..7: number of legal moves; bits 8..31: a 24-bit hash of the legal-move LIST (cache_tag). Both are
+                    // checked on a hit: the priors are aligned with that list, and it is information the key does not hold
     float pri[kMaxLegal];
 };
 static_assert(sizeof(CacheEntry) == 528, "cache entry is 528 bytes");
@@ -62,6 +63,8 @@ struct BoardStats {
     // evaluation cache, counted per board by the board's own wave (no atomics): leaves probed, hits, leaves served by another
     // board's evaluator row of the same step, entries stored
     unsigned int cache_probes, cache_hits, cache_shared, cache_stores;
+    // CCZ_FLAG_CACHE_VERIFY: hits that were sent through the evaluator again, and those whose fresh priors / value differ
+    unsigned int cache_verified, cache_mismatch;
 };
 
 struct Dev {
@@ -92,6 +95,7 @@ struct Dev {
     uint32_t *cslot;      // [B] slot of the pending leaf
     uint8_t *cstate;      // [B] 0 = miss: needs a row of the evaluator, 1 = hit, 2 = no evaluation needed (terminal leaf, none)
     uint8_t *cins;        // [B] this board's fresh evaluation is stored (it is the slot's claim winner)
+    uint8_t *cver;        // [B] CCZ_FLAG_CACHE_VERIFY: a hit that is evaluated again and compared with what the table returned
     int32_t *crep;        // [B] the board whose evaluator row this board uses (itself, or the same-key board of lower index)
     int32_t *row_of;      // [B] compact evaluator row holding this board's logits / value (misses)
     float *vleaf;         // [B] leaf value of the pending leaf (step / expand_backup read it when value_dev == NULL)

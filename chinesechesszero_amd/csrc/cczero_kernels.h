@@ -550,6 +550,20 @@ __global__ __launch_bounds__(64) void k_step(Dev D, const float *prob, const flo
     CCZ_STAMP(D, b, lane, 9)
 }
 
+// What a cache entry is checked against besides its 64-bit key: the number of legal moves (8 bits) and a 24-bit hash of the
+// legal-move LIST in the order the priors are stored in. The list is derived from the position, not from the key: a position that
+// collides with another one on all 64 key bits (2^-40 per probe of an occupied slot, i.e. once in days at 2 x 10^5 probes a
+// second) would also have to have the same legal moves in the same order to be served the other position's priors; a list that
+// differs in any entry passes with probability 2^-24. Residual per probe: < 2^-64.
+__device__ __forceinline__ uint32_t cache_tag(int id0, int id1, int k, int lane)
+{
+    uint64_t h = 0;
+    if (lane < k) h ^= mix64(((uint64_t)(uint32_t)id0 << 8 | (uint32_t)lane) + 0x9E3779B97F4A7C15ull);
+    if (64 + lane < k) h ^= mix64(((uint64_t)(uint32_t)id1 << 8 | (uint32_t)(64 + lane)) + 0x9E3779B97F4A7C15ull);
+    h = wave_readlane64(wave_incl_xor64(h), 63);
+    return ((uint32_t)(h >> 40) << 8) | (uint32_t)(k & 0xff);
+}
+
 // ------------------------------------------------------------------ compact evaluator boundary: logits -> priors of the legal moves
 // exp(log_softmax(logits))[legal ids] (net.py:202-205) for every board in one pass: the wave reads its 2086
 // logits once (coalesced), reduces max and sum on the DPP network, and writes only the <= 128 priors the
@@ -587,10 +601,22 @@ __global__ __launch_bounds__(64) void k_softmax_gather(Dev D, const T *logits, c
     float *out = D.prior128 + (size_t)b * kMaxLegal;
     const float p0 = lane < k ? __expf(row[id0] - mx) / sum : 0.0f;
     const float p1 = 64 + lane < k ? __expf(row[id1] - mx) / sum : 0.0f;
-    if (lane < k) out[lane] = p0;
-    if (64 + lane < k) out[64 + lane] = p1;
     if (PLANNED) {
         const float v = vcompact[src];
+        if (D.cver[b]) {
+            // CCZ_FLAG_CACHE_VERIFY: this leaf HIT the table (the probe left the cached priors / value in prior128 / vleaf) and was
+            // sent through the evaluator all the same: the fresh numbers must be the cached ones, bit for bit
+            const bool d0 = lane < k && __float_as_uint(out[lane]) != __float_as_uint(p0);
+            const bool d1 = 64 + lane < k && __float_as_uint(out[64 + lane]) != __float_as_uint(p1);
+            const bool dv = __float_as_uint(D.vleaf[b]) != __float_as_uint(v);
+            const bool bad = __ballot(d0 || d1 || dv) != 0ull;
+            if (lane == 0) {
+                D.stats[b].cache_verified += 1u;
+                if (bad) D.stats[b].cache_mismatch += 1u;
+            }
+        }
+        if (lane < k) out[lane] = p0;
+        if (64 + lane < k) out[64 + lane] = p1;
         const uint32_t slot = D.cslot[b];
         if (lane == 0) {
             D.vleaf[b] = v;
@@ -598,10 +624,14 @@ __global__ __launch_bounds__(64) void k_softmax_gather(Dev D, const T *logits, c
         }
         if (D.cins[b]) { // the slot's claim winner stores its evaluation (nobody reads the table before the next launch)
             CacheEntry *e = D.cache + slot;
+            const uint32_t tag = cache_tag(id0, id1, k, lane);
             e->pri[lane] = p0;
             e->pri[64 + lane] = p1;
-            if (lane == 0) { e->v = v; e->k = (uint32_t)k; e->key = D.leaf_key[b]; D.stats[b].cache_stores += 1u; }
+            if (lane == 0) { e->v = v; e->k = tag; e->key = D.leaf_key[b]; D.stats[b].cache_stores += 1u; }
         }
+    } else {
+        if (lane < k) out[lane] = p0;
+        if (64 + lane < k) out[64 + lane] = p1;
     }
 }
 
@@ -624,20 +654,26 @@ __global__ __launch_bounds__(64) void k_cache_probe(Dev D)
     const uint64_t ekey = e->key;
     const uint32_t ek = e->k;
     const float ev = e->v, q0 = e->pri[lane], q1 = e->pri[64 + lane];
-    const bool hit = ekey == key && ek == (uint32_t)D.leaf_k[b];
+    const uint16_t *ids = D.leaf_ids + (size_t)b * kMaxLegal;
+    const uint32_t tag = cache_tag(ids[lane], ids[64 + lane], D.leaf_k[b], lane);
+    const bool hit = ekey == key && ek == tag;
     if (hit) {
         float *out = D.prior128 + (size_t)b * kMaxLegal;
         out[lane] = q0;
         out[64 + lane] = q1;
     }
+    // CCZ_FLAG_CACHE_VERIFY: one hit in 128 (chosen by the key, the board and the board's probe count) is ALSO planned as an evaluator row;
+    // k_softmax_gather compares its fresh priors / value with what the table just returned. It does not bid for the slot.
+    BoardStats &st = D.stats[b];
+    const bool verify = hit && (D.flags & 8u) && (mix64(key + 0x632BE59BD9B4E019ull * (uint64_t)st.cache_probes + 0xD1342543DE82EF95ull * (uint64_t)b) & 127ull) == 0ull;
     if (lane == 0) {
         D.cslot[b] = slot;
-        D.cstate[b] = hit ? 1 : 0;
+        D.cstate[b] = hit && !verify ? 1 : 0;
+        D.cver[b] = verify ? 1 : 0;
         if (hit) D.vleaf[b] = ev;
         else atomicMin(D.claim + slot, b);
-        BoardStats &st = D.stats[b];
         st.cache_probes += 1u;
-        if (hit) st.cache_hits += 1u;
+        if (hit && !verify) st.cache_hits += 1u;
     }
 }
 

@@ -32,11 +32,14 @@ class SelfPlayEngine:
                  device: int = 0, max_nodes: int = 0, max_depth: int = 0, max_plies: int = 0,
                  reference_quirks: bool = False, mirror: bool = True, reserve_nodes: int = 0,
                  move_rank="tools", plane_of_type="tools", value_f16: bool = False, type_rank="tools",
-                 pawn_move_resets_clock="tools", perpetual_check="tools", eval_cache_log2: int = 0):
+                 pawn_move_resets_clock="tools", perpetual_check="tools", eval_cache_log2: int = 0,
+                 cache_verify: bool = False):
         """``move_rank`` (uint16[2086] permutation, None = ascending id) and ``plane_of_type`` (8 entries, None = type-1)
         are the run-time rule tables of ``ccz_config`` (ABI 2); the default "tools" takes the process-wide choice of
         :func:`chinesechesszero_amd.tools.set_rules`. ``eval_cache_log2`` = n > 0: an evaluation cache of 2^n positions
-        (528 B each) for the planned evaluator boundary (:meth:`eval_plan`, ``include/cczero.h`` ccz_eval_plan)."""
+        (528 B each) for the planned evaluator boundary (:meth:`eval_plan`, ``include/cczero.h`` ccz_eval_plan);
+        ``cache_verify``: its debug mode (CCZ_FLAG_CACHE_VERIFY): one hit in 128 is evaluated again and compared bit for bit
+        (``stats()['cache_verified']`` / ``['cache_verify_mismatches']``)."""
         self.L = _lib.lib()
         if not torch.cuda.is_available():
             raise CczError("no GPU visible to PyTorch-ROCm; the engine has no CPU fallback")
@@ -44,7 +47,8 @@ class SelfPlayEngine:
         self.B = int(n_boards)
         self.n_playout = int(n_playout)
         flags = (_lib.FLAG_REFERENCE_QUIRKS if reference_quirks else 0) | (0 if mirror else _lib.FLAG_NO_MIRROR) \
-            | (_lib.FLAG_VALUE_F16 if value_f16 else 0)  # value_f16: Q accumulated in float16 as on the reference's CUDA path
+            | (_lib.FLAG_VALUE_F16 if value_f16 else 0) | (_lib.FLAG_CACHE_VERIFY if cache_verify else 0)
+        # value_f16: Q accumulated in float16 as on the reference's CUDA path
         self.mirror = mirror
         self.reference_quirks = bool(reference_quirks)
         self.max_plies = int(max_plies) if int(max_plies) > 0 else 2048  # recorded plies per game (ccz_config.max_plies)
@@ -175,6 +179,10 @@ class SelfPlayEngine:
         f16 = self._check_logits(logits, value)
         check(self.L.ccz_gather_priors(self.h, self._stream(), _ptr(logits), f16))
 
+    def expand_backup_compact(self, value: torch.Tensor | None):
+        """``value`` None: the engine-owned leaf values of the planned boundary."""
+        check(self.L.ccz_expand_backup_compact(self.h, self._stream(), _ptr(value)))
+
     def step_compact(self, value: torch.Tensor | None) -> torch.Tensor:
         """``value`` None: the engine-owned leaf values of the planned boundary (:meth:`gather_priors_planned`)."""
         check(self.L.ccz_step_compact(self.h, self._stream(), _ptr(value), _ptr(self.leaf_input)))
@@ -258,6 +266,15 @@ class SelfPlayEngine:
         depth = np.zeros(B, np.int32)
         check(self.L.ccz_leaf_info(self.h, self._stream(), _ptr(status), _ptr(k), _ptr(ids), _ptr(depth)))
         return {"status": status, "k": k, "ids": ids, "depth": depth}
+
+    def leaf_priors(self, values: bool = True):
+        """What the compact / planned boundary hands the tree for the pending leaves, after ``gather_priors[_planned]``:
+        ``(prior float32 [B,128] aligned with leaf_info()['ids'], value float32 [B] or None)``; ``values`` needs an evaluation
+        cache (engine-owned leaf values). Syncs (tests)."""
+        pri = np.zeros((self.B, MAX_LEGAL), np.float32)
+        val = np.zeros(self.B, np.float32) if values else None
+        check(self.L.ccz_leaf_priors(self.h, self._stream(), _ptr(pri), _ptr(val)))
+        return pri, val
 
     def leaf_keys(self):
         """(keys int64 [B], status uint8 [B]) of the pending leaves as device tensors (no sync): equal keys = equal evaluator

@@ -81,7 +81,10 @@ class BatchedSelfPlay:
 
     def __init__(self, evaluator, n_boards: int, n_playout: int = 400, c_puct: float = C_PUCT, eps: float = EPS,
                  alpha: float = ALPHA, temp: float = 1.0, seed: int = 0, board_id_base: int = 0, device: int = 0,
-                 sampling: str = "device", use_graph: bool = False, **engine_kw):
+                 sampling: str = "device", use_graph: bool = False, version_fn=None, **engine_kw):
+        """``version_fn() -> hashable``: what tells the evaluation cache (and a captured hipGraph) that the evaluator's weights
+        changed; default: ``weights_version`` of the evaluator's owner. An evaluator that accepts a plan but exposes neither is
+        refused: its cached evaluations could never be invalidated."""
         if sampling not in ("device", "numpy"):
             raise ValueError("sampling must be 'device' (Philox on the GPU) or 'numpy' (reference-exact host RNG)")
         self.evaluator = evaluator
@@ -100,9 +103,21 @@ class BatchedSelfPlay:
         # the network again (include/cczero.h ccz_eval_plan). Same results, bit for bit.
         self.planned = bool(self.engine.eval_cache_log2 > 0 and getattr(evaluator, "accepts_plan", False)
                             and getattr(evaluator, "returns_logits", False))
+        self.version_fn = version_fn
+        if self.planned and version_fn is None and not hasattr(getattr(evaluator, "__self__", None), "weights_version") \
+                and not getattr(evaluator, "stateless", False):
+            raise ValueError("planned evaluator boundary (evaluation cache) with an evaluator that exposes no weights_version: "
+                             "pass version_fn=... (what changes when its weights do), mark it `stateless = True`, or use eval_cache_log2=0")
         self._cache_version = self._evaluator_version()
+        self._sim = 0        # simulations done of the current move
+        self._leaf = None    # the pending leaf batch (None: the next simulation starts with select_leaves)
+        self._acc = 0
 
     def _evaluator_version(self):
+        """What tells the evaluation cache that the evaluator's weights changed: ``version_fn()`` if one was given, else the
+        ``weights_version`` of the object the evaluator is a bound method of (``PolicyValueNet``)."""
+        if self.version_fn is not None:
+            return self.version_fn()
         return getattr(getattr(self.evaluator, "__self__", None), "weights_version", None)
 
     def _planned_eval(self, leaf):
@@ -124,40 +139,74 @@ class BatchedSelfPlay:
         prob, value = self.evaluator(leaf)
         (e.expand_backup_logits if getattr(self.evaluator, "returns_logits", False) else e.expand_backup)(prob, value)
 
-    def run_move(self, on_playout=None):
-        """n_playout simulations then one move on every board. Returns the moves (device int32 [B]).
+    def advance(self, steps: int, hooks=None, boundary=None, on_playout=None):
+        """``steps`` lockstep simulations of every board from wherever the search stands in its move; a move that completes on the
+        way (simulation ``n_playout``) is played: ``boundary()`` if given (it must call :meth:`finish_move` itself -- bench.py wraps
+        the harvest / exchange and its timers around it), else :meth:`finish_move`. Returns the moves of the last move played in
+        this call (device int32 [B]) or None.
 
-        Launch sequence: select, (evaluator, fused step) x (n-1), evaluator, expand_backup."""
+        Launch sequence of a move: select, (evaluator, fused step) x (n-1), evaluator, expand_backup -- with an evaluation cache:
+        (probe + plan, evaluator on the planned rows, softmax + gather + store, fused step).
+        ``hooks(stage, sim)`` -- stage "eval0" / "eval1" / "step1" = before the evaluator, between evaluator and simulator
+        kernel, after the simulator kernel of simulation index ``sim`` (0-based within its move): where bench.py records its HIP
+        events and triggers the concurrent trainer. THE loop: ``run_move``, the bench, the soak and the tests all run this one."""
         e = self.engine
-        interval = max(1, self.n_playout // 100)
-        acc = 0
-        leaf = e.select_leaves()
-        if self.use_graph and self._graph is None and not self.planned:
-            self._graph = GraphedStep(e, self.evaluator)
+        n = self.n_playout
         logits = getattr(self.evaluator, "returns_logits", False)
-        step = e.step_logits if logits else e.step
-        last = e.expand_backup_logits if logits else e.expand_backup
-        for i in range(self.n_playout):
-            if self.planned:
-                if i + 1 < self.n_playout:
-                    leaf = e.step_planned(*self._planned_eval(leaf))
-                else:
-                    e.expand_backup_planned(*self._planned_eval(leaf))
-            elif i + 1 < self.n_playout:
-                if self._graph is not None:
-                    self._graph.replay()
-                else:
-                    leaf = step(*self.evaluator(leaf))
+        interval = max(1, n // 100)
+        moves = None
+        for _ in range(int(steps)):
+            i = self._sim
+            last = i + 1 == n
+            if self._leaf is None:
+                self._leaf = e.select_leaves()
+                if self.use_graph and self._graph is None and not self.planned:
+                    self._graph = GraphedStep(e, self.evaluator, version_fn=self.version_fn)
+            if hooks is not None:
+                hooks("eval0", i)
+            if self._graph is not None and not last and hooks is None:
+                self._graph.replay()   # evaluator + fused step as one captured graph (launch-bound small batches)
             else:
-                last(*self.evaluator(leaf))
-            acc += 1
-            if on_playout is not None and (acc >= interval or i == self.n_playout - 1):
+                if self.planned:   # cache probe + plan, the network on the planned rows only, softmax + gather + cache store
+                    e.gather_priors_planned(*self._planned_eval(self._leaf))
+                    value = None   # step / expand_backup then use the engine-owned leaf values (hits and fresh evaluations alike)
+                else:
+                    prob, value = self.evaluator(self._leaf)
+                    if logits:     # the softmax + gather of the legal priors belongs to the evaluator side of the split
+                        e.gather_priors(prob, value)
+                if hooks is not None:
+                    hooks("eval1", i)
+                if last:
+                    e.expand_backup_compact(value) if (logits or self.planned) else e.expand_backup(prob, value)
+                    self._leaf = None
+                else:
+                    self._leaf = e.step_compact(value) if (logits or self.planned) else e.step(prob, value)
+            if hooks is not None:
+                hooks("step1", i)
+            self._sim = 0 if last else i + 1
+            self._acc += 1
+            if on_playout is not None and (self._acc >= interval or last):
                 try:
-                    on_playout(acc)  # mcts.py:153-160
+                    on_playout(self._acc)  # mcts.py:153-160
                 except Exception:
                     pass
-                acc = 0
-        return self.finish_move()
+                self._acc = 0
+            if last:
+                self._acc = 0
+                moves = boundary() if boundary is not None else self.finish_move()
+        return moves
+
+    def search(self, on_playout=None, hooks=None):
+        """The simulations that are left of the current move (all ``n_playout`` from a move's start) WITHOUT playing it: the roots
+        can be read (``engine.root_children()``) before :meth:`finish_move`."""
+        left = self.n_playout - self._sim
+        if left > 1:
+            self.advance(left - 1, hooks=hooks, on_playout=on_playout)
+        self.advance(1, hooks=hooks, on_playout=on_playout, boundary=lambda: None)
+
+    def run_move(self, on_playout=None):
+        """n_playout simulations then one move on every board. Returns the moves (device int32 [B])."""
+        return self.advance(self.n_playout - self._sim, on_playout=on_playout)
 
     def watch(self, board_index: int, viewer):
         """Show ONE selected board of the batch in a viewer window (``frontend.ChessWindow`` or anything with
@@ -177,6 +226,7 @@ class BatchedSelfPlay:
                             + (" - game over" if st["over"][b] else ""))
 
     def finish_move(self):
+        self._sim, self._leaf, self._acc = 0, None, 0   # whatever leaf was pending belongs to the old root
         moves = self._finish_move()
         if getattr(self, "_watch", None) is not None:
             self._show(moves)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define CCZ_ABI_VERSION 4
+#define CCZ_ABI_VERSION 5
 #define CCZ_NSQ 90
 #define CCZ_SQ_STRIDE 96            /* mailbox row stride in bytes (90 squares + 6 pad)         */
 #define CCZ_NMOVES 2086             /* action space, reference tools.py:172-272                 */
@@ -70,6 +70,11 @@ extern "C" {
                                         (mcts.py:63-71 under NEP 50). With this flag the leaf value is rounded to float16
                                         and every operation of the incremental mean rounds to float16; default (off) is
                                         the float32 arithmetic of the reference's CPU path                              */
+
+#define CCZ_FLAG_CACHE_VERIFY 8u     /* debug mode of the evaluation cache (ABI 5): one table hit in 128 is sent through the evaluator
+                                        again and its fresh priors / value are compared, bit for bit, with what the table
+                                        returned (ccz_stats.cache_verified / cache_verify_mismatches). Results are unchanged;
+                                        the evaluator computes ~0.8 % of the hits again. Needs eval_cache_log2 > 0           */
 
 /* leaf status written by ccz_select_leaves */
 #define CCZ_LEAF_EXPAND 0 /* non-terminal: children are created from the evaluator's priors */
@@ -139,6 +144,10 @@ typedef struct ccz_stats {
     int64_t cache_hits;        /* ... served from the cache                                       */
     int64_t cache_shared_rows; /* ... served by the evaluator row of another board of the same step (same position) */
     int64_t cache_stores;      /* entries written                                                 */
+    /* CCZ_FLAG_CACHE_VERIFY (ABI 5; zero without it) */
+    int64_t cache_verified;          /* table hits that were evaluated again                        */
+    int64_t cache_verify_mismatches; /* ... whose fresh priors or value differ from the cached ones: must stay 0 (a colliding
+                                        position, a non-deterministic evaluator, or weights changed without ccz_eval_cache_clear) */
 } ccz_stats;
 
 #define CCZ_ERR_NODE_POOL 1   /* a board ran out of tree nodes (raise max_nodes)                 */
@@ -212,7 +221,10 @@ int ccz_expand_backup_compact(ccz_engine *e, void *stream, const float *value_de
  * reference evaluates every leaf on its own (mcts.py:114); here a position that was evaluated before -- by this board (a
  * transposition), by another board (every restarted game walks through openings that earlier games searched), or by another
  * board in this very step -- is not sent through the network again. Results are unchanged bit for bit as long as the evaluator is
- * a deterministic function of the position that does not depend on the row it sits in (tests/test_gpu_evaluator_depth.py).
+ * a deterministic function of the position that does not depend on the row it sits in (tests/test_gpu_evaluator_depth.py) --
+ * up to key collisions: a hit needs the 64-bit key, the number of legal moves AND a 24-bit hash of the legal-move list (in the
+ * order the priors are stored in) to agree, so a foreign position is served with probability < 2^-64 per probe (about 1e-9 per
+ * day at 2 x 10^5 probes a second); CCZ_FLAG_CACHE_VERIFY re-evaluates a sample of the hits and counts disagreements.
  *   ccz_eval_plan: probes the direct-mapped table (2^n entries: key, value, the priors of the legal moves) for every pending
  *     leaf that needs an evaluation; hits receive their priors and value at once. The misses are deduplicated (boards with the
  *     same key share one row) and compacted: miss_rows_dev int32 [B] receives the board index of every row the evaluator has to
@@ -265,6 +277,14 @@ int ccz_root_positions(ccz_engine *e, void *stream, uint8_t *sq_host);
  * ids uint16[B*128], depth int32[B]; any pointer may be NULL. */
 int ccz_leaf_info(ccz_engine *e, void *stream, uint8_t *status_host, int32_t *k_host,
                   uint16_t *ids_host, int32_t *depth_host);
+
+/* What the compact / planned evaluator boundary hands the tree for the pending leaves, AFTER ccz_gather_priors[_planned] and
+ * before ccz_step_compact / ccz_expand_backup_compact consume it (syncs; tests): prior_host float [B*128] = the engine-owned
+ * prior rows, entry i of board b belongs to the i-th id of ccz_leaf_info (entries past k and rows of terminal leaves are
+ * unspecified); value_host float [B] = the engine-owned leaf values of the planned boundary (table hits and fresh evaluations
+ * alike; only with an evaluation cache, else pass NULL). Either may be NULL. This is the `(act_probs, leaf_value)` pair of
+ * mcts.py:114 as the tree will see it: a sequential oracle fed these numbers must grow the same tree. */
+int ccz_leaf_priors(ccz_engine *e, void *stream, float *prior_host, float *value_host);
 
 /* Zobrist keys (pieces + side to move: everything the evaluator input of net.py:160-173 depends on) and CCZ_LEAF_* status of
  * the pending leaves, copied device-to-device on `stream` (no sync): keys_dev uint64 [B], status_dev uint8 [B], either may be

@@ -170,6 +170,27 @@ class SampleMirror:
             self.mcts[j].expand_backup(leaf, ids, P[j][ids], V[j])
         self.steps += 1
 
+    def backup_on_oracles_compact(self, prior128, value, check=True):
+        """The compact / planned evaluator boundary: ``prior128`` float32 [B,128] and ``value`` float32 [B] are what
+        ``engine.leaf_priors()`` returned AFTER ``gather_priors[_planned]`` -- the numbers the tree is about to consume, whether they
+        came from the evaluator's row of this board, from another board's row (a duplicate leaf of the same step) or from the
+        evaluation cache. Entry i of a row belongs to the i-th legal id. Call before ``step_compact`` / ``expand_backup_compact``."""
+        e = self.e
+        info = e.leaf_info() if (check and self.steps % self.check_every == 0) else None
+        status = info["status"] if info is not None else e.leaf_info()["status"]
+        for j, b in enumerate(self.sample):
+            if status[b] == 3:      # finished board: no pending leaf on the engine, nothing to follow
+                continue
+            leaf, depth = self.mcts[j].select(self.boards[j])
+            ids = leaf.legal_ids()
+            if info is not None:
+                assert depth == info["depth"][b] and info["k"][b] == len(ids), (b, depth, info["depth"][b])
+                assert info["ids"][b][:len(ids)].tolist() == ids, b
+                end, tie = leaf.is_game_over(), leaf.is_tie()
+                assert info["status"][b] == (0 if (not end and not tie) else (1 if (end and tie) else 2)), b
+            self.mcts[j].expand_backup(leaf, ids, prior128[b][:len(ids)], value[b])
+        self.steps += 1
+
     def compare_roots(self, rc=None):
         rc = self.e.root_children() if rc is None else rc
         for j, b in enumerate(self.sample):
@@ -182,6 +203,13 @@ class SampleMirror:
             assert np.array_equal(rc["prior"][b][:k].view(np.uint32), prior.view(np.uint32)), b
             assert rc["root_visits"][b] == self.mcts[j].root_visits(), b
         return rc
+
+    def restarted(self, mask):
+        """The engine restarted the boards whose mask byte is set (``engine.reset(mask)``): fresh game, fresh tree."""
+        for j, b in enumerate(self.sample):
+            if mask[b]:
+                self.boards[j] = OracleBoard()
+                self.mcts[j].update_with_move(-1)
 
     def played(self, moves, keep_tree=True):
         """The engine played ``moves`` (int array [B], -1 = none): follow on the oracles."""

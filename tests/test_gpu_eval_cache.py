@@ -15,6 +15,7 @@ class LogitsEvaluator:
     batched = True
     returns_logits = True
     accepts_plan = True
+    stateless = True   # fixed weights: nothing can invalidate a cached evaluation
 
     def __init__(self, device, seed=0, sharp=6.0):
         g = torch.Generator(device="cpu").manual_seed(seed)
