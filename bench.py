@@ -70,6 +70,13 @@ def parse():
     ap.add_argument("--warm-moves", type=int, default=2, help="untimed setup: full moves searched with the real evaluator before the "
                     "alignment steps, so that the timed window sees the evaluation cache as continuous self-play leaves it (restarted "
                     "games walking through openings that earlier games searched) instead of a cold table; 0 = none")
+    ap.add_argument("--ring-ranks", choices=["auto", "all", "0"], default="auto", help="N>1: which ranks expand the gathered records into a dense "
+                    "replay ring in their HBM: all (every rank may sample the union), 0 (rank 0 only: the trainer's rank); auto = 0 when a "
+                    "trainer runs (--train-every), all otherwise")
+    ap.add_argument("--dist-timeout", type=int, default=180, help="N>1: seconds a collective may wait for a peer before the job fails")
+    ap.add_argument("--cache-verify", action="store_true", help="evaluation cache debug mode (CCZ_FLAG_CACHE_VERIFY): one table hit in 128 is "
+                    "evaluated again and compared bit for bit; the count of mismatches is in the line")
+    ap.add_argument("--inject-fault", default="", help="testing: RANK:STEP raises on that rank at that timed step (the fail-fast path)")
     ap.add_argument("--value-f16", action="store_true", help="accumulate Q in float16 as the reference's CUDA path does (CCZ_FLAG_VALUE_F16, "
                     "net.py:178-189 -> mcts.py:63-71); default: float32, its CPU path")
     return ap.parse_args()
@@ -90,8 +97,9 @@ def host_cores() -> int:
 
 def cpu_baseline(seconds: float, blocks: int, channels: int):
     """Oracle leg: BASELINE config[0] restated -- ONE game, strictly sequential PUCT (oracle/xq_mcts.c,
-    restating mcts.py), n_playout=200, batch-1 reference-architecture net on the host CPU in fp32."""
-    import oracle
+    restating mcts.py), n_playout=200, batch-1 reference-architecture net on the host CPU in fp32 -- with the time split
+    net / rules / tree BASELINE.md section 3 promised, and the same loop with a constant-time stub evaluator (the non-net part
+    on its own). 80 % of the budget goes to the net leg, 20 % to the stub leg."""
     from oracle import OracleBoard, OracleMCTS
     from chinesechesszero_amd.net import Net
 
@@ -100,64 +108,70 @@ def cpu_baseline(seconds: float, blocks: int, channels: int):
     cores = host_cores()
     torch.set_num_threads(cores)
     t_net = [0.0]
+    t_enc = [0.0]
 
-    def evaluator(board, ids):
-        x = torch.from_numpy(board.leaf_planes()[None])
+    def net_evaluator(board, ids):
         t0 = time.perf_counter()
+        x = torch.from_numpy(board.leaf_planes()[None])   # decode_board + the 17 plane groups (tools.py:74-106, net.py:160-177)
+        t1 = time.perf_counter()
         with torch.no_grad():
             logp, v = net(x)
-        t_net[0] += time.perf_counter() - t0
         p = np.exp(logp.numpy().reshape(-1))
+        t_enc[0] += t1 - t0
+        t_net[0] += time.perf_counter() - t1
         return p[ids], v.numpy().reshape(-1)[0]
 
-    board = OracleBoard()
-    mcts = OracleMCTS(evaluator, c_puct=5, n_playout=200)
-    rs = np.random.RandomState(0)
-    sims = moves = 0
-    t0 = time.perf_counter()
-    deadline = t0 + seconds
-    while time.perf_counter() < deadline and not board.is_game_over():
-        done_move = True
-        for _ in range(200):
-            mcts.playout(board)
-            sims += 1
-            if time.perf_counter() >= deadline:
-                done_move = False
+    def stub_evaluator(board, ids):
+        return np.full(len(ids), 1.0 / 2086, np.float32), 0.0
+
+    def leg(evaluator, budget):
+        board = OracleBoard()
+        mcts = OracleMCTS(evaluator, c_puct=5, n_playout=200)
+        mcts.set_timing(True)
+        rs = np.random.RandomState(0)
+        sims = moves = 0
+        t0 = time.perf_counter()
+        deadline = t0 + budget
+        while time.perf_counter() < deadline and not board.is_game_over():
+            done_move = True
+            for _ in range(200):
+                mcts.playout(board)
+                sims += 1
+                if time.perf_counter() >= deadline:
+                    done_move = False
+                    break
+            if not done_move:
                 break
-        if not done_move:
-            break
-        acts, visits, _, _ = mcts.root_children()
-        temp = 1.0
-        x = 1.0 / temp * np.log(visits.astype(np.int64) + 1e-10)
-        pr = np.exp(x - x.max())
-        pr /= pr.sum()
-        move = int(rs.choice(acts, p=0.75 * pr + 0.25 * rs.dirichlet(0.2 * np.ones(len(pr)))))
-        mcts.update_with_move(move)
-        board.push_id(move)
-        moves += 1
-    dt = time.perf_counter() - t0
+            acts, visits, _, _ = mcts.root_children()
+            temp = 1.0
+            x = 1.0 / temp * np.log(visits.astype(np.int64) + 1e-10)
+            pr = np.exp(x - x.max())
+            pr /= pr.sum()
+            move = int(rs.choice(acts, p=0.75 * pr + 0.25 * rs.dirichlet(0.2 * np.ones(len(pr)))))
+            mcts.update_with_move(move)
+            board.push_id(move)
+            moves += 1
+        dt = time.perf_counter() - t0
+        rules_s, tree_s = mcts.timers()
+        return sims, moves, dt, rules_s, tree_s
+
+    sims, moves, dt, rules_s, tree_s = leg(net_evaluator, 0.8 * seconds)
+    rules_s += t_enc[0]                                   # the leaf encoding is rules-side work (tools.decode_board)
+    other = max(0.0, dt - t_net[0] - rules_s - tree_s)    # Python glue: ctypes callback, array conversions, move choice
+    s_sims, s_moves, s_dt, s_rules, s_tree = leg(stub_evaluator, 0.2 * seconds)
     return {"value": sims / dt, "unit": "sims/s", "cores": cores, "kind": "port",
             "sample": f"{sims} sequential playouts ({moves} full moves) of one self-play game, n_playout=200, "
                       f"batch-1 {blocks}x{channels} net fp32 on CPU, {dt:.1f} s; net share {t_net[0] / dt:.2f}",
-            "moves_per_sec": moves / dt if moves else sims / dt / 200.0}
-
-
-def self_launch(n: int) -> int:
-    """``python bench.py --gpus N`` without a launcher: run ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N
-    bench.py <the same arguments>`` as a CHILD process (one rank per GPU over RCCL) and return its exit code. Called before
-    anything has initialised the GPU in this process, which only waits; rank 0's JSON line goes to the inherited stdout.
-    (Never an exec: replacing a process is refused on the GPU boxes, and a child keeps the exit code honest.)"""
-    import socket
-    import subprocess
-    with socket.socket() as s:  # a free rendezvous port on the loopback
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's intra-node transport needs it on these hosts
-    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
-    return subprocess.call(cmd, env=env)
+            "moves_per_sec": moves / dt if moves else sims / dt / 200.0,
+            # where a CPU playout spends its time (C rules and tree of the oracle: an OPTIMISTIC stand-in for
+            # the reference's pure-Python cchess + mcts.py; the net is the reference's architecture on the same threads)
+            "split": {"net": t_net[0] / dt, "rules": rules_s / dt, "tree": tree_s / dt, "python_glue": other / dt,
+                      "ms_per_playout": {"net": 1e3 * t_net[0] / max(1, sims), "rules": 1e3 * rules_s / max(1, sims),
+                                         "tree": 1e3 * tree_s / max(1, sims)}},
+            "stub": {"value": s_sims / s_dt, "unit": "sims/s", "what": "the same sequential loop with a constant-time evaluator "
+                     "(uniform priors, v = 0): rules + tree + Python callback glue only",
+                     "sample": f"{s_sims} playouts ({s_moves} moves), {s_dt:.1f} s",
+                     "split": {"rules": s_rules / s_dt, "tree": s_tree / s_dt, "python_glue": max(0.0, s_dt - s_rules - s_tree) / s_dt}}}
 
 
 def preroll(e, plies: int, stagger: bool):
@@ -191,28 +205,29 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from chinesechesszero_amd import launch   # (touches no GPU)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # plain `python bench.py --gpus N`: start the N ranks ourselves (a child process; nothing has touched the GPU yet)
-        raise SystemExit(self_launch(a.gpus))
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (a child process; nothing has touched the GPU yet). A node
+        # with fewer GPUs than ranks is refused here, in one line, before any rank exists.
+        raise SystemExit(launch.self_launch(__file__, a.gpus, sys.argv[1:], share_gpu=a.share_gpu, cores=host_cores()))
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    if a.share_gpu:
+        local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: cuda:{local_rank} does not exist ({torch.cuda.device_count()} device(s) visible): --gpus {a.gpus} needs one GPU per rank")
     if world > 1:  # every rank runs MIOpen's find step: keep their user perf-db / kernel caches apart
         os.environ.setdefault("MIOPEN_USER_DB_PATH", f"/tmp/cczero_miopen_rank{rank}")
         os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", f"/tmp/cczero_miopen_rank{rank}/cache")
         os.makedirs(os.environ["MIOPEN_CUSTOM_CACHE_DIR"], exist_ok=True)
     import torch.distributed as dist
-    if a.share_gpu:
-        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(a.backend)
+        # 180 s, not torch's 10 minutes: a rank that dies mid-window must not keep its peers in the all-gather for long
+        launch.init_distributed(a.backend, dev, timeout_s=a.dist_timeout)
     xdev = dev if a.backend == "nccl" else torch.device("cpu")  # where the exchange buffers live
 
     from chinesechesszero_amd.net import PolicyValueNet, uniform_evaluator
@@ -229,13 +244,16 @@ def main():
         evaluator = uniform_evaluator
     sp = BatchedSelfPlay(evaluator, B, n_playout=n, seed=0, board_id_base=rank * B, device=local_rank,
                          sampling="device", max_plies=a.max_plies, value_f16=a.value_f16,
-                         eval_cache_log2=a.eval_cache_log2 if a.evaluator == "net" else 0)
+                         eval_cache_log2=a.eval_cache_log2 if a.evaluator == "net" else 0, cache_verify=a.cache_verify)
     e = sp.engine
-    planned = [sp.planned]
     gather = RecordGatherer(max(a.gather_plies, e.max_plies), xdev) if world > 1 else None
-    # the "shared replay buffer" of BASELINE configs[3]: every rank keeps the union of all ranks' rows as a dense ring in
-    # its own HBM; finished games arrive as compact records and are expanded straight into the ring (ccz_expand_records)
-    rb = ReplayBuffer(a.replay_rows or 40000 * world, dev) if (world > 1 or a.train_every > 0) else None
+    # the "shared replay buffer" of BASELINE configs[3]: the union of all ranks' rows as a dense ring in HBM; finished games
+    # arrive as compact records and are expanded straight into the ring (ccz_expand_records) -- on the ranks that CONSUME it:
+    # every rank without a trainer ("all": any rank may sample), rank 0 only when a trainer runs there (configs[4]: the other
+    # ranks would write 8 x 28 k rows x 29,768 B = 6.8 GB per move into rings nobody reads)
+    ring_ranks = a.ring_ranks if a.ring_ranks != "auto" else ("0" if a.train_every > 0 else "all")
+    has_ring = (world > 1 or a.train_every > 0) and (ring_ranks == "all" or rank == 0)
+    rb = ReplayBuffer(a.replay_rows or 40000 * world, dev) if has_ring else None
     bad_records = torch.zeros(1, dtype=torch.int32, device=dev)
 
     trainer = None
@@ -258,10 +276,13 @@ def main():
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     boundary = {"events": [], "host_s": 0.0, "n": 0, "rows": 0, "rows_local": 0, "games": 0, "gather_s": 0.0, "collectives": 0, "expand_s": 0.0}
+    timing = [False]
+    step_no = [0]
 
-    def per_move(timed):
+    def per_move():
         """The move boundary: pi + Dirichlet-mixed choice + re-root + push + game end (k_finish_move, k_flip_half), tuple
         harvest of the games that ended (k_harvest) with restart, and for N > 1 the all-gather of those rows."""
+        timed = timing[0]
         if timed:
             # the launch loop runs ahead of the GPU; the boundary's first host read would wait for the queued steps anyway:
             # drain them here so that the boundary's own wall time is what gets measured (no extra wait in total)
@@ -270,7 +291,7 @@ def main():
         if timed:
             m0, m1 = ev(), ev()
             m0.record()
-        sp.finish_move()
+        moves = sp.finish_move()
         st = e.game_status()
         done = int(st["over"].sum())
         if gather is None:
@@ -285,10 +306,13 @@ def main():
             rows = loc = 0
             for union, games in exchange_finished_games(sp, gather, done):   # k_harvest_records + ONE collective per iteration
                 g1 = time.perf_counter()
-                if trainer is not None:
-                    torch.cuda.current_stream(dev).wait_event(side_done)  # the trainer's gather reads must not race the append
-                # every rank rebuilds the dense rows of ALL ranks' games in its replay ring (k_expand_records, asynchronous)
-                rows += rb.append_records(union.to(dev, non_blocking=True), e.record_flags(), e.plane_of_type, bad=bad_records)
+                if rb is not None:
+                    if trainer is not None:
+                        torch.cuda.current_stream(dev).wait_event(side_done)  # the trainer's gather reads must not race the append
+                    # the dense rows of ALL ranks' games rebuilt in this rank's replay ring (k_expand_records, asynchronous)
+                    rows += rb.append_records(union.to(dev, non_blocking=True), e.record_flags(), e.plane_of_type, bad=bad_records)
+                else:
+                    rows += (2 if e.mirror else 1) * int(union.shape[0])   # received, not expanded: this rank consumes no rows
                 if timed:
                     boundary["gather_s"] += gather.seconds
                     boundary["collectives"] += gather.collectives
@@ -305,60 +329,44 @@ def main():
             boundary["rows_local"] += loc
             if gather is None:
                 boundary["games"] += done
+        return moves
 
-    logits_in = bool(getattr(evaluator, "returns_logits", False))
-    import ctypes as _C
-    from chinesechesszero_amd._lib import check as check_rc
-    ptr_of = lambda t: _C.c_void_p(t.data_ptr())
-    step_no = [0]
-    state = {"leaf": None}
-    trace = []
+    pairs, trace, cur = [], [], {}
+
+    def hooks(stage, i):
+        """HIP events around the evaluator side and the simulator kernel of every timed step (on the stream they are launched
+        on), the step counter, the concurrent trainer's cadence and the fault injection of the fail-fast test."""
+        if stage == "eval0":
+            if timing[0]:
+                cur["e"] = (ev(), ev(), ev())
+                cur["e"][0].record()
+            return
+        if stage == "eval1":
+            if timing[0]:
+                cur["e"][1].record()
+            return
+        if timing[0]:
+            e0, e1, e2 = cur["e"]
+            e2.record()
+            if i + 1 < n:
+                pairs.append((e0, e1, e2))
+            trace.append((i, e0, e2))
+            if a.inject_fault and a.inject_fault == f"{rank}:{len(trace)}":
+                raise RuntimeError(f"injected fault on rank {rank} at timed step {len(trace)} (--inject-fault)")
+        step_no[0] += 1
+        if trainer is not None and step_no[0] % a.train_every == 0:
+            side.wait_stream(torch.cuda.current_stream(dev))  # replay-buffer appends (main stream) happen before the sample
+            with torch.cuda.stream(side):
+                trainer.step(*rb.sample(2048), sync=False)
+                side_done.record(side)
+            train_steps[0] += 1 if timing[0] else 0  # updates inside the timed window
 
     def run(steps, timed):
-        """steps x [evaluator -> fused k_step (expand+backup of this leaf, select of the next)]; a move boundary
-        flushes with expand_backup, plays the move and re-selects."""
-        pairs = []
-        for _ in range(steps):
-            if state["leaf"] is None:
-                state["leaf"] = e.select_leaves()
-            last_of_move = (step_no[0] + 1) % n == 0
-            if timed:
-                e0, e1, e2 = ev(), ev(), ev()
-                e0.record()
-            use_plan = planned[0] and logits_in
-            if use_plan:   # cache probe + plan, the network on the planned rows only, softmax + gather + cache store
-                prob, value = evaluator(state["leaf"], plan=e.eval_plan())
-                e.gather_priors_planned(prob, value)
-                value = None   # step / expand_backup then use the engine-owned leaf values (hits and fresh evaluations alike)
-            else:
-                prob, value = evaluator(state["leaf"])
-                if logits_in:  # the softmax+gather of the legal priors belongs to the evaluator side of the split
-                    e.gather_priors(prob, value)
-            if timed:
-                e1.record()
-            if last_of_move:
-                if logits_in:
-                    check_rc(e.L.ccz_expand_backup_compact(e.h, e._stream(), None if value is None else ptr_of(value)))
-                else:
-                    e.expand_backup(prob, value)
-                state["leaf"] = None
-            else:
-                state["leaf"] = e.step_compact(value) if logits_in else e.step(prob, value)
-            if timed:
-                e2.record()
-                if not last_of_move:
-                    pairs.append((e0, e1, e2))
-                trace.append((step_no[0] % n, e0, e2))
-            step_no[0] += 1
-            if trainer is not None and step_no[0] % a.train_every == 0:
-                side.wait_stream(torch.cuda.current_stream(dev))  # replay-buffer appends (main stream) happen before the sample
-                with torch.cuda.stream(side):
-                    trainer.step(*rb.sample(2048), sync=False)
-                    side_done.record(side)
-                train_steps[0] += 1 if timed else 0  # updates inside the timed window
-            if last_of_move:
-                per_move(timed)
-        return pairs
+        """``steps`` lockstep simulations through the PRODUCT's loop (BatchedSelfPlay.advance: evaluator -> fused k_step; a move
+        boundary flushes with expand_backup, plays the move, harvests and re-selects)."""
+        timing[0] = timed
+        sp.advance(steps, hooks=hooks, boundary=per_move)
+        timing[0] = False
 
     # ---- untimed setup: steady-state board states, trees warmed with the REAL evaluator up to the point where the
     # timed window starts, so that the K timed steps straddle a real move boundary of every board (the end of one
@@ -372,19 +380,13 @@ def main():
     half = min(a.steps, n) // 2
     phase = (n - half - a.warmup) % n if a.align else 0
     if a.align_evaluator == "stub" and a.evaluator == "net":
-        real, evaluator = evaluator, uniform_evaluator
-        logits_in = False
-        run(max(phase - 1, 0), False)   # the pending leaf of the stub phase is consumed through the dense entry point, and that
-        if phase > 0:                   # IS simulation number `phase`: both evaluators start the timed window on the same index
-            if state["leaf"] is None:
-                state["leaf"] = e.select_leaves()
-            e.expand_backup(*uniform_evaluator(state["leaf"]))
-            state["leaf"] = None
-            step_no[0] += 1
-        assert step_no[0] % n == phase
-        evaluator, logits_in = real, bool(getattr(real, "returns_logits", False))
+        real = (sp.evaluator, sp.planned)     # (the pending leaf does not care which evaluator answers it)
+        sp.evaluator, sp.planned = uniform_evaluator, False
+        run(phase, False)
+        sp.evaluator, sp.planned = real
     else:
         run(phase, False)
+    assert sp._sim == phase % n
     setup_s = time.perf_counter() - t_setup
 
     if gather is not None:  # one untimed exchange: communicator / channel set-up of the collective is not part of a move
@@ -392,35 +394,43 @@ def main():
     run(a.warmup, False)
     torch.cuda.synchronize()
     s0 = e.stats()
+    tower_probe = None
+    if a.evaluator == "net":
+        tower_probe = pvn._infer.tower_probe = []   # one HIP-event pair around the tower's 2 x blocks launches of every timed step
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pairs = run(a.steps, True)
+    run(a.steps, True)
     torch.cuda.synchronize()
     dt_local = time.perf_counter() - t0  # this rank's own time (the per-rank rates); the job's time is taken behind the barrier
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ranks_seen, per_rank = 1, None
+    if a.evaluator == "net":
+        pvn._infer.tower_probe = None
+    s1 = e.stats()
+    ranks_seen, per_rank, err_any, bad_total = 1, None, int(s1["error_flags"]), int(bad_records.item())
     if world > 1:
-        t = torch.zeros(world + 1, dtype=torch.float64, device=xdev)
+        t = torch.zeros(world + 4, dtype=torch.float64, device=xdev)
         t[0] = dt
         mx = t[:1].clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         t[0] = 0.0
         t[1 + rank] = B * a.steps / dt_local
-        cnt = torch.ones(1, dtype=torch.float64, device=xdev)
+        t[world + 1] = 1.0                                      # ranks that got here
+        t[world + 2] = float(bad_total)                         # records of cut games seen by the expansion, all ranks
+        t[world + 3] = 1.0 if s1["error_flags"] else 0.0        # ranks whose engine raised a sticky error bit
         dist.all_reduce(t)
-        dist.all_reduce(cnt)
         dt = float(mx.item())
-        ranks_seen = int(cnt.item())
-        per_rank = [float(v) for v in t[1:].tolist()]
-    s1 = e.stats()
+        ranks_seen = int(t[world + 1].item())
+        bad_total = int(t[world + 2].item())
+        err_any = int(t[world + 3].item())
+        per_rank = [float(v) for v in t[1:world + 1].tolist()]
     e.check_healthy()
     st_end = e.game_status()
-    # what a HIP-event pair reports around a trivial kernel on this stream (the floor included in avg_launch_us)
+    # what a HIP-event pair reports around a trivial kernel on this stream: the floor included in every per-kernel event figure
     tiny = torch.zeros(64, device=dev)
     fl = []
     for _ in range(64):
@@ -432,17 +442,20 @@ def main():
     torch.cuda.synchronize()
     event_floor_us = float(np.median([x.elapsed_time(y) for x, y in fl])) * 1e3
 
-    # the evaluator's dominant kernel (2 x blocks launches per step): the fused tower convolution, timed live on this stream
-    # over the whole tower on the activations of a real leaf batch (ReLU-sparse data clocks higher than dense random data)
+    sims = s1["sims"] - s0["sims"]
+    probes = s1["cache_probes"] - s0["cache_probes"]
+    planned = sp.planned
+    rows_per_step = ((probes - (s1["cache_hits"] - s0["cache_hits"]) - (s1["cache_shared_rows"] - s0["cache_shared_rows"])) / a.steps) if planned else float(B)
+
+    # the evaluator's dominant kernel (2 x blocks launches per step): the fused tower convolution. In the WINDOW: the HIP-event pair
+    # around the tower of every timed step over the rows those steps really computed; after it: a full-batch tower on the
+    # activations of a real leaf batch (what round 3 reported as the only figure)
     net_roofline = None
-    if a.evaluator == "net" and rank == 0 and a.channels == 256 and B >= 192 and os.environ.get("CCZ_FUSED_CONV", "1") != "0":
-        net_roofline = tower_roofline(a, pvn, e, state, B, ev)
+    if a.evaluator == "net" and rank == 0 and a.channels == 256 and B >= 192 and pvn._infer.opt_fused_conv():
+        net_roofline = tower_roofline(a, pvn, e, sp, B, ev, tower_probe, rows_per_step, 1e3 * dt / a.steps)
 
     if os.environ.get("CCZ_BENCH_TRACE") and rank == 0:  # per-step GPU time inside the timed window (diagnostics, stderr)
         print("trace: (simulation index within its move, ms) " + " ".join(f"{i}:{x.elapsed_time(y):.2f}" for i, x, y in trace[:4000]), file=sys.stderr)
-    sims = s1["sims"] - s0["sims"]
-    probes = s1["cache_probes"] - s0["cache_probes"]
-    rows_per_step = ((probes - (s1["cache_hits"] - s0["cache_hits"]) - (s1["cache_shared_rows"] - s0["cache_shared_rows"])) / a.steps) if planned[0] else float(B)
     exp = max(1, s1["expansions"] - s0["expansions"])
     kbar = (s1["sum_children"] - s0["sum_children"]) / exp
     dbar = (s1["sum_depth"] - s0["sum_depth"]) / max(1, sims)
@@ -461,7 +474,17 @@ def main():
         a_exp = (4 * kbar + 4) + 18 * kbar + 16 * (dbar + 1)
         a_step = a_sel + a_exp
         a_sim_survey = a_step - 3780 + 21420
-        ach = a_step * B / t_step if t_step == t_step else None
+        # roofline.frac / achieved: THIS run's algorithmic bytes over THIS run's k_step duration, measured live with HIP events
+        # around every k_step launch of the timed window on the stream it is launched on, minus the event floor measured the same
+        # way around a trivial kernel (an event pair costs ~10 us on a ~30 us kernel; the floor holds the trivial kernel's own
+        # ~2 us, so the net duration is if anything too short by that much). A k_step regression moves this number.
+        t_live = (t_step - event_floor_us * 1e-6) if t_step == t_step else None
+        if t_live is not None and t_live <= 0:
+            t_live = t_step
+        ach = a_step * B / t_live if t_live else 0.0
+        ach_raw = a_step * B / t_step if t_step == t_step else 0.0
+        # committed rocprofv3 profile of the same command: average k_step duration and PMC traffic, REPLAYED (never measured inside
+        # bench.py) and named as such; only when this run is the profiled workload
         traffic = traffic_source = rocprof_ns = pmc_window = None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
@@ -475,9 +498,6 @@ def main():
                     raise LookupError("the committed profile is of another workload")
                 ks = pm.get("k_step", {})
                 rocprof_ns = ks.get("avg_ns")
-                # NOT measured in this run: rocprofv3 PMC passes cannot run inside bench.py; these are the committed counters.
-                # `window` = the k_step launches of the PMC passes' own timed window, with the k-bar / d-bar / algorithmic bytes
-                # of THAT window next to them (same trees: the passes align with the real net, as this run does)
                 pmc_window = ks.get("window")
                 traffic = (pmc_window or {}).get("hbm_bytes_per_launch", ks.get("hbm_bytes_per_launch"))
                 traffic_source = f"profiles/pmc_summary.json ({pm.get('run', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, separate runs')}), replayed, not live"
@@ -487,12 +507,6 @@ def main():
                     net_roofline["traffic_source"] = traffic_source
             except Exception:
                 traffic = None
-        # roofline.frac: algorithmic bytes of THIS window over the kernel's duration. The duration HIP events report around one
-        # ~28 us kernel includes a ~10 us event floor (event_floor_us), so the headline fraction uses the rocprofv3 --kernel-trace
-        # --stats average of the same kernel and command (profiles/rNN_kernel_stats.csv -> pmc_summary.json, replayed); the
-        # live event figure stays beside it. Without a committed profile the event figure is all there is.
-        dur = rocprof_ns * 1e-9 if rocprof_ns else (t_step if t_step == t_step else None)
-        ach_rp = a_step * B / dur if dur else 0.0
         # the move boundary, measured: HIP events around finish_move + harvest/restart (+ exchange) and the host wall
         # around the same region (the harvest and the exchange read counts on the host)
         mb_ev = float(np.mean([x.elapsed_time(y) for x, y in boundary["events"]])) if boundary["events"] else None
@@ -505,7 +519,7 @@ def main():
         state_desc = (f"boards in steady state (plies 1..{a.preroll_plies} of their games, evenly; games adjudicated at {a.max_plies} plies)"
                       if a.preroll_plies > 0 else "all boards from the opening position")
         if a.evaluator == "net":
-            state_desc += f", {a.warm_moves} untimed moves searched before the window" + (f" (they warm the evaluation cache of 2^{e.eval_cache_log2} positions)" if planned[0] else "")
+            state_desc += f", {a.warm_moves} untimed moves searched before the window" + (f" (they warm the evaluation cache of 2^{e.eval_cache_log2} positions)" if planned else "")
         out = {
             "metric": "self-play MCTS simulations/sec", "value": value, "unit": "sims/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
@@ -527,14 +541,17 @@ def main():
                                       "k_harvest_records + restart + all-gather of the records + k_expand_records into the replay ring"),
                               "moves_per_sec_formula": "n_gpus * boards / (sims_per_move * (ms_per_step without the boundary) + ms_host)"},
             "roofline": {"bound": "hbm", "kernel": "k_step (fused expand+backup+select+movegen+encode)",
-                         "achieved": ach_rp / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach_rp / HBM_PEAK,
-                         "duration_source": ("rocprofv3 --kernel-trace --stats average of k_step (profiles/, replayed)" if rocprof_ns else "HIP events (live)"),
-                         "avg_launch_us": (dur or 0) * 1e6,
+                         "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
+                         "duration_source": "HIP events around every k_step launch of the timed window on its stream, minus event_floor_us (live)",
+                         "avg_launch_us": (t_live or 0) * 1e6,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": a_step * B, "k_bar": kbar, "d_bar": dbar,
-                         # the live measurement: HIP events around every k_step launch of the timed window on its stream
-                         "avg_launch_us_hip_events": t_step * 1e6, "event_floor_us": event_floor_us,
-                         "achieved_hip_events": (ach or 0) / 1e9, "frac_hip_events": (ach or 0) / HBM_PEAK,
+                         # the raw event figure (floor included) and the floor itself
+                         "avg_launch_us_hip_events_raw": t_step * 1e6, "event_floor_us": event_floor_us,
+                         "frac_hip_events_raw": ach_raw / HBM_PEAK,
+                         # cross-check, NOT this run: this run's bytes over the committed rocprofv3 --kernel-trace --stats average of k_step
+                         "avg_launch_us_committed_rocprofv3": (rocprof_ns * 1e-3 if rocprof_ns else None),
+                         "frac_at_committed_rocprofv3_duration": (a_step * B / (rocprof_ns * 1e-9) / HBM_PEAK if rocprof_ns else None),
                          # counters and algorithmic bytes of ONE pass (the PMC passes' own timed window): reproducible from profiles/
                          "pmc_window": pmc_window},
             "survey_a_sim_bytes": a_sim_survey,
@@ -549,35 +566,68 @@ def main():
                             "rows_computed_per_step": rows_per_step,
                             "fraction_of_needed_evaluations_skipped": 1.0 - rows_per_step * a.steps / max(1, probes),
                             "stores_total": s1["cache_stores"],
+                            "verify": ({"hits_evaluated_again": s1["cache_verified"], "mismatches": s1["cache_verify_mismatches"]} if a.cache_verify else None),
                             "what": "positions evaluated before (this board / another board / another board of the same step) skip the network; "
-                                    "visit counts unchanged bit for bit (tests/test_gpu_eval_cache.py)"} if planned[0] else None),
+                                    "the same trees bit for bit (tests/test_gpu_timed_path.py: cache on vs off at 4096 boards, oracle mirror through the planned boundary)"} if planned else None),
             "engine_hbm_gb": s1["hbm_bytes"] / 1e9, "nodes_peak": s1["nodes_peak"], "depth_peak": s1["depth_peak"],
+            "error_flags_any": err_any,
             "plies": {"start_mean": float(plies0.mean()), "start_max": int(plies0.max()), "end_mean": float(plies1.mean())},
             "setup_seconds": setup_s,
         }
         if world > 1:
             out["multi_gpu"] = {"world_size": world, "ranks_seen": ranks_seen, "backend": a.backend,
+                                "error_flags_any": err_any, "bad_records": bad_total,
                                 "per_rank_sims_per_sec": per_rank, "exchanges_in_window": boundary["n"],
                                 "collectives_in_window": boundary["collectives"], "rows_gathered": boundary["rows"],
                                 "gather_ms": 1e3 * boundary["gather_s"] / max(1, boundary["n"]),
                                 "expand_ms_host": 1e3 * boundary["expand_s"] / max(1, boundary["n"]),
                                 "wire_format": "compact ply records, 880 B per ply = 2 dense rows of 29,768 B (ccz_harvest_records -> "
-                                               "all_gather_into_tensor -> ccz_expand_records into every rank's replay ring)",
+                                               "all_gather_into_tensor -> ccz_expand_records into the replay ring of the ranks that consume rows)",
                                 "bytes_sent_per_rank_per_collective": gather.bytes_per_exchange(), "gather_capacity_plies": gather.cap,
                                 "payload_bytes_rank0_per_exchange": 880 * boundary["rows_local"] // (2 if e.mirror else 1) // max(1, boundary["n"]),
-                                "replay_ring_rows": rb.cap, "replay_rows_total": rb.total, "bad_records": int(bad_records.item())}
+                                "ring_ranks": ring_ranks, "replay_ring_rows": rb.cap if rb is not None else 0,
+                                "replay_rows_total": rb.total if rb is not None else 0,
+                                "dist_timeout_s": a.dist_timeout}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_seconds, a.blocks, a.channels)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
-def tower_roofline(a, pvn, e, state, B, ev):
-    import torch.nn.functional as F
+def tower_roofline(a, pvn, e, sp, B, ev, tower_probe, rows_per_step, ms_per_step):
+    """MFMA roofline of the tower convolution (2 x blocks launches per step).
+
+    ``frac`` / ``achieved`` / ``avg_launch_us`` describe the TIMED WINDOW: the HIP-event pair around the tower of every timed
+    step (on the stream its launch chains fork from and join), divided by its 2 x blocks layers, against the algorithmic flops of
+    the rows those steps really computed (the evaluation cache and terminal leaves remove rows). ``*_full_batch`` is the
+    post-window figure round 3 printed: the whole 4096-row tower on the activations of a real leaf batch."""
     inf = pvn._infer
-    leaf = state["leaf"] if state["leaf"] is not None else e.select_leaves()
+    layers = 2 * a.blocks
+    flops_per_row_layer = 2.0 * 90 * 256 * 256 * 9           # 106.17 MFLOP: one 3x3 256->256 layer on one board
+    g16 = inf._g16(B)
+    groups = inf.tower_groups(B, g16)
+    chains = inf.tower_chains(B, groups)
+    nr = {"bound": "mfma", "kernel": ("k_conv3x3_g16" if g16 else "k_conv3x3_c256") + " (tower conv3x3 256->256 + bias + residual + ReLU, fp16 in / fp32 acc)",
+          "row_layout": "group-of-16 (whole-rank tiles, off-board taps skipped)" if g16 else "nhwc (256-pixel tiles)",
+          "peak": MFMA_PEAK_F16 / 1e12, "unit": "TFLOP/s", "traffic": None, "launches_per_step": layers, "groups": groups, "chains": chains,
+          "note": "a 'launch' is one layer over the step's live rows, issued as groups x chains kernel launches over board ranges "
+                  "(groups one after the other, the chains of a group concurrently)"}
+    if tower_probe:
+        t_layer = float(np.mean([x.elapsed_time(y) for x, y in tower_probe])) * 1e-3 / layers
+        fl = flops_per_row_layer * rows_per_step
+        nr.update({"achieved": fl / t_layer / 1e12, "frac": fl / t_layer / MFMA_PEAK_F16, "avg_launch_us": t_layer * 1e6,
+                   "algorithmic_flops_per_launch": fl, "rows_per_launch": rows_per_step,
+                   "duration_source": f"HIP events around the tower of each of the {len(tower_probe)} timed steps, / {layers} layers (live, in the window)",
+                   # the algorithmic count is the convention for a padded 3x3 convolution (9 taps for every pixel); the group-of-16
+                   # kernel does not issue the MFMAs of taps with dx off the board (150 of 162 per pair of ranks)
+                   "mfma_flops_issued_per_launch": fl * (150.0 / 162.0 if g16 else 1.0)})
+        # a figure that cannot fit in the step it describes must not be printed
+        assert layers * nr["avg_launch_us"] <= ms_per_step * 1e3 * 1.001, (layers * nr["avg_launch_us"], ms_per_step)
+    # post-window: the whole batch through the tower (no plan), three times on real activations
+    leaf = sp._leaf if sp._leaf is not None else e.select_leaves()
     with torch.no_grad():
         x0 = inf._stem_fused(leaf)
         inf._tower_fused(x0.clone(memory_format=torch.preserve_format))
@@ -588,24 +638,15 @@ def tower_roofline(a, pvn, e, state, B, ev):
             inf._tower_fused(xi)
         c1.record()
     torch.cuda.synchronize()
-    t_conv = c0.elapsed_time(c1) * 1e-3 / (len(xs) * 2 * a.blocks)
-    conv_flops = 2.0 * B * 90 * 256 * 256 * 9
-    g16 = inf._g16(B) and B % 16 == 0
-    nr = {"bound": "mfma", "kernel": ("k_conv3x3_g16" if g16 else "k_conv3x3_c256") + " (tower conv3x3 256->256 + bias + residual + ReLU, fp16 in / fp32 acc)",
-          "row_layout": "group-of-16 (whole-rank tiles, off-board taps skipped)" if g16 else "nhwc (256-pixel tiles)",
-          "achieved": conv_flops / t_conv / 1e12, "peak": MFMA_PEAK_F16 / 1e12, "unit": "TFLOP/s",
-          "frac": conv_flops / t_conv / MFMA_PEAK_F16, "traffic": None, "avg_launch_us": t_conv * 1e6,
-          "algorithmic_flops_per_launch": conv_flops, "launches_per_step": 2 * a.blocks,
-          # the algorithmic count is the convention for a padded 3x3 convolution (9 taps for every pixel); the group-of-16 kernel
-          # does not issue the MFMAs of taps with dx off the board (150 of 162 per pair of ranks)
-          "mfma_flops_issued_per_launch": conv_flops * (150.0 / 162.0 if g16 else 1.0),
-          "groups": int(os.environ.get("CCZ_TOWER_GROUPS", "0")) or -(-B // (inf.TOWER_GROUP_BOARDS_G16 if g16 else inf.TOWER_GROUP_BOARDS)),
-          "note": "a 'launch' is one layer over the whole batch, issued as groups x chains kernel launches over board ranges "
-                  "(groups one after the other, the chains of a group concurrently)"}
-    per_group = -(-B // nr["groups"])
-    nr["chains"] = max(1, min(int(os.environ.get("CCZ_TOWER_CHAINS", inf.TOWER_CHAINS)), 8, per_group // 256))
+    t_conv = c0.elapsed_time(c1) * 1e-3 / (len(xs) * layers)
+    nr.update({"avg_launch_us_full_batch": t_conv * 1e6, "frac_full_batch": flops_per_row_layer * B / t_conv / MFMA_PEAK_F16,
+               "full_batch_note": f"after the window: all {B} rows through the tower, 3 passes; NOT the timed kernel (the window computed {rows_per_step:.0f} rows per step)"})
+    if "frac" not in nr:   # no probe (path without the fused tower): the post-window figure is all there is
+        nr.update({"achieved": flops_per_row_layer * B / t_conv / 1e12, "frac": nr["frac_full_batch"], "avg_launch_us": t_conv * 1e6,
+                   "algorithmic_flops_per_launch": flops_per_row_layer * B, "duration_source": "post-window full batch"})
     return nr
 
 
 if __name__ == "__main__":
-    main()
+    from chinesechesszero_amd.launch import guarded
+    sys.exit(guarded(main))

@@ -91,6 +91,37 @@ def pack_conv_weights_g16(w):
     return w5.permute(2, 1, 0, 3, 4).contiguous().view(cin // 32, 9, co, 32)
 
 
+class EvalOptions:
+    """The evaluator's A/B switches, read from the environment ONCE (when an ``InferenceNet`` is built) instead of on every
+    call of the hot host path; non-default values are logged once. Tests and A/B scripts change them on a live object with
+    ``InferenceNet.set_options(layout="g16", ...)``.
+
+    ``CCZ_FUSED_CONV=0`` (fused_conv): MIOpen convolutions + one-pass epilogue instead of the hand-written tower kernels;
+    ``CCZ_FUSED_STEM=0`` (fused_stem): the stem through torch; ``CCZ_FUSED_HEADS=0`` (fused_heads): heads and FC layers through
+    torch GEMMs; ``CCZ_CONV_LAYOUT=auto|nhwc|g16`` (layout): activation row layout (auto: group-of-16 from 640 boards on);
+    ``CCZ_CONV_FORCE=small|tile`` (force): one convolution kernel whatever the batch size; ``CCZ_TOWER_GROUPS`` / ``CCZ_TOWER_CHAINS``
+    (groups, chains): launch structure of the tower; ``CCZ_CONV_ZIGZAG=0`` (zigzag): no alternating tile order."""
+
+    FIELDS = ("fused_conv", "fused_stem", "fused_heads", "layout", "force", "groups", "chains", "zigzag")
+
+    def __init__(self, env=None):
+        env = os.environ if env is None else env
+        self.fused_conv = env.get("CCZ_FUSED_CONV", "1") != "0"
+        self.fused_stem = env.get("CCZ_FUSED_STEM", "1") != "0"
+        self.fused_heads = env.get("CCZ_FUSED_HEADS", "1") != "0"
+        self.layout = env.get("CCZ_CONV_LAYOUT", "auto")
+        self.force = {"small": 16, "tile": 32}.get(env.get("CCZ_CONV_FORCE", ""), 0)
+        self.groups = int(env.get("CCZ_TOWER_GROUPS", "0"))
+        self.chains = int(env.get("CCZ_TOWER_CHAINS", "0"))   # 0 = InferenceNet.TOWER_CHAINS
+        self.zigzag = env.get("CCZ_CONV_ZIGZAG", "1") == "1"
+        if self.layout not in ("auto", "nhwc", "g16"):
+            raise ValueError("CCZ_CONV_LAYOUT must be auto, nhwc or g16")
+
+    def non_default(self):
+        d = EvalOptions(env={})
+        return {f: getattr(self, f) for f in self.FIELDS if getattr(self, f) != getattr(d, f)}
+
+
 class InferenceNet(nn.Module):
     """Inference copy of ``Net`` for the lockstep evaluator: BN folded, fp16, channels-last.
 
@@ -105,6 +136,10 @@ class InferenceNet(nn.Module):
         super().__init__()
         self.dtype = dtype
         self.live_only = live_only
+        self.opt = EvalOptions()
+        if self.opt.non_default():
+            from .tools import log
+            log(f"evaluator options from the environment: {self.opt.non_default()}")
         cl = torch.channels_last
         w, b = _fold(net.conv_block, net.conv_block_bn)
         if live_only:
@@ -150,6 +185,41 @@ class InferenceNet(nn.Module):
         self.value_fc2_w = nn.Parameter(net.value_fc2.weight.detach().to(dtype), requires_grad=False)
         self.value_fc2_b = nn.Parameter(net.value_fc2.bias.detach().to(dtype), requires_grad=False)
 
+    def set_options(self, **kw):
+        """Change A/B switches of a live object (tests, profile scripts): ``set_options(layout="g16", fused_conv=False)``;
+        ``force`` takes "small" / "tile" / "" as the environment variable does."""
+        for k, v in kw.items():
+            if k not in EvalOptions.FIELDS:
+                raise KeyError(k)
+            if k == "force" and isinstance(v, str):
+                v = {"small": 16, "tile": 32, "": 0}[v]
+            setattr(self.opt, k, v)
+        if self.opt.layout not in ("auto", "nhwc", "g16"):
+            raise ValueError("layout must be auto, nhwc or g16")
+        self.__dict__.pop("_path_cache", None)
+        return self
+
+    def opt_fused_conv(self) -> bool:
+        return self.opt.fused_conv
+
+    def tower_groups(self, B: int, g16: bool) -> int:
+        """Sequential board groups of the tower for a batch of B boards (Infinity-Cache residency, :meth:`_tower_fused`)."""
+        return self.opt.groups or -(-B // (self.TOWER_GROUP_BOARDS_G16 if g16 else self.TOWER_GROUP_BOARDS))
+
+    def tower_chains(self, B: int, groups: int = 1) -> int:
+        """Concurrent launch chains per group (one HIP stream each)."""
+        return max(1, min(self.opt.chains or self.TOWER_CHAINS, 8, -(-B // groups) // 256))
+
+    @torch.no_grad()
+    def repack_derived(self):
+        """The tensors derived from others (the weights packed for k_conv3x3_g16) re-derived IN PLACE after the primary ones were
+        overwritten (``replay.broadcast_model(what="inference")``): addresses stay what captured graphs hold."""
+        if hasattr(self, "ws_g16"):
+            for dst, w in zip(self.ws_g16, self.ws):
+                dst.copy_(pack_conv_weights_g16(w.permute(0, 2, 3, 1)))
+        if hasattr(self, "stem_w64_g16"):
+            self.stem_w64_g16.copy_(pack_conv_weights_g16(self.stem_w64))
+
     def _epilogue(self, y, bias, residual=None):
         """relu(y + bias [+ residual]) in ONE pass (libcczero ccz_bias_act_f16) on NHWC fp16 device tensors;
         plain torch ops otherwise (CPU tests, other dtypes)."""
@@ -175,8 +245,8 @@ class InferenceNet(nn.Module):
 
     def _use_fused_tower(self, x) -> bool:
         """The hand-written MFMA convolution (libcczero ccz_conv3x3_c256_f16) covers the tower's shape only:
-        fp16 NHWC on the GPU, 256 channels. ``CCZ_FUSED_CONV=0`` selects the MIOpen + epilogue path for A/B runs."""
-        if os.environ.get("CCZ_FUSED_CONV", "1") == "0":
+        fp16 NHWC on the GPU, 256 channels. ``fused_conv=False`` (``CCZ_FUSED_CONV=0``) selects the MIOpen + epilogue path for A/B runs."""
+        if not self.opt.fused_conv:
             return False
         return bool(x.is_cuda and x.dtype == torch.float16 and x.shape[1] == 256 and x.shape[0] >= self.FUSED_MIN_BOARDS
                     and x.is_contiguous(memory_format=torch.channels_last))
@@ -189,8 +259,8 @@ class InferenceNet(nn.Module):
     # kernels add in the same order).
 
     def _g16(self, B) -> bool:
-        mode = os.environ.get("CCZ_CONV_LAYOUT", "auto")
-        if mode == "nhwc" or self._force_flag():
+        mode = self.opt.layout
+        if mode == "nhwc" or self.opt.force:
             return False
         return B >= (65 if mode == "g16" else self.G16_MIN_BOARDS)
 
@@ -222,7 +292,7 @@ class InferenceNet(nn.Module):
         Bt = x.shape[0]
         # (group-of-16 layout, round 3, 4096 boards with the evaluation cache: 1 group x 2 chains 23.54 ms/step, 2 x 2 23.80,
         # 1 x 1 24.89, 1 x 4 24.42: the cache-residency gain of two groups is gone, the tail-filling of two chains is not)
-        groups = int(os.environ.get("CCZ_TOWER_GROUPS", "0")) or -(-Bt // (self.TOWER_GROUP_BOARDS_G16 if g16 else self.TOWER_GROUP_BOARDS))
+        groups = self.tower_groups(Bt, g16)
         if torch.cuda.is_current_stream_capturing():
             groups = 1
         if plan is not None:
@@ -241,9 +311,7 @@ class InferenceNet(nn.Module):
         from . import _lib
         B = x.shape[0]
         cur = torch.cuda.current_stream(x.device)
-        want = int(os.environ.get("CCZ_TOWER_CHAINS", self.TOWER_CHAINS))
-        per_group = -(-B // groups)
-        chains = 1 if torch.cuda.is_current_stream_capturing() else max(1, min(want, 8, per_group // 256))
+        chains = 1 if torch.cuda.is_current_stream_capturing() else self.tower_chains(B, groups)
         n_parts = groups * chains
         if g16:
             cap = -(-(B // 16) // n_parts) * 1440            # whole 16-board groups (B is padded to a multiple of 16)
@@ -257,7 +325,7 @@ class InferenceNet(nn.Module):
                 self._chain_streams = pool
         live = C.c_void_p(plan[1].data_ptr())
         xp, yp = C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr())
-        down = 2 if os.environ.get("CCZ_CONV_ZIGZAG", "1") == "1" else 0
+        down = 2 if self.opt.zigzag else 0
         for g in range(groups):
             streams = [cur] + [self._chain_streams[1][k] for k in range(chains - 1)]
             if chains > 1:
@@ -282,8 +350,7 @@ class InferenceNet(nn.Module):
         from . import _lib
         B = hi - lo
         cur = torch.cuda.current_stream(x.device)
-        want = int(os.environ.get("CCZ_TOWER_CHAINS", self.TOWER_CHAINS))
-        parts = 1 if torch.cuda.is_current_stream_capturing() else max(1, min(want, 8, B // 256))
+        parts = 1 if torch.cuda.is_current_stream_capturing() else self.tower_chains(B)
         step = -(-B // parts)
         if parts > 1:
             step = -(-step // 128) * 128  # 128 boards = 45 whole tiles: no partial tile inside the batch
@@ -305,11 +372,9 @@ class InferenceNet(nn.Module):
         # launches are enqueued layer by layer across the chains, so that the chains advance together (the same layer's
         # weights stay hot in L2) and no chain waits for the host to finish enqueuing another one. The tile order
         # alternates from layer to layer: what the previous layer wrote last (still in the Infinity Cache) is read
-        # first (-0.7 % on the step; CCZ_CONV_ZIGZAG=0 switches it off).
-        down = 2 if os.environ.get("CCZ_CONV_ZIGZAG", "1") == "1" else 0
-        v2 = 4 if os.environ.get("CCZ_CONV_V2", "0") == "1" else 0  # A/B only: the experimental two-workgroups-per-CU form
-        # (cczero_conv2.h, compiled into diagnostic builds with -DCCZ_CONV2; the shipped library ignores the bit)
-        v2 |= self._force_flag() | (_lib.CONV_G16 if g16 else 0)
+        # first (-0.7 % on the step; zigzag=False / CCZ_CONV_ZIGZAG=0 switches it off).
+        down = 2 if self.opt.zigzag else 0
+        v2 = self.opt.force | (_lib.CONV_G16 if g16 else 0)
         wsrc = self.ws_g16 if g16 else self.ws
         for i in range(0, len(self.ws), 2):
             w1, b1_, w2, b2_ = (C.c_void_p(t.data_ptr()) for t in (wsrc[i], self.bs32[i], wsrc[i + 1], self.bs32[i + 1]))
@@ -322,11 +387,10 @@ class InferenceNet(nn.Module):
             join.record(st)
             cur.wait_event(join)
 
-    @staticmethod
-    def _force_flag() -> int:
-        """A/B switch ``CCZ_CONV_FORCE=small|tile``: run every convolution on k_conv3x3_small / on the 256-pixel tile kernel
-        whatever the batch size (the library picks by batch size otherwise; the results are bit-identical either way)."""
-        return {"small": 16, "tile": 32}.get(os.environ.get("CCZ_CONV_FORCE", ""), 0)
+    def _force_flag(self) -> int:
+        """A/B switch ``force`` (``CCZ_CONV_FORCE=small|tile``): run every convolution on k_conv3x3_small / on the 256-pixel tile
+        kernel whatever the batch size (the library picks by batch size otherwise; the results are bit-identical either way)."""
+        return self.opt.force
 
     def _stem_fused(self, leaf_input, plan=None, g16=None):
         """Stem on the same MFMA kernel: pack the 21 live planes as NHWC rows of 64 channels, then one 64-channel chunk of
@@ -379,54 +443,71 @@ class InferenceNet(nn.Module):
         rows = x.permute(0, 2, 3, 1).reshape(Bp // 16, 90, 16, Cn).permute(0, 2, 1, 3).reshape(Bp, 10, 9, Cn)[:B]
         return rows.permute(0, 3, 1, 2)
 
+    def _path(self, leaf_input) -> str:
+        """ONE decision per batch shape (cached; ``set_options`` clears the cache): which kernels the stem and the tower run on.
+        "g16" / "nhwc": pack + stem + tower on the hand-written MFMA kernels, rows in the group-of-16 / board-major order;
+        "torch_stem": the stem through torch (full 119-plane input or ``fused_stem`` off), the tower on the hand-written kernels
+        when it is 256 wide fp16 on the GPU; "torch": everything through torch / MIOpen + the one-pass epilogue."""
+        B = leaf_input.shape[0]
+        key = (B, leaf_input.is_cuda, leaf_input.dtype, leaf_input.is_contiguous())
+        cache = self.__dict__.setdefault("_path_cache", {})
+        if key not in cache:
+            o = self.opt
+            fused = (hasattr(self, "stem_w64") and leaf_input.is_cuda and leaf_input.dtype == torch.float16 and leaf_input.is_contiguous()
+                     and B >= self.FUSED_MIN_BOARDS and self.dtype == torch.float16 and o.fused_conv and o.fused_stem)
+            if fused:
+                cache[key] = "g16" if self._g16(B) else "nhwc"
+            else:
+                cache[key] = "torch_stem" if (o.fused_conv and leaf_input.is_cuda and self.dtype == torch.float16
+                                              and self.ws and self.ws[0].shape[0] == 256 and self.ws[0].shape[1] == 256) else "torch"
+        return cache[key]
+
     @torch.no_grad()
     def forward(self, leaf_input: torch.Tensor, return_logits: bool = False, plan=None):
         """``plan`` = (rows int32 [B], n_rows int32 [1]) device tensors of the planned evaluator boundary (``ccz_eval_plan``):
         outputs are COMPACT -- row i is the evaluation of board rows[i], for i < n_rows; the other rows are unspecified. On the
         fused path only the live rows are computed; elsewhere the rows are gathered and the whole batch is evaluated."""
         B = leaf_input.shape[0]
-        fused_ok = (hasattr(self, "stem_w64") and leaf_input.is_cuda and leaf_input.dtype == torch.float16 and leaf_input.is_contiguous()
-                    and B >= self.FUSED_MIN_BOARDS and self.dtype == torch.float16 and os.environ.get("CCZ_FUSED_CONV", "1") != "0"
-                    and os.environ.get("CCZ_FUSED_STEM", "1") != "0" and self.stem_w64.shape[0] == 256)
-        if plan is not None and not fused_ok:
+        path = self._path(leaf_input)
+        if plan is not None and path not in ("g16", "nhwc"):
             leaf_input = leaf_input.index_select(0, plan[0].long().clamp_(0, B - 1))
             plan = None
-        tower_done = False
-        g16 = False   # True: x holds its rows in the group-of-16 layout (and ceil(B / 16) * 16 boards)
-        if plan is not None:
-            g16 = self._g16(B)
-            x = self._tower_fused(self._stem_fused(leaf_input, plan, g16), plan, g16)
-            tower_done = True
-        elif fused_ok and self._g16(B):
-            g16 = True
-            x = self._tower_fused(self._stem_fused(leaf_input, None, True), None, True)
-            tower_done = True
-        elif (hasattr(self, "stem_w64") and leaf_input.is_cuda and leaf_input.dtype == torch.float16 and leaf_input.is_contiguous()
-                and B >= self.FUSED_MIN_BOARDS and self.dtype == torch.float16 and os.environ.get("CCZ_FUSED_CONV", "1") != "0"
-                and os.environ.get("CCZ_FUSED_STEM", "1") != "0"):
-            x = self._stem_fused(leaf_input)
+        g16 = path == "g16"   # True: x holds its rows in the group-of-16 layout (and ceil(B / 16) * 16 boards)
+        if path in ("g16", "nhwc"):
+            x = self._stem_fused(leaf_input, plan, g16)
+            probe = self.__dict__.get("tower_probe")   # bench.py: a list that receives one HIP-event pair around the 80 tower launches
+            if probe is not None:   # (recorded on the current stream: the chains fork from it and join it)
+                p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                p0.record()
+            x = self._tower_fused(x, plan, g16)
+            if probe is not None:
+                p1.record()
+                probe.append((p0, p1))
         else:
             x = leaf_input.view(B, PLAYS * PIECES, 10, 9)
             if self.live_only:
                 x = torch.cat([x[:, 49:56], x[:, 105:119]], dim=1)
             x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
             x = self._epilogue(F.conv2d(x, self.stem_w, None, padding=1), self.stem_b)
-        if tower_done:
-            pass
-        elif self._use_fused_tower(x):
-            x = self._tower_fused(x)
-        else:
-            if x.is_cuda and x.dtype == torch.float16 and os.environ.get("CCZ_FUSED_CONV", "1") != "0":
-                key = (int(x.shape[0]), int(x.shape[1]))
-                seen = self.__dict__.setdefault("_off_fused_seen", set())
-                if key not in seen:  # once per shape: the caller should know this batch does not run on the MFMA kernel
-                    seen.add(key)
-                    from .tools import log
-                    log(f"evaluator: batch of {key[0]} boards x {key[1]} channels is off the fused tower kernels "
-                        f"(k_conv3x3_g16 / k_conv3x3_small serve 256-channel towers): MIOpen convolutions + one-pass epilogue")
-            for i in range(0, len(self.ws), 2):
-                y = self._epilogue(F.conv2d(x, self.ws[i], None, padding=1), self.bs[i])
-                x = self._epilogue(F.conv2d(y, self.ws[i + 1], None, padding=1), self.bs[i + 1], x)
+            if path == "torch_stem" and self._use_fused_tower(x):
+                x = self._tower_fused(x, None, False)
+            else:
+                if x.is_cuda and x.dtype == torch.float16 and self.opt.fused_conv:
+                    key = (int(x.shape[0]), int(x.shape[1]))
+                    seen = self.__dict__.setdefault("_off_fused_seen", set())
+                    if key not in seen:  # once per shape: the caller should know this batch does not run on the MFMA kernel
+                        seen.add(key)
+                        from .tools import log
+                        log(f"evaluator: batch of {key[0]} boards x {key[1]} channels is off the fused tower kernels "
+                            f"(k_conv3x3_g16 / k_conv3x3_small serve 256-channel towers): MIOpen convolutions + one-pass epilogue")
+                for i in range(0, len(self.ws), 2):
+                    y = self._epilogue(F.conv2d(x, self.ws[i], None, padding=1), self.bs[i])
+                    x = self._epilogue(F.conv2d(y, self.ws[i + 1], None, padding=1), self.bs[i + 1], x)
+        return self._heads(x, B, g16, plan, return_logits)
+
+    def _heads(self, x, B, g16, plan, return_logits):
+        """Policy / value heads and FC layers (reference net.py:96-109) on the tower's output ``x`` (channels-last rows in memory
+        order; ``g16``: group-of-16 row order, padded to whole groups)."""
         Bx = x.shape[0]
         rows = x.permute(0, 2, 3, 1).reshape(Bx * 90, x.shape[1])   # a view of the activations in memory order: one row per pixel
         h = F.relu_(torch.addmm(self.head_b, rows, self.head_wT))
@@ -468,6 +549,9 @@ class PolicyValueNet:
                       "(reference-trained weights: try tools.set_rules(preset='python-chess-lineage') [unverified] if this one plays nonsense)")
         self._infer = None
         self._graph = None
+        # MIOpen "find" mode for the evaluator's torch convolutions (towers that are not 256 wide): read once; CCZ_MIOPEN_FIND=0 =
+        # immediate mode, no per-shape find step (tests, tiny nets)
+        self._miopen_find = os.environ.get("CCZ_MIOPEN_FIND", "1") != "0"
         self.weights_version = 0  # bumped whenever the inference copy is rebuilt or invalidated (hipGraphs hold its addresses)
 
     def invalidate_inference_copy(self):
@@ -491,7 +575,7 @@ class PolicyValueNet:
         """[B,17,7,10,9] fp16 device tensor -> (prob float32 [B,2086], value float32 [B]) on the same stream."""
         if self._infer is None:
             self.refresh_inference_copy()
-        if os.environ.get("CCZ_MIOPEN_FIND", "1") == "0":  # immediate mode: no per-shape find step (tests, tiny nets)
+        if not self._miopen_find:
             return self._infer(leaf_input)
         with torch.backends.cudnn.flags(enabled=True, benchmark=True):  # find mode for the evaluator's convs only
             return self._infer(leaf_input)
@@ -506,7 +590,7 @@ class PolicyValueNet:
         with an evaluation cache (``SelfPlayEngine.eval_plan()``): only the planned rows are computed, outputs are compact."""
         if self._infer is None:
             self.refresh_inference_copy()
-        if os.environ.get("CCZ_MIOPEN_FIND", "1") == "0":
+        if not self._miopen_find:
             return self._infer(leaf_input, return_logits=True, plan=plan)
         with torch.backends.cudnn.flags(enabled=True, benchmark=True):
             return self._infer(leaf_input, return_logits=True, plan=plan)

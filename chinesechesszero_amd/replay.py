@@ -22,11 +22,15 @@ NMOVES = 2086
 REC_BYTES, REC_HDR = 880, 96  # compact ply record, include/cczero.h CCZ_REC_BYTES / CCZ_REC_HDR
 
 
+class GatherAborted(RuntimeError):
+    """Raised on EVERY rank of an exchange in which some rank could not take part (e.g. one game longer than the slot)."""
+
+
 class _FusedGather:
     """ONE ``all_gather_into_tensor`` per round: every rank sends one fixed-size uint8 slot ``[header 64 B | payload]``.
 
     header = int64 x 8: items in this round, items this rank still holds after it, ``more`` flag of the caller, ``user``
-    counter (finished games), 4 spare. Counts therefore travel inside the same collective as the payload; after it ONE
+    counter (finished games), ``abort`` (this rank cannot take part: every rank raises after the collective, together), 3 spare. Counts therefore travel inside the same collective as the payload; after it ONE
     small device-to-host copy (world x 64 B) tells every rank what each slot holds. The shape is fixed (padded) so that
     every rank issues the same collective whatever finished where."""
 
@@ -53,6 +57,7 @@ class _FusedGather:
         self.collectives = 0
         self.seconds = 0.0
         self.rows_per_rank: list[int] = []
+        self._abort_why = ""
 
     def bytes_per_exchange(self) -> int:
         """Bytes one rank sends in one round (it receives (world - 1) x this)."""
@@ -61,12 +66,14 @@ class _FusedGather:
     def _solo(self) -> bool:
         return self.world == 1 and not (self.always_collective and dist.is_initialized())
 
-    def _round(self, m: int, left: int, more: bool, user: int):
-        """Header in, the collective, headers out (the one host sync): int64 [world, 8] on the host."""
+    def _round(self, m: int, left: int, more: bool, user: int, abort: int = 0):
+        """Header in, the collective, headers out (the one host sync): int64 [world, 8] on the host. A rank that cannot go on
+        (``abort`` != 0) still takes part in THIS collective, so that nobody is left waiting in it; afterwards every rank raises."""
         self._hdr_host[0] = m
         self._hdr_host[1] = left
         self._hdr_host[2] = 1 if more else 0
         self._hdr_host[3] = int(user)
+        self._hdr_host[4] = int(abort)
         self._send[:self.HEADER].view(torch.int64).copy_(self._hdr_host, non_blocking=True)
         dist.all_gather_into_tensor(self._recv, self._send, group=self.group)
         self.collectives += 1
@@ -75,6 +82,9 @@ class _FusedGather:
         for k in range(self.world):
             self.any_more |= bool(int(heads[k, 2]))
             self.user_sum += int(heads[k, 3])
+        bad = [k for k in range(self.world) if int(heads[k, 4])]
+        if bad:
+            raise GatherAborted(f"rank(s) {bad} aborted the exchange" + (f": {self._abort_why}" if self.rank in bad and self._abort_why else ""))
         return heads
 
 
@@ -130,10 +140,14 @@ class RecordGatherer(_FusedGather):
         mine = self._payload(self._send, 0)
         lo = 0
         while True:
-            m = self._whole_games(records, lo, self.cap) if n > lo else 0
+            abort = 0
+            try:
+                m = self._whole_games(records, lo, self.cap) if n > lo else 0
+            except ValueError as e:   # this rank holds a game the slot cannot carry: the peers are (or will be) in the collective --
+                m, abort, self._abort_why = 0, 1, str(e)   # join it with the abort flag up, so that all ranks raise together
             if m:
                 mine[:m].copy_(records[lo:lo + m])
-            heads = self._round(m, n - lo - m, more, user if self.rounds == 0 else 0)
+            heads = self._round(m, n - lo - m, more, user if self.rounds == 0 else 0, abort)
             again = bool((heads[:, 1] > 0).any())  # some rank still holds records: another round of the same shape follows
             for k in range(self.world):
                 mk = int(heads[k, 0])
@@ -159,6 +173,11 @@ def exchange_finished_games(source, gatherer: RecordGatherer, done: int):
     ranks, rank-major, whole games --, finished games summed over ranks)``. There is more than one iteration only when
     some rank finished more plies than the gatherer's slot holds; the "more" flag and the game count ride in the header
     of the same collective (no extra all-reduce). ``source``: anything with ``harvest_record_chunks(max_plies)``."""
+    longest = getattr(getattr(source, "engine", source), "max_plies", None)
+    if longest is not None and int(longest) > gatherer.cap:
+        # the same test on every rank (they share the configuration), BEFORE any collective: nobody is left waiting in one
+        raise ValueError(f"exchange slot of {gatherer.cap} plies is smaller than the longest game the engine records ({longest} plies): "
+                         f"RecordGatherer(capacity_plies >= max_plies)")
     it = iter(source.harvest_record_chunks(gatherer.cap)) if done else iter(())
     chunk = next(it, None)
     first = True
@@ -313,15 +332,58 @@ class ReplayBuffer:
         return self.states[idx], self.pi[idx], self.z[idx]
 
 
-def broadcast_model(policy_value_net, src: int = 0, group=None):
-    """Model hot-reload across ranks: broadcast every parameter and buffer of the
-    ``PolicyValueNet`` from ``src`` (the trainer's rank) and rebuild the inference copy. The reference's
-    collector loads its model once per process and never refreshes it (collect.py:49)."""
-    net = policy_value_net.policy_value_net
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+def _flat_bytes(tensors, device):
+    """The tensors' memory as ONE uint8 buffer on ``device`` (any mix of dtypes), and the (offset, nbytes) of each."""
+    spans, off = [], 0
+    for t in tensors:
+        nb = t.numel() * t.element_size()
+        spans.append((off, nb))
+        off += -(-nb // 16) * 16
+    flat = torch.empty((off,), dtype=torch.uint8, device=device)
+    return flat, spans
+
+
+def broadcast_model(policy_value_net, src: int = 0, group=None, what: str = "state"):
+    """Model hot-reload across ranks as ONE broadcast of one flat byte buffer (round 3 issued one collective per
+    tensor, ~500 of them). The reference's collector loads its model once per process and never refreshes it (collect.py:49).
+
+    ``what="state"`` (default): every parameter and buffer of the fp32 ``Net`` (204 MB at 40 x 256), bit-exact; each rank then
+    rebuilds its fp16 inference copy -- afterwards any rank can ``save_model`` or train. ``what="inference"``: only the BN-folded
+    fp16 inference copy (102 MB), written IN PLACE into the receivers' copy (same device addresses, so captured hipGraphs stay
+    valid); for ranks that only ever evaluate. Either way ``weights_version`` moves, which empties evaluation caches keyed to it."""
+    if what not in ("state", "inference"):
+        raise ValueError("what must be 'state' or 'inference'")
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    rank = dist.get_rank(group) if multi else 0
+    if what == "state":
+        net = policy_value_net.policy_value_net
+        tensors = [t.data for t in list(net.parameters()) + list(net.buffers())]
+    else:
+        if getattr(policy_value_net, "_infer", None) is None:
+            policy_value_net.refresh_inference_copy()
+        inf = policy_value_net._infer
+        derived = {n for n, _ in inf.named_parameters() if "g16" in n}   # packed copies: re-derived locally, not sent
+        tensors = [p.data for n, p in inf.named_parameters() if n not in derived]
+    if multi and tensors:
+        dev = tensors[0].device
+        if dist.get_backend(group) == "gloo":
+            dev = torch.device("cpu")
         with torch.no_grad():
-            for t in list(net.parameters()) + list(net.buffers()):
-                dist.broadcast(t.data, src=src, group=group)
-    if hasattr(policy_value_net, "refresh_inference_copy"):
-        policy_value_net.refresh_inference_copy()
+            flat, spans = _flat_bytes(tensors, dev)
+            if rank == src:
+                for t, (o, nb) in zip(tensors, spans):
+                    flat[o:o + nb].copy_(t.contiguous().reshape(-1).view(torch.uint8))
+            dist.broadcast(flat, src=src, group=group)
+            if rank != src:
+                for t, (o, nb) in zip(tensors, spans):
+                    t.copy_(flat[o:o + nb].view(t.dtype).view(t.shape))
+    if what == "state":
+        if hasattr(policy_value_net, "refresh_inference_copy"):
+            policy_value_net.refresh_inference_copy()
+    else:
+        inf = policy_value_net._infer
+        if multi and rank != src:
+            inf.repack_derived()
+        policy_value_net._graph = None
+        policy_value_net.weights_version += 1
     return policy_value_net

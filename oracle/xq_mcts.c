@@ -11,11 +11,13 @@
  *   - select (mcts.py:54-61): Python max() keeps the FIRST maximal child in insertion order;
  *     unvisited children score +inf.
  */
+#define _POSIX_C_SOURCE 200809L /* clock_gettime (the optional playout timers) */
 #include "xq_oracle.h"
 
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 enum { V_INT0 = 0, V_PYFLOAT = 1, V_F32 = 2 };
 
@@ -59,7 +61,26 @@ struct xq_mcts {
     int value_f16;  /* the evaluator's value is a float16 ndarray (reference CUDA/autocast path, net.py:178-189) */
     node *cur_leaf; /* set by xq_mcts_select */
     int64_t live_nodes;
+    /* optional wall-clock split of a playout (bench.py's cpu_baseline leg): seconds spent in the rules (push along the path,
+       legal-move generation, game-end / draw predicates) and in the tree (PUCT scan, expansion, backup); the evaluator callback
+       is timed by the caller. Off by default: no clock call is made. */
+    int timing;
+    double t_rules, t_tree;
 };
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+void xq_mcts_set_timing(xq_mcts *t, int on) { t->timing = on != 0; t->t_rules = t->t_tree = 0.0; }
+void xq_mcts_timers(const xq_mcts *t, double *rules_s, double *tree_s)
+{
+    if (rules_s) *rules_s = t->t_rules;
+    if (tree_s) *tree_s = t->t_tree;
+}
 
 static node *node_new(xq_mcts *t, node *parent, float prob)
 {
@@ -156,6 +177,7 @@ int xq_mcts_select(xq_mcts *t, const xq_board *root_board, xq_board *leaf_out, i
 {
     node *n = t->root;
     int depth = 0;
+    double t0 = t->timing ? now_s() : 0.0, tr = 0.0;
     *leaf_out = *root_board; /* board.copy()  mcts.py:151 */
     while (n->nchild != 0) {
         int i, best = 0;
@@ -164,10 +186,16 @@ int xq_mcts_select(xq_mcts *t, const xq_board *root_board, xq_board *leaf_out, i
             double v = puct_value(n->child[i], t->c_puct);
             if (v > bestv) { bestv = v; best = i; } /* strict: first maximum wins */
         }
-        xq_push(leaf_out, xq_move_from(n->act[best]), xq_move_to(n->act[best]));
+        if (t->timing) {
+            double p0 = now_s();
+            xq_push(leaf_out, xq_move_from(n->act[best]), xq_move_to(n->act[best]));
+            tr += now_s() - p0;
+        } else
+            xq_push(leaf_out, xq_move_from(n->act[best]), xq_move_to(n->act[best]));
         n = n->child[best];
         depth++;
     }
+    if (t->timing) { t->t_rules += tr; t->t_tree += now_s() - t0 - tr; }
     t->cur_leaf = n;
     if (depth_out) *depth_out = depth;
     return 0;
@@ -178,7 +206,9 @@ void xq_mcts_expand_backup(xq_mcts *t, const xq_board *leaf, int k, const uint16
                            const float *prob, float value)
 {
     node *n = t->cur_leaf;
+    double t0 = t->timing ? now_s() : 0.0, t1;
     int end = xq_is_game_over(leaf, k), tie = xq_is_tie(leaf, k);
+    t1 = t->timing ? now_s() : 0.0;
     if (!end && !tie) {
         int i;
         /* Node.expand  mcts.py:31-39 : one child per (action, prob), evaluator order */
@@ -200,6 +230,7 @@ void xq_mcts_expand_backup(xq_mcts *t, const xq_board *leaf, int k, const uint16
         double lv = winner == leaf->pos.turn ? 1.0 : -1.0;
         node_update_recursive(n, 0, 0.0f, -lv, t->value_f16);
     }
+    if (t->timing) { t->t_rules += t1 - t0; t->t_tree += now_s() - t1; }
     t->cur_leaf = NULL;
 }
 
@@ -211,7 +242,12 @@ void xq_mcts_playout(xq_mcts *t, const xq_board *root_board, xq_eval_fn fn, void
     float value = 0.0f;
     int k, depth;
     xq_mcts_select(t, root_board, &leaf, &depth);
-    k = xq_legal_ids(&leaf, ids);
+    if (t->timing) {
+        double p0 = now_s();
+        k = xq_legal_ids(&leaf, ids);
+        t->t_rules += now_s() - p0;
+    } else
+        k = xq_legal_ids(&leaf, ids);
     /* the reference evaluates the net on terminal leaves too and discards the result (mcts.py:114);
        that is results-neutral, so the evaluator is only called where its output is used */
     if (!xq_is_game_over(&leaf, k) && !xq_is_tie(&leaf, k)) value = fn(user, &leaf, k, ids, prob);

@@ -114,6 +114,9 @@ void xq_mcts_free(xq_mcts *t);
 /* the evaluator's value is a float16 ndarray (reference CUDA path: autocast, net.py:178-189): Node.value is then
    accumulated in float16 (NEP 50). Default off = the float32 value of the reference's CPU path. */
 void xq_mcts_set_value_f16(xq_mcts *t, int on);
+/* wall-clock split of the playouts since the call (bench.py cpu_baseline: "net / rules / tree"); off by default */
+void xq_mcts_set_timing(xq_mcts *t, int on);
+void xq_mcts_timers(const xq_mcts *t, double *rules_s, double *tree_s);
 void xq_mcts_playout(xq_mcts *t, const xq_board *root_board, xq_eval_fn fn, void *user);
 /* runs n_playout playouts (mcts.py:131-166); returns k root children; visits/acts/probs sized >= XQ_MAX_LEGAL */
 int xq_mcts_get_move_probs(xq_mcts *t, const xq_board *b, double temp, xq_eval_fn fn, void *user,

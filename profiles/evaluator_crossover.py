@@ -14,8 +14,7 @@ for B in (8, 16, 32, 64, 128, 256):
     leaf = (torch.rand(B, 17, 7, 10, 9, device=dev) > 0.9).half()
     res = {}
     for fused in (1, 0):
-        os.environ["CCZ_FUSED_CONV"] = str(fused)
-        InferenceNet.FUSED_MIN_BOARDS = 1
+        inf.set_options(fused_conv=bool(fused))
         with torch.no_grad(), torch.backends.cudnn.flags(enabled=True, benchmark=True):
             res[fused] = t(lambda: inf(leaf, return_logits=True))
     print(B, "fused ms %.3f" % res[1], "miopen ms %.3f" % res[0])

@@ -96,15 +96,14 @@ def main():
         x[:, 7] = (torch.rand((B, 7, 10, 9), device=dev) > 0.9).half()
         x[:, 16] = 1.0
         for path in ("default", "small", "tile", "miopen"):
-            old_min, old_env = InferenceNet.FUSED_MIN_BOARDS, os.environ.get("CCZ_FUSED_CONV")
             try:
-                os.environ.pop("CCZ_CONV_FORCE", None)
+                inf.set_options(force="", fused_conv=True)
                 if path in ("small", "tile"):
                     if path == "small" and B > 1024:
                         continue
-                    os.environ["CCZ_CONV_FORCE"] = path
+                    inf.set_options(force=path)
                 elif path == "miopen":
-                    os.environ["CCZ_FUSED_CONV"] = "0"
+                    inf.set_options(fused_conv=False)
                 with torch.backends.cudnn.flags(enabled=True, benchmark=True):
                     fn = lambda: inf(x, return_logits=True)
                     fn()
@@ -115,12 +114,7 @@ def main():
                     us = 1e6 * timed(gq.replay, 30 if B <= 192 else 5)
                 rows.append({"boards": B, "tower": path, "evaluator_us": us, "us_per_board": us / B, "us_per_tower_layer": us / 80})
             finally:
-                InferenceNet.FUSED_MIN_BOARDS = old_min
-                os.environ.pop("CCZ_CONV_FORCE", None)
-                if old_env is None:
-                    os.environ.pop("CCZ_FUSED_CONV", None)
-                else:
-                    os.environ["CCZ_FUSED_CONV"] = old_env
+                inf.set_options(force="", fused_conv=True)
             print(rows[-1], file=sys.stderr, flush=True)
     out["evaluator_by_batch"] = rows
     out["reference_python_on_8_cpu_cores_sims_per_sec"] = 30.0   # the reference's own mcts.py + net.py, fp32, build container

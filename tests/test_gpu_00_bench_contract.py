@@ -63,11 +63,59 @@ def test_bench_starts_its_own_ranks_and_exchanges_inside_the_timed_window():
     assert m["payload_bytes_rank0_per_exchange"] == 880 * j["move_boundary"]["rows_harvested_rank0"] // 2
     # every rank's ring received the union: the window's exchange and those of the two untimed warm-up moves before it
     assert m["bad_records"] == 0 and m["replay_rows_total"] >= m["rows_gathered"] and j["config"]["warm_moves"] == 2
+    assert m["error_flags_any"] == 0 and m["ring_ranks"] == "all" and m["expand_ms_host"] >= 0 and m["dist_timeout_s"] == 180
     assert len(m["per_rank_sims_per_sec"]) == 2 and all(v > 0 for v in m["per_rank_sims_per_sec"])
     # whole-job value = all ranks' simulations over the slowest rank's time: never above the sum of the per-rank rates
     assert 0 < j["value"] <= sum(m["per_rank_sims_per_sec"]) * 1.001
     assert j["move_boundary"]["in_window"] == 1 and j["move_boundary"]["ms_host"] > 0
     assert abs(j["ms_per_step"] * 12 * 1e-3 * j["value"] - 2 * 256 * 12) < 1e-3 * 2 * 256 * 12
+
+
+def test_bench_a_rank_that_fails_inside_the_timed_window_ends_the_job_fast():
+    """Rank 1 raises at its 3rd timed step (--inject-fault) while rank 0 goes on into the move boundary's all-gather. The rank
+    guard ends rank 1's process at once, the launcher tears the job down: non-zero exit code, the failing rank named, no JSON
+    line -- long before the 600-second collective timeout this run asks for."""
+    import time
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2", "--backend", "gloo",
+           "--share-gpu", "--gather-plies", "1024", "--playout", "16", "--inject-fault", "1:3", "--dist-timeout", "600"] + SMALL
+    env = _env()
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    took = time.time() - t0
+    assert r.returncode != 0 and "[rank 1] failed" in r.stderr and "injected fault on rank 1" in r.stderr, (r.stdout[-1000:], r.stderr[-3000:])
+    assert '"metric"' not in r.stdout
+    assert took < 240, took      # set-up of two ranks + a few steps; nowhere near the 600 s a hung collective would take
+
+
+def test_bench_refuses_more_ranks_than_gpus_before_starting_any():
+    """`python bench.py --gpus 8` on a one-GPU box: the parent counts the GPUs without touching HIP and says no in one line."""
+    import time
+    env = _env()
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"] + SMALL, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "not starting any rank" in r.stderr and "--gpus 8 needs 8 visible GPU(s)" in r.stderr
+    assert time.time() - t0 < 120 and '"metric"' not in r.stdout
+
+
+def test_bench_under_the_launcher_with_one_rank_prints_the_single_gpu_line():
+    """SCALE's N = 1 (`torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`) has to be BENCH's N = 1 line: the same keys
+    (roofline, cpu_baseline, no multi_gpu block), the same workload description, n_gpus 1."""
+    args = ["--steps", "10", "--warmup", "3", "--cpu-baseline-seconds", "2", "--playout", "64"] + SMALL
+    plain = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
+    assert plain.returncode == 0, (plain.stdout[-2000:], plain.stderr[-3000:])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args
+    under = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
+    assert under.returncode == 0, (under.stdout[-2000:], under.stderr[-3000:])
+    a, b = _json_line(plain.stdout), _json_line(under.stdout)
+    assert set(a) == set(b) and "multi_gpu" not in b and "cpu_baseline" in b and b["n_gpus"] == 1
+    assert a["config"] == b["config"] and set(a["roofline"]) == set(b["roofline"]) and set(a["cpu_baseline"]) == set(b["cpu_baseline"])
+    # the same deterministic search: identical tree statistics in both runs
+    assert a["nodes_peak"] == b["nodes_peak"] and a["roofline"]["k_bar"] == b["roofline"]["k_bar"] and a["roofline"]["d_bar"] == b["roofline"]["d_bar"]
 
 
 def test_bench_refuses_a_gpu_count_that_contradicts_the_launcher():
@@ -90,6 +138,7 @@ def test_bench_two_ranks_with_concurrent_trainer_on_rank0():
     assert j["multi_gpu"]["ranks_seen"] == 2 and j["multi_gpu"]["exchanges_in_window"] == 1
     assert j["multi_gpu"]["rows_gathered"] >= 2 * 22 * 12 * 2     # both ranks' finished games reached rank 0's buffer
     assert j["trainer_updates"] == 4                               # one 2048-row update per 4 steps, inside the window
+    assert j["multi_gpu"]["ring_ranks"] == "0"                     # with a trainer only its rank expands the records into a dense ring
     assert j["value"] > 0
 
 
@@ -110,10 +159,22 @@ def test_bench_single_gpu_line_contract():
     mb = j["move_boundary"]
     assert mb["in_window"] == 1 and mb["games_finished"] >= 22 and mb["rows_harvested_rank0"] >= 22 * 12 * 2
     assert mb["ms_events"] > 0 and mb["ms_host"] > 0 and j["moves_per_sec"] > 0
+    # the headline fraction is THIS run's measurement (HIP events minus the floor); the committed rocprofv3 figure has its own name
+    assert "live" in rf["duration_source"] and rf["avg_launch_us"] > 0 and rf["avg_launch_us_hip_events_raw"] >= rf["avg_launch_us"]
+    assert "frac_at_committed_rocprofv3_duration" in rf and rf["frac_hip_events_raw"] <= rf["frac"]
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    # the split net / rules / tree of a CPU playout, and the same loop with a constant-time stub evaluator
+    sp = cb["split"]
+    assert 0.5 < sp["net"] < 1.0 and 0 < sp["rules"] < 0.2 and 0 < sp["tree"] < 0.2 and abs(sp["net"] + sp["rules"] + sp["tree"] + sp["python_glue"] - 1.0) < 1e-6
+    assert cb["stub"]["value"] > 20 * cb["value"] and cb["stub"]["unit"] == "sims/s"
     nr = j["net_roofline"]
     assert nr["bound"] == "mfma" and nr["peak"] == 2500.0 and 0 < nr["frac"] < 1
+    # the tower figure describes the timed window: its launches fit in the step they are part of; the post-window full-batch
+    # figure is kept under its own name
+    assert "in the window" in nr["duration_source"] and nr["launches_per_step"] * nr["avg_launch_us"] <= j["ms_per_step"] * 1e3
+    assert nr["rows_per_launch"] <= 256 and 0 < nr["frac_full_batch"] < 1
+    assert j["error_flags_any"] == 0
     assert j["plies"]["start_mean"] > 3
 
 

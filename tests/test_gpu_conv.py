@@ -145,9 +145,9 @@ def test_fused_tower_matches_reference_architecture_and_miopen_path(monkeypatch)
         inf = InferenceNet(net).to(dev).eval()
         assert inf._use_fused_tower(torch.empty(B, 256, 10, 9, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last))
         p_f, v_f = inf(x.half())
-        monkeypatch.setenv("CCZ_FUSED_CONV", "0")
+        inf.set_options(fused_conv=False)
         p_m, v_m = inf(x.half())
-        monkeypatch.delenv("CCZ_FUSED_CONV")
+        inf.set_options(fused_conv=True)
         lg_f, _ = inf(x.half(), return_logits=True)
     assert (logp.exp() - p_f).abs().max().item() < 2e-3 and (v.view(-1) - v_f).abs().max().item() < 2e-2
     assert (p_m - p_f).abs().max().item() < 2e-3 and (v_m - v_f).abs().max().item() < 2e-2
@@ -166,7 +166,7 @@ def test_fused_tower_board_ranges_on_several_streams_equal_one_chain(monkeypatch
     net = Net(256, 2).to(dev).eval()
     inf = InferenceNet(net).to(dev).eval()
     for B in (600, 608):   # 600 boards: board-major rows, 256-pixel tiles; 608 = 38 groups of 16: the group-of-16 layout (forced)
-        monkeypatch.setenv("CCZ_CONV_LAYOUT", "g16" if B == 608 else "auto")
+        inf.set_options(layout="g16" if B == 608 else "auto")
         x0 = torch.relu(torch.randn(B, 256, 10, 9, device=dev)).half().contiguous(memory_format=torch.channels_last)
         outs = []
         for chains in (1, 8, 3):

@@ -80,11 +80,11 @@ def test_fused_evaluator_at_full_depth_is_no_worse_than_the_reference_autocast_p
         assert inf._use_fused_tower(torch.empty((B, 256, 10, 9), dtype=torch.float16, device=dev).contiguous(memory_format=torch.channels_last))
         p16, v16 = inf(x)                                      # this build: stem + tower on k_conv3x3_c256, BN folded
         logits, v16b = inf(x, return_logits=True)
-        os.environ["CCZ_FUSED_CONV"] = "0"                     # same folded weights through MIOpen + the one-pass epilogue
+        inf.set_options(fused_conv=False)                      # same folded weights through MIOpen + the one-pass epilogue
         try:
             p_mi, v_mi = inf(x)
         finally:
-            del os.environ["CCZ_FUSED_CONV"]
+            inf.set_options(fused_conv=True)
     assert torch.isfinite(p16).all() and torch.isfinite(v16).all() and torch.equal(v16, v16b)
     assert torch.allclose(torch.softmax(logits.float(), 1), p16, atol=1e-6)
     act = float(v32.abs().mean())
@@ -138,7 +138,7 @@ def test_tower_activations_do_not_depend_on_the_batch_size(monkeypatch):
     probe = x[123:124].clone()
     outs = []
     for B, layout in ((1, "auto"), (24, "auto"), (90, "auto"), (300, "auto"), (700, "auto"), (90, "g16"), (300, "g16")):
-        monkeypatch.setenv("CCZ_CONV_LAYOUT", layout)
+        inf.set_options(layout=layout)
         assert inf._g16(B) == (B >= 640 or (layout == "g16" and B > 64))
         xb = x[:B].clone()
         xb[B // 2] = probe[0]
@@ -202,7 +202,7 @@ def test_both_row_layouts_give_the_same_evaluation(monkeypatch):
     n_rows = torch.tensor([3000], dtype=torch.int32, device=dev)
     out = {}
     for layout in ("g16", "nhwc"):
-        monkeypatch.setenv("CCZ_CONV_LAYOUT", layout)
+        pvn._infer.set_options(layout=layout)
         full = pvn.evaluate_leaves_logits(x)
         part = pvn._infer.tower_activations(x[:3990].contiguous())
         plan = pvn.evaluate_leaves_logits(x, plan=(rows, n_rows))

@@ -25,7 +25,7 @@ class LinearEvaluator:
         return torch.softmax(x @ self.W, dim=1).contiguous(), torch.tanh(x @ self.w).contiguous()
 
 
-@pytest.mark.parametrize("mode", ["dense_eager", "net_logits_hipgraph"])
+@pytest.mark.parametrize("mode", ["dense_eager", "net_logits_hipgraph", "net_planned_cache_verify"])
 def test_full_games_replay_on_oracle(mode):
     from oracle import OracleBoard
     from chinesechesszero_amd.selfplay import BatchedSelfPlay
@@ -33,12 +33,20 @@ def test_full_games_replay_on_oracle(mode):
     if mode == "dense_eager":
         ev = LinearEvaluator(torch.device("cuda", 0))
         sp = BatchedSelfPlay(ev, B, n_playout=n, seed=42, max_plies=max_plies)
-    else:   # the real evaluator boundary: PyTorch net -> logits -> ccz_gather_priors, replayed as a hipGraph
+    elif mode == "net_logits_hipgraph":   # the real evaluator boundary: PyTorch net -> logits -> ccz_gather_priors, replayed as a hipGraph
         from chinesechesszero_amd.net import PolicyValueNet
         torch.manual_seed(5)
         pvn = PolicyValueNet(device="cuda:0", num_channels=32, resblocks_num=2)
         B, n_moves = 64, 260
         sp = BatchedSelfPlay(pvn.evaluate_leaves_logits, B, n_playout=n, seed=43, max_plies=max_plies, use_graph=True)
+    else:   # the planned boundary on the hand-written tower kernels (256 wide) with the evaluation cache in its verify mode: whole
+        # games, restarts, thousands of table hits of which ~1 % are evaluated again and must come back bit-identical
+        from chinesechesszero_amd.net import PolicyValueNet
+        torch.manual_seed(6)
+        pvn = PolicyValueNet(device="cuda:0", num_channels=256, resblocks_num=1)
+        B, n_moves = 80, 260
+        sp = BatchedSelfPlay(pvn.evaluate_leaves_logits, B, n_playout=n, seed=44, max_plies=max_plies, eval_cache_log2=16, cache_verify=True)
+        assert sp.planned
     e = sp.engine
     games = [[] for _ in range(B)]
     finished = decisive = natural_draws = truncated = rows_total = 0
@@ -91,6 +99,8 @@ def test_full_games_replay_on_oracle(mode):
     s = e.stats()
     e.check_healthy()
     assert s["games"] == finished and s["truncated_games"] == truncated
+    if mode == "net_planned_cache_verify":
+        assert s["cache_hits"] > 1000 and s["cache_verified"] > 10 and s["cache_verify_mismatches"] == 0, s
     assert finished >= B and (decisive + natural_draws > 0 or mode != "dense_eager"), (finished, decisive, natural_draws, truncated)
     print("soak:", dict(finished=finished, decisive=decisive, draws=natural_draws, truncated=truncated, rows=rows_total,
                         depth_peak=s["depth_peak"], nodes_peak=s["nodes_peak"]))
