@@ -21,6 +21,7 @@ MAX_LEGAL = 128
 MASK_WORDS = 66
 PLANES = 10710
 REC_BYTES, REC_HDR, REC_IDS, REC_PI = 880, 96, 112, 368  # compact ply record (include/cczero.h CCZ_REC_*)
+HEAD_POL_STRIDE, HEAD_VAL_STRIDE = 1536, 640  # CCZ_HEAD_*_STRIDE: fp16 elements per board of the head kernels' outputs
 
 ABI_VERSION = 5
 CONV_RELU, CONV_DESCENDING, CONV_FORCE_SMALL, CONV_FORCE_TILE, CONV_G16 = 1, 2, 16, 32, 64  # CCZ_CONV_* flag bits
@@ -111,6 +112,9 @@ PROTOTYPES = {
     "ccz_pack_conv_weights_g16_f16": (C.c_int, [_P, _P, _P, C.c_int32]),
     "ccz_conv3x3_c256_f16_live": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, _P, C.c_int32, C.c_int32]),
     "ccz_conv3x3_stem_f16_live": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int32, _P, C.c_int32, C.c_int32]),
+    "ccz_heads_conv1x1_f16": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
+    "ccz_fc_f16": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "ccz_value_out_f32": (C.c_int, [_P, _P, _P, C.c_float, _P, C.c_int32, _P]),
 }
 
 _lib = None

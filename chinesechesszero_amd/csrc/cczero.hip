@@ -17,6 +17,7 @@
 #include "cczero_conv.h"
 #include "cczero_conv_small.h"
 #include "cczero_conv_g16.h"
+#include "cczero_heads.h"
 #ifdef CCZ_CONV3 // round 3's form without a barrier per half-step: measured slower, A-B builds only (make ab NAME=v3 ABFLAGS=-DCCZ_CONV3)
 #include "../../profiles/experiments/cczero_conv3.h"
 #endif
@@ -936,5 +937,55 @@ int ccz_debug_stamps(ccz_engine *e, void *stream, unsigned long long *out_host)
     return 0;
 }
 #endif
+
+int ccz_heads_conv1x1_f16(void *stream, const void *x_dev, const void *w32_dev, const void *bias32_f32_dev, void *pol_dev, void *val_dev,
+                          int32_t n_boards, int32_t flags, const int32_t *live_boards_dev)
+{
+    if (!x_dev || !w32_dev || !bias32_f32_dev || !pol_dev || !val_dev || n_boards < 0) return fail(-1, "ccz_heads_conv1x1_f16: bad arguments");
+    if ((((uintptr_t)x_dev) | ((uintptr_t)w32_dev) | ((uintptr_t)bias32_f32_dev)) & 15) return fail(-1, "ccz_heads_conv1x1_f16: x, weights and bias must be 16-byte aligned");
+    if (flags & ~CCZ_CONV_G16) return fail(-1, "ccz_heads_conv1x1_f16: unknown flags 0x%x", flags);
+    const bool g16 = (flags & CCZ_CONV_G16) != 0;
+    if (g16 && (n_boards & 15)) return fail(-1, "ccz_heads_conv1x1_f16: the group-of-16 layout holds whole groups of 16 boards (n_boards = %d)", n_boards);
+    if (n_boards == 0) return 0;
+    const long cells = ((long)n_boards * 90 + 15) / 16;
+    const unsigned blocks = (unsigned)((cells + 3) / 4 < 1024 ? (cells + 3) / 4 : 1024);
+    if (g16)
+        hipLaunchKernelGGL(k_head_conv1x1<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w32_dev,
+                           (const float *)bias32_f32_dev, (_Float16 *)pol_dev, (_Float16 *)val_dev, (int)n_boards, (const int *)live_boards_dev);
+    else
+        hipLaunchKernelGGL(k_head_conv1x1<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w32_dev,
+                           (const float *)bias32_f32_dev, (_Float16 *)pol_dev, (_Float16 *)val_dev, (int)n_boards, (const int *)live_boards_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ccz_fc_f16(void *stream, const void *a_dev, int32_t lda, const void *w_dev, const void *bias_f32_dev, void *c_dev, int32_t ldc,
+               int32_t m, int32_t n, int32_t k, int32_t relu, const int32_t *live_rows_dev)
+{
+    if (!a_dev || !w_dev || !bias_f32_dev || !c_dev || m < 0 || n <= 0 || k <= 0) return fail(-1, "ccz_fc_f16: bad arguments");
+    if ((k & 63) || (lda & 7) || lda < k || (n & 1) || (ldc & 1) || ldc < n) return fail(-1, "ccz_fc_f16: k must be a multiple of 64, lda a multiple of 8 and >= k, n and ldc even, ldc >= n");
+    if ((((uintptr_t)a_dev) | ((uintptr_t)w_dev) | ((uintptr_t)bias_f32_dev)) & 15 || ((uintptr_t)c_dev & 3)) return fail(-1, "ccz_fc_f16: a, w, bias must be 16-byte aligned, c 4-byte aligned");
+    if (m == 0) return 0;
+    const dim3 grid((unsigned)((n + kFcBN - 1) / kFcBN), (unsigned)((m + kFcBM - 1) / kFcBM));
+    if (relu)
+        hipLaunchKernelGGL(k_fc_f16<true>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16 *)a_dev, (int)lda, (const _Float16 *)w_dev,
+                           (const float *)bias_f32_dev, (_Float16 *)c_dev, (int)ldc, (int)m, (int)n, (int)k, (const int *)live_rows_dev);
+    else
+        hipLaunchKernelGGL(k_fc_f16<false>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16 *)a_dev, (int)lda, (const _Float16 *)w_dev,
+                           (const float *)bias_f32_dev, (_Float16 *)c_dev, (int)ldc, (int)m, (int)n, (int)k, (const int *)live_rows_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ccz_value_out_f32(void *stream, const void *h_dev, const void *w2_dev, float b2, float *v_dev, int32_t m, const int32_t *live_rows_dev)
+{
+    if (!h_dev || !w2_dev || !v_dev || m < 0) return fail(-1, "ccz_value_out_f32: bad arguments");
+    if ((((uintptr_t)h_dev) | ((uintptr_t)w2_dev)) & 7) return fail(-1, "ccz_value_out_f32: h and w2 must be 8-byte aligned");
+    if (m == 0) return 0;
+    hipLaunchKernelGGL(k_value_out, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)h_dev, (const _Float16 *)w2_dev, b2, v_dev,
+                       (int)m, (const int *)live_rows_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 
 } // extern "C"

@@ -1,0 +1,226 @@
+// cczero_heads.h -- the evaluator's tail as three kernels: both 1x1 head convolutions, the fully connected layers, tanh.
+//
+//   policy = relu(bn(conv1x1(x, 256 -> 17)));  logits = fc(flatten(policy), 1530 -> 2086)            (reference net.py:96-99)
+//   value  = relu(bn(conv1x1(x, 256 -> 7)));   v = tanh(fc2(relu(fc1(flatten(value), 630 -> 256)), 256 -> 1))   (net.py:101-109)
+//
+// Round 3 ran this part through torch (one GEMM for both 1x1 convolutions, a permuting copy out of the group-of-16 row order,
+// four slicing / casting copies, two hipBLASLt GEMMs, tanh): 0.21 ms of a 21.7 ms step, always on all 4096 rows, and the
+// one piece of the evaluator whose result for a board could depend on the batch it sat in (a library GEMM picks its kernel and
+// its split of K by the problem size). Here:
+//
+//   * k_head_conv1x1 reads the tower's rows ONCE (189 MB at 4096 boards: the HBM / Infinity-Cache-bound part) in whatever row
+//     order the tower ran in and writes [board][pos][17] and [board][pos][7] fp16 in BOARD order: the g16 -> board permutation,
+//     bias, ReLU and the policy / value split happen in its epilogue. One wave per 16-row cell, weights (24 x 256, padded to 32)
+//     held in registers as MFMA A fragments for the wave's whole life, the next cell's rows in flight while this one multiplies.
+//   * k_fc_f16 is a plain tiled MFMA GEMM C[m, n] = act(bias[n] + sum_k A[m, k] W[n, k]) (128 x 128 x 64 tiles, double-buffered
+//     LDS, XOR-swizzled rows) for the policy FC (K = 1530 padded to 1536) and the first value FC (K = 630 padded to 640).
+//   * k_value_out: the 256 -> 1 layer + tanh, one wave per board.
+//
+// All three take the device-side live-row count of the planned evaluator boundary (ccz_eval_plan): rows past it are not computed.
+// Every output element is one fixed chain of MFMAs over k = 0, 32, 64, ... whatever the batch size, tile or wave it lands in, so a
+// board's logits and value do not depend on the batch it is evaluated in (tests/test_gpu_evaluator_depth.py) -- which is what the
+// evaluation cache assumes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cczero_conv.h"
+#include "cczero_device.h"
+
+namespace ccz {
+
+constexpr int kHdPol = 17, kHdVal = 7;        // head channels (net.py:12 PLAYS, net.py:11 PIECES)
+constexpr int kHdPolStride = 1536;            // fp16 elements per board of the policy-head output: 90 * 17 = 1530 + 6 zeros
+constexpr int kHdValStride = 640;             // ... of the value-head output: 90 * 7 = 630 + 10 zeros
+
+// X: tower rows [n_rows][256] fp16 (NHWC: row = board * 90 + pos; G16: row = (g * 90 + pos) * 16 + j for board 16 g + j).
+// Wh: [32][256] fp16, rows 0..16 policy, 17..23 value, 24..31 zero; bh: float [32]. pol / val: [boards][kHdPolStride / kHdValStride].
+// live: device count of live boards (rows of boards past it are skipped) or nullptr.
+template <bool G16>
+__global__ __launch_bounds__(256) void k_head_conv1x1(const _Float16 *__restrict__ X, const _Float16 *__restrict__ Wh,
+                                                        const float *__restrict__ bh, _Float16 *__restrict__ pol,
+                                                        _Float16 *__restrict__ val, int n_boards, const int *__restrict__ live)
+{
+    const int lane = threadIdx.x & 63, r = lane & 15, q4 = lane >> 4;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    int nb = n_boards;
+    if (live) { const int l = *live; nb = l < nb ? l : nb; }
+    const long n_rows = G16 ? (long)((nb + 15) >> 4) * 1440 : (long)nb * 90;
+    const int n_cells = (int)((n_rows + 15) >> 4);
+    if (wave >= n_cells) return;
+    // weights as A fragments: [row block m][k-step s]: row m * 16 + r, k = s * 32 + q4 * 8 .. + 7
+    cv_half8 a[2][8];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) a[m][s] = *(const cv_half8 *)(Wh + (m * 16 + r) * 256 + s * 32 + q4 * 8);
+    float4 bias[2];
+    bias[0] = *(const float4 *)(bh + 4 * q4);
+    bias[1] = *(const float4 *)(bh + 16 + 4 * q4);
+    auto load = [&](int cell, cv_half8 (&b)[8]) {
+        long row = (long)cell * 16 + r;
+        row = row < n_rows ? row : n_rows - 1; // (a clamped row is computed and not stored)
+        const _Float16 *src = X + row * 256 + q4 * 8;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) b[s] = *(const cv_half8 *)(src + s * 32);
+    };
+    cv_half8 b[8], bn[8];
+    load(wave, b);
+    for (int cell = wave; cell < n_cells; cell += n_waves) {
+        const int next = cell + n_waves;
+        if (next < n_cells) load(next, bn);
+        cv_f32x4 acc0, acc1;
+        acc0[0] = bias[0].x; acc0[1] = bias[0].y; acc0[2] = bias[0].z; acc0[3] = bias[0].w;
+        acc1[0] = bias[1].x; acc1[1] = bias[1].y; acc1[2] = bias[1].z; acc1[3] = bias[1].w;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][s], b[s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1][s], b[s], acc1, 0, 0, 0);
+        }
+        // lane: channels 4 q4 .. + 3 (acc0) and 16 + 4 q4 .. + 3 (acc1) of row cell * 16 + r
+        int board, pos;
+        if (G16) {
+            const int g = cell / 90;
+            pos = cell - g * 90;
+            board = g * 16 + r;
+        } else {
+            const long row = (long)cell * 16 + r;
+            board = (int)(row / 90);
+            pos = (int)(row - (long)board * 90);
+        }
+        if (board < nb) {
+            _Float16 *po = pol + (long)board * kHdPolStride + pos * kHdPol;
+            _Float16 *vo = val + (long)board * kHdValStride + pos * kHdVal;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) po[4 * q4 + e] = (_Float16)fmaxf(acc0[e], 0.0f);
+            if (q4 == 0) {
+                po[16] = (_Float16)fmaxf(acc1[0], 0.0f);
+                vo[0] = (_Float16)fmaxf(acc1[1], 0.0f);
+                vo[1] = (_Float16)fmaxf(acc1[2], 0.0f);
+                vo[2] = (_Float16)fmaxf(acc1[3], 0.0f);
+            } else if (q4 == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vo[3 + e] = (_Float16)fmaxf(acc1[e], 0.0f);
+            }
+        }
+        if (next < n_cells) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) b[s] = bn[s];
+        }
+    }
+}
+
+// C[m, n] = act(bias[n] + sum_k A[m, k] W[n, k]); A [M][lda] fp16, W [ceil(N / 128) * 128][K] fp16 (rows past N zero), K a
+// multiple of 64, bias float [ceil(N / 128) * 128], C [M][ldc] fp16 (N and ldc even). grid (ceil(N / 128), ceil(M / 128)).
+constexpr int kFcBM = 128, kFcBN = 128, kFcBK = 64;
+constexpr int kFcTile = kFcBN * kFcBK * 2; // bytes of one operand tile (128 rows of 128 B)
+template <bool RELU>
+__global__ __launch_bounds__(256) void k_fc_f16(const _Float16 *__restrict__ A, int lda, const _Float16 *__restrict__ W,
+                                                  const float *__restrict__ bias, _Float16 *__restrict__ C, int ldc, int M, int N,
+                                                  int K, const int *__restrict__ live)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * kFcTile]; // [buffer][W tile | A tile]
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q4 = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wv & 1, wm = wv >> 1;
+    const int n0 = blockIdx.x * kFcBN, m0 = blockIdx.y * kFcBM;
+    int Ml = M;
+    if (live) { const int l = *live; Ml = l < Ml ? l : Ml; }
+    if (m0 >= Ml) return;
+    // staging: thread t moves chunks j * 256 + t (j = 0..3) of each operand tile: row = idx >> 3, 16-byte chunk c = idx & 7,
+    // stored at chunk c ^ ((row >> 1) & 7) of its 128-byte row: the 16 rows a fragment read touches land on 16 distinct granules
+    const _Float16 *wsrc[4], *asrc[4];
+    int dst[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = j * 256 + tid, row = idx >> 3, c = idx & 7;
+        wsrc[j] = W + (long)(n0 + row) * K + c * 8;
+        int m = m0 + row;
+        m = m < Ml ? m : Ml - 1; // (rows past the live ones are computed from a clamped row and not stored)
+        asrc[j] = A + (long)m * lda + c * 8;
+        dst[j] = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
+    }
+    cv_half8 gw[4], ga[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { gw[j] = *(const cv_half8 *)(wsrc[j] + k0); ga[j] = *(const cv_half8 *)(asrc[j] + k0); }
+    };
+    auto lstore = [&](int buf) {
+        unsigned char *base = lds + buf * 2 * kFcTile;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { *(cv_half8 *)(base + dst[j]) = gw[j]; *(cv_half8 *)(base + kFcTile + dst[j]) = ga[j]; }
+    };
+    // accumulators start at the bias: acc[i][j] = n tile i (rows n0 + wn * 64 + i * 16 + 4 q4 .. + 3) x m tile j (column m0 + wm * 64 + j * 16 + r)
+    cv_f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 bv = *(const float4 *)(bias + n0 + wn * 64 + i * 16 + 4 * q4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[i][j][0] = bv.x; acc[i][j][1] = bv.y; acc[i][j][2] = bv.z; acc[i][j][3] = bv.w; }
+    }
+    const int nk = K / kFcBK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload((kt + 1) * kFcBK);
+        const unsigned char *wb = lds + (kt & 1) * 2 * kFcTile, *ab = wb + kFcTile;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            cv_half8 fa[4], fb[4];
+            const int c = kh * 4 + q4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wn * 64 + i * 16 + r;
+                fa[i] = *(const cv_half8 *)(wb + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wm * 64 + j * 16 + r;
+                fb[j] = *(const cv_half8 *)(ab + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore((kt + 1) & 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + r;
+        if (m >= Ml) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + 4 * q4;
+            typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+            half2_t lo, hi;
+            float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+            if (RELU) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f); }
+            lo[0] = (_Float16)v0; lo[1] = (_Float16)v1; hi[0] = (_Float16)v2; hi[1] = (_Float16)v3;
+            _Float16 *out = C + (long)m * ldc + n;
+            if (n + 1 < N) *(half2_t *)out = lo;
+            if (n + 3 < N) *(half2_t *)(out + 2) = hi;
+        }
+    }
+}
+
+// v[m] = tanh(fp16(b2 + sum_k h[m, k] w2[k])), h [M][256] fp16 (the first value FC's ReLU output), one wave per board
+// (reference net.py:107-109: value_fc2 -> tanh; the fp16 rounding in front of tanh is the fp16 linear layer's output rounding).
+__global__ __launch_bounds__(256) void k_value_out(const _Float16 *__restrict__ h, const _Float16 *__restrict__ w2, float b2,
+                                                    float *__restrict__ v, int M, const int *__restrict__ live)
+{
+    const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int Ml = M;
+    if (live) { const int l = *live; Ml = l < Ml ? l : Ml; }
+    if (m >= Ml) return;
+    const cv_half4 x = *(const cv_half4 *)(h + (long)m * 256 + lane * 4), w = *(const cv_half4 *)(w2 + lane * 4);
+    float s = (float)x[0] * (float)w[0];
+    s += (float)x[1] * (float)w[1];
+    s += (float)x[2] * (float)w[2];
+    s += (float)x[3] * (float)w[3];
+    s = wave_sum_f32(s) + b2;
+    if (lane == 0) v[m] = tanhf((float)(_Float16)s);
+}
+
+} // namespace ccz

@@ -184,6 +184,31 @@ class InferenceNet(nn.Module):
         self.value_fc1_b = nn.Parameter(net.value_fc1.bias.detach().to(dtype), requires_grad=False)
         self.value_fc2_w = nn.Parameter(net.value_fc2.weight.detach().to(dtype), requires_grad=False)
         self.value_fc2_b = nn.Parameter(net.value_fc2.bias.detach().to(dtype), requires_grad=False)
+        # the same weights laid out for the hand-written head kernels (csrc/cczero_heads.h; include/cczero.h ccz_heads_conv1x1_f16,
+        # ccz_fc_f16, ccz_value_out_f32): head convolutions as ONE [32, 256] matrix (17 policy + 7 value rows + 8 zero rows), FC
+        # weights with their input columns in (pos, channel) order zero-padded to the kernels' K granule (1530 -> 1536, 630 -> 640)
+        # and their rows to whole 128-row tiles, biases in float32 (added to the fp32 accumulator)
+        if C_in == 256 and dtype == torch.float16:
+            w32 = torch.zeros(32, C_in, dtype=torch.float64)
+            w32[:PLAYS + PIECES] = torch.cat([wp, wv], 0).reshape(PLAYS + PIECES, C_in)
+            b32 = torch.zeros(32, dtype=torch.float64)
+            b32[:PLAYS + PIECES] = torch.cat([bp, bv], 0)
+            self.head_w32 = nn.Parameter(w32.to(dtype), requires_grad=False)
+            self.head_b32 = nn.Parameter(b32.float(), requires_grad=False)
+
+            def padded(w, rows, cols):
+                out = torch.zeros(rows, cols, dtype=dtype)
+                out[:w.shape[0], :w.shape[1]] = w.to(dtype)
+                return out
+
+            def padded_bias(b, rows):
+                out = torch.zeros(rows, dtype=torch.float32)
+                out[:b.shape[0]] = b.detach().to(dtype).float()   # (the fp16-rounded bias the torch path adds)
+                return out
+            self.policy_fc_wp = nn.Parameter(padded(pc(net.policy_fc.weight, PLAYS), 2176, 1536), requires_grad=False)
+            self.policy_fc_b32 = nn.Parameter(padded_bias(net.policy_fc.bias, 2176), requires_grad=False)
+            self.value_fc1_wp = nn.Parameter(padded(pc(net.value_fc1.weight, PIECES), 256, 640), requires_grad=False)
+            self.value_fc1_b32 = nn.Parameter(padded_bias(net.value_fc1.bias, 256), requires_grad=False)
 
     def set_options(self, **kw):
         """Change A/B switches of a live object (tests, profile scripts): ``set_options(layout="g16", fused_conv=False)``;
@@ -219,6 +244,7 @@ class InferenceNet(nn.Module):
                 dst.copy_(pack_conv_weights_g16(w.permute(0, 2, 3, 1)))
         if hasattr(self, "stem_w64_g16"):
             self.stem_w64_g16.copy_(pack_conv_weights_g16(self.stem_w64))
+        self.__dict__.pop("_b2", None)
 
     def _epilogue(self, y, bias, residual=None):
         """relu(y + bias [+ residual]) in ONE pass (libcczero ccz_bias_act_f16) on NHWC fp16 device tensors;
@@ -505,9 +531,49 @@ class InferenceNet(nn.Module):
                     x = self._epilogue(F.conv2d(y, self.ws[i + 1], None, padding=1), self.bs[i + 1], x)
         return self._heads(x, B, g16, plan, return_logits)
 
+    def _heads_fused(self, x, B, g16, plan):
+        """The evaluator's tail on the hand-written kernels (csrc/cczero_heads.h): both 1x1 head convolutions + ReLU + the
+        group-of-16 -> board permutation in ONE pass over the tower's rows, the two big FC layers as MFMA GEMMs, value_fc2 + tanh
+        -- on the LIVE rows only (``plan``: a device-side count), the same bits for a board at every batch size. Returns
+        (logits fp16 [B, 2086], value float32 [B])."""
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        Bx, dev = x.shape[0], x.device
+        bufs = self.__dict__.setdefault("_head_bufs", {})
+        key = (Bx, dev)
+        if key not in bufs:   # the pad columns (never written) must be zero: allocated once, zeroed once
+            bufs[key] = (torch.zeros((Bx, _lib.HEAD_POL_STRIDE), dtype=torch.float16, device=dev),
+                         torch.zeros((Bx, _lib.HEAD_VAL_STRIDE), dtype=torch.float16, device=dev),
+                         torch.empty((Bx, 256), dtype=torch.float16, device=dev))
+        pol, val, h1 = bufs[key]
+        logits = torch.empty((B, 2086), dtype=torch.float16, device=dev)
+        v = torch.empty((B,), dtype=torch.float32, device=dev)
+        s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        live = C.c_void_p(plan[1].data_ptr()) if plan is not None else None
+        P = lambda t: C.c_void_p(t.data_ptr())
+        _lib.check(L.ccz_heads_conv1x1_f16(s, P(x), P(self.head_w32), P(self.head_b32), P(pol), P(val), Bx, _lib.CONV_G16 if g16 else 0, live))
+        _lib.check(L.ccz_fc_f16(s, P(pol), _lib.HEAD_POL_STRIDE, P(self.policy_fc_wp), P(self.policy_fc_b32), P(logits), 2086, B, 2086, 1536, 0, live))
+        _lib.check(L.ccz_fc_f16(s, P(val), _lib.HEAD_VAL_STRIDE, P(self.value_fc1_wp), P(self.value_fc1_b32), P(h1), 256, B, 256, 640, 1, live))
+        _lib.check(L.ccz_value_out_f32(s, P(h1), P(self.value_fc2_w), self._value_b2(), P(v), B, live))
+        return logits, v
+
+    def _value_b2(self) -> float:
+        """value_fc2's bias as the host float the kernel takes by value (read once; ``repack_derived`` refreshes it)."""
+        b2 = self.__dict__.get("_b2")
+        if b2 is None:
+            b2 = self.__dict__["_b2"] = float(self.value_fc2_b.detach().float().cpu().item())
+        return b2
+
     def _heads(self, x, B, g16, plan, return_logits):
         """Policy / value heads and FC layers (reference net.py:96-109) on the tower's output ``x`` (channels-last rows in memory
         order; ``g16``: group-of-16 row order, padded to whole groups)."""
+        if (self.opt.fused_heads and hasattr(self, "head_w32") and x.is_cuda and x.dtype == torch.float16 and x.shape[1] == 256
+                and x.is_contiguous(memory_format=torch.channels_last)):
+            logits, v = self._heads_fused(x, B, g16, plan)
+            if return_logits:
+                return logits, v
+            return torch.exp(F.log_softmax(logits.float(), dim=1)).contiguous(), v
         Bx = x.shape[0]
         rows = x.permute(0, 2, 3, 1).reshape(Bx * 90, x.shape[1])   # a view of the activations in memory order: one row per pixel
         h = F.relu_(torch.addmm(self.head_b, rows, self.head_wT))

@@ -414,6 +414,32 @@ int ccz_conv3x3_stem_f16_live(void *stream, const void *x64_dev, const void *w_d
                               void *y_dev, int64_t n_pixels, int32_t relu, const int32_t *live_rows_dev,
                               int32_t part, int32_t n_parts);
 
+/* ---- the evaluator's tail: head convolutions, fully connected layers, tanh (reference net.py:96-109) -------------------------
+ * Hand-written like the tower so that (1) only the LIVE rows of a planned batch are computed, (2) the group-of-16 -> board
+ * permutation, bias, ReLU and the policy / value split cost no passes of their own, and (3) a board's logits and value are the
+ * same bits at every batch size (each output element is one fixed chain of MFMAs over k = 0, 32, 64, ...).
+ *
+ * ccz_heads_conv1x1_f16: both 1x1 head convolutions (policy_conv 256 -> 17, value_conv 256 -> 7, BatchNorm folded) + ReLU on the
+ *   tower's output rows x [n_boards * 90, 256] fp16 (NHWC rows, or the group-of-16 row order with flags = CCZ_CONV_G16: n_boards
+ *   a multiple of 16). w32: [32, 256] fp16, rows 0..16 = policy channels, 17..23 = value channels, 24..31 zero; bias32: float
+ *   [32]. Outputs in BOARD order: pol [n_boards, 1536] fp16 = (pos, channel)-major 90 x 17 values + 6 pad elements that are
+ *   never written (keep them zero), val [n_boards, 640] fp16 = 90 x 7 values + 10 pad. live_boards_dev: device int32 count of
+ *   live boards (rows of boards past it are skipped) or NULL.
+ * ccz_fc_f16: c[m, n] = act(bias[n] + sum_k a[m, k] * w[n, k]): a [m, lda] fp16, w [ceil(n / 128) * 128, k] fp16 with zero rows
+ *   past n, bias float [ceil(n / 128) * 128], c [m, ldc] fp16; k a multiple of 64 (zero-pad the columns of w), n and ldc even;
+ *   relu != 0 applies ReLU. policy_fc: a = pol, k = 1536, n = 2086; value_fc1: a = val, k = 640, n = 256, relu. The FC weights'
+ *   input columns are in (pos, channel) order (the reference flattens (channel, pos): net.py:98,103).
+ * ccz_value_out_f32: v[m] = tanh(fp16(b2 + sum_k h[m, k] * w2[k])), h [m, 256] fp16, w2 fp16 [256] (value_fc2 + tanh, net.py:107-109).
+ * live_rows_dev as above (rows past *live_rows_dev are not computed) or NULL. Asynchronous on `stream`. */
+#define CCZ_HEAD_POL_STRIDE 1536
+#define CCZ_HEAD_VAL_STRIDE 640
+int ccz_heads_conv1x1_f16(void *stream, const void *x_dev, const void *w32_dev, const void *bias32_f32_dev, void *pol_dev,
+                          void *val_dev, int32_t n_boards, int32_t flags, const int32_t *live_boards_dev);
+int ccz_fc_f16(void *stream, const void *a_dev, int32_t lda, const void *w_dev, const void *bias_f32_dev, void *c_dev, int32_t ldc,
+               int32_t m, int32_t n, int32_t k, int32_t relu, const int32_t *live_rows_dev);
+int ccz_value_out_f32(void *stream, const void *h_dev, const void *w2_dev, float b2, float *v_dev, int32_t m,
+                      const int32_t *live_rows_dev);
+
 #ifdef __cplusplus
 }
 #endif

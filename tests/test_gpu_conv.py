@@ -371,3 +371,67 @@ def test_group_of_16_kernel_live_rows(live, n_parts):
     groups = -(-live // 16)
     assert torch.equal(yg[:groups], full[:groups])
     assert torch.isnan(yg[groups:].float()).all()
+
+
+@pytest.mark.parametrize("B,g16", [(1, False), (7, False), (200, False), (48, True), (1040, True)])
+def test_head_kernels_against_float32(B, g16):
+    """csrc/cczero_heads.h against plain float32 torch: both 1x1 head convolutions + bias + ReLU with the board-order output
+    (k_head_conv1x1, either row layout), the FC GEMM with bias / ReLU and K, N tails (k_fc_f16), value_fc2 + tanh (k_value_out);
+    a device-side live-row count leaves the rows past it untouched."""
+    import ctypes as C
+    from chinesechesszero_amd import _lib
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(B)
+    s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    x = torch.relu(torch.randn(B, 90, 256, generator=g)).half()                       # board-major rows [board][pos][256]
+    w = (torch.randn(24, 256, generator=g) * 0.08).half()
+    b = (torch.randn(24, generator=g) * 0.2).float()
+    w32 = torch.zeros(32, 256, dtype=torch.float16)
+    w32[:24] = w
+    b32 = torch.zeros(32)
+    b32[:24] = b
+    want = torch.relu(x.float() @ w.float().t() + b)                                  # [B, 90, 24]
+    xr = x.view(B // 16, 16, 90, 256).permute(0, 2, 1, 3).contiguous() if g16 else x  # group-of-16 rows: (g * 90 + pos) * 16 + j
+    pol = torch.zeros(B, 1536, dtype=torch.float16, device=dev)
+    val = torch.zeros(B, 640, dtype=torch.float16, device=dev)
+    xd, wd, bd = xr.to(dev).contiguous(), w32.to(dev), b32.to(dev)      # (named: a temporary would be recycled before the launch runs)
+    _lib.check(L.ccz_heads_conv1x1_f16(s, P(xd), P(wd), P(bd), P(pol), P(val), B, _lib.CONV_G16 if g16 else 0, None))
+    got_p, got_v = pol.cpu().float(), val.cpu().float()
+    assert torch.allclose(got_p[:, :1530].view(B, 90, 17), want[:, :, :17], atol=2e-3, rtol=2e-3)
+    assert torch.allclose(got_v[:, :630].view(B, 90, 7), want[:, :, 17:], atol=2e-3, rtol=2e-3)
+    assert float(got_p[:, 1530:].abs().max()) == 0 and float(got_v[:, 630:].abs().max()) == 0      # pad columns are never written
+    # with a live count: boards past it keep what they held
+    live_n = max(1, B // 2)
+    live = torch.tensor([live_n], dtype=torch.int32, device=dev)
+    pol2 = torch.full((B, 1536), 7.0, dtype=torch.float16, device=dev)
+    val2 = torch.full((B, 640), 7.0, dtype=torch.float16, device=dev)
+    _lib.check(L.ccz_heads_conv1x1_f16(s, P(xd), P(wd), P(bd), P(pol2), P(val2), B, _lib.CONV_G16 if g16 else 0, P(live)))
+    assert torch.equal(pol2[:live_n, :1530], pol[:live_n, :1530]) and float((pol2[live_n:] - 7.0).abs().max() if live_n < B else 0) == 0
+    # ---- the FC GEMM: policy shape (K 1536, N 2086 = 16 tiles + a 38-column tail) and value shape (K 640, N 256, ReLU)
+    for K, N, relu in ((1536, 2086, 0), (640, 256, 1)):
+        Np = -(-N // 128) * 128
+        a = torch.zeros(B, K, dtype=torch.float16)
+        a[:, :K - 6] = torch.relu(torch.randn(B, K - 6, generator=g)).half()
+        wf = torch.zeros(Np, K, dtype=torch.float16)
+        wf[:N, :K - 6] = (torch.randn(N, K - 6, generator=g) * 0.03).half()
+        bf = torch.zeros(Np)
+        bf[:N] = torch.randn(N, generator=g) * 0.3
+        ref = a.float() @ wf[:N].float().t() + bf[:N]
+        ref = torch.relu(ref) if relu else ref
+        c = torch.full((B, N), 9.0, dtype=torch.float16, device=dev)
+        ad, wfd, bfd = a.to(dev), wf.to(dev), bf.to(dev)
+        _lib.check(L.ccz_fc_f16(s, P(ad), K, P(wfd), P(bfd), P(c), N, B, N, K, relu, None))
+        assert torch.allclose(c.cpu().float(), ref, atol=1.5e-2, rtol=4e-3), (K, N)
+        c2 = torch.full((B, N), 9.0, dtype=torch.float16, device=dev)
+        _lib.check(L.ccz_fc_f16(s, P(ad), K, P(wfd), P(bfd), P(c2), N, B, N, K, relu, P(live)))
+        assert torch.equal(c2[:live_n], c[:live_n]) and (live_n == B or float((c2[live_n:] - 9.0).abs().max()) == 0)
+    # ---- value_fc2 + tanh
+    h = torch.relu(torch.randn(B, 256, generator=g)).half()
+    w2 = (torch.randn(256, generator=g) * 0.1).half()
+    v = torch.full((B,), 5.0, device=dev)
+    hd, w2d = h.to(dev), w2.to(dev)
+    _lib.check(L.ccz_value_out_f32(s, P(hd), P(w2d), 0.125, P(v), B, None))
+    refv = torch.tanh((h.float() @ w2.float() + 0.125).half().float())
+    assert torch.allclose(v.cpu(), refv, atol=2e-3)

@@ -124,12 +124,13 @@ def test_shapes_off_the_fused_path_are_logged(caplog):
     assert not [r for r in caplog.records if "fused" in r.getMessage()]      # 64 boards and ONE board: both on the fused kernels
 
 
-def test_tower_activations_do_not_depend_on_the_batch_size(monkeypatch):
+def test_a_boards_evaluation_does_not_depend_on_the_batch_size(monkeypatch):
     """One board evaluated alone and in a batch of 24 (k_conv3x3_small), of 90 and of 300 (the 256-pixel tile kernel), of 700 (the
     group-of-16 kernel, from 640 boards on) and -- layout forced -- of 90 and 300 on the group-of-16 kernel (padded to whole
     groups): the stem + tower output of that board is the same, bit for bit -- all three kernels add the same products in the same
-    order. (The heads are GEMMs of torch and may pick another kernel per batch size: logits agree to float16 round-off, not bit
-    for bit.)"""
+    order -- and, since round 4, so are its LOGITS and its VALUE: heads and FC layers are hand-written kernels too
+    (csrc/cczero_heads.h), every output element one fixed chain of MFMAs whatever tile it lands in. (Round 3's heads were torch
+    GEMMs that pick a kernel per problem size: float16 round-off apart.)"""
     from chinesechesszero_amd.net import InferenceNet, Net
     dev = torch.device("cuda", 0)
     torch.manual_seed(3)
@@ -146,11 +147,44 @@ def test_tower_activations_do_not_depend_on_the_batch_size(monkeypatch):
         outs.append(t[B // 2].clone())
         lg, v = inf(xb, return_logits=True)
         if B == 1:
-            lg1, v1 = lg[0].float().clone(), v[0].clone()
+            lg1, v1 = lg[0].clone(), v[0].clone()
         else:
-            assert (lg[B // 2].float() - lg1).abs().max().item() < 2e-2 and abs(float(v[B // 2] - v1)) < 2e-3
+            assert torch.equal(lg[B // 2], lg1) and torch.equal(v[B // 2], v1), (B, layout)
     for t in outs[1:]:
         assert torch.equal(t, outs[0])
+    # the torch tail (fused_heads off) agrees to float16 round-off: the kernels compute the reference's layers, not something else
+    inf.set_options(layout="auto", fused_heads=False)
+    lg_t, v_t = inf(probe, return_logits=True)
+    inf.set_options(fused_heads=True)
+    assert (lg_t[0].float() - lg1.float()).abs().max().item() < 2e-2 and abs(float(v_t[0] - v1)) < 2e-3
+
+
+def test_one_board_has_the_same_logits_and_value_at_batch_sizes_1_200_4096_and_on_the_planned_boundary():
+    """The full 40 x 256 evaluator: a position alone, among 200 boards (256-pixel tile kernel), among 4096 (group-of-16 kernel, two
+    concurrent chains) and as a planned row of a 4096-board batch of which 3000 rows are live: bit-identical logits and value.
+    This is what the evaluation cache rests on (a cached evaluation is the evaluation the network would give again, whatever
+    batch the position turns up in), now by construction."""
+    from chinesechesszero_amd.net import PolicyValueNet
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(13)
+    pvn = PolicyValueNet(device=dev)
+    pvn.refresh_inference_copy()
+    x = _leaf_batch(4096, 24, seed=17)
+    probe = x[2222].clone()
+    got = []
+    for B, slot in ((1, 0), (200, 137), (4096, 4095), (4096, 16)):
+        xb = x[:B].clone()
+        xb[slot] = probe
+        lg, v = pvn.evaluate_leaves_logits(xb)
+        got.append((lg[slot].clone(), v[slot].clone()))
+    rows = torch.randperm(4096, device=dev)[:3000].to(torch.int32).contiguous()
+    rows[1234] = 2222
+    n_rows = torch.tensor([3000], dtype=torch.int32, device=dev)
+    lg, v = pvn.evaluate_leaves_logits(x, plan=(rows, n_rows))
+    got.append((lg[1234].clone(), v[1234].clone()))
+    for lg_i, v_i in got[1:]:
+        assert torch.equal(lg_i, got[0][0]) and torch.equal(v_i, got[0][1])
+    assert torch.isfinite(got[0][0].float()).all() and abs(float(got[0][1])) < 1
 
 
 def test_a_boards_evaluation_does_not_depend_on_its_slot_in_the_batch():

@@ -164,9 +164,10 @@ def test_cache_verify_mode_catches_stale_entries():
     sp = BatchedSelfPlay(pvn.evaluate_leaves_logits, B, n_playout=n, seed=4, max_plies=30, eval_cache_log2=18, cache_verify=True)
     e = sp.engine
     sp.run_move()
+    e.reset()                                            # the same openings again: ~30 k hits, ~1 % of them evaluated again
     sp.run_move()
     s = e.stats()
-    assert s["cache_verified"] > 0 and s["cache_verify_mismatches"] == 0
+    assert s["cache_hits"] > 10000 and s["cache_verified"] > 50 and s["cache_verify_mismatches"] == 0
     with torch.no_grad():
         for p in pvn.policy_value_net.parameters():
             p.add_(torch.randn_like(p) * 0.05)
