@@ -882,7 +882,7 @@ int ccz_pack_live_planes_rows_f16(void *stream, const void *leaf_dev, void *x64_
     if ((uintptr_t)x64_dev & 15) return fail(-1, "ccz_pack_live_planes_rows_f16: output must be 16-byte aligned");
     if (n_boards == 0) return 0;
     hipLaunchKernelGGL(k_pack_live_planes, dim3((unsigned)n_boards), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)leaf_dev, (half8_t *)x64_dev, (int)n_boards,
-                       (const int *)rows_dev, (const int *)n_rows_dev, 0);
+                       (const int *)rows_dev, (const int *)n_rows_dev, 2); // planned form: only the chunks that can be non-zero are written
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -903,7 +903,7 @@ int ccz_pack_live_planes_g16_f16(void *stream, const void *leaf_dev, void *x64_d
     if ((uintptr_t)x64_dev & 15) return fail(-1, "ccz_pack_live_planes_g16_f16: output must be 16-byte aligned");
     if (n_boards == 0) return 0;
     hipLaunchKernelGGL(k_pack_live_planes, dim3((unsigned)n_boards), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)leaf_dev, (half8_t *)x64_dev, (int)n_boards,
-                       (const int *)rows_dev, (const int *)n_rows_dev, 1);
+                       (const int *)rows_dev, (const int *)n_rows_dev, rows_dev ? 3 : 1); // planned form: as ccz_pack_live_planes_rows_f16
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -948,7 +948,7 @@ int ccz_heads_conv1x1_f16(void *stream, const void *x_dev, const void *w32_dev, 
     if (g16 && (n_boards & 15)) return fail(-1, "ccz_heads_conv1x1_f16: the group-of-16 layout holds whole groups of 16 boards (n_boards = %d)", n_boards);
     if (n_boards == 0) return 0;
     const long cells = ((long)n_boards * 90 + 15) / 16;
-    const unsigned blocks = (unsigned)((cells + 3) / 4 < 1024 ? (cells + 3) / 4 : 1024);
+    const unsigned blocks = (unsigned)((cells + 3) / 4 < 768 ? (cells + 3) / 4 : 768); // 768 x 4 waves = 3 per SIMD on 256 CUs: all resident, one round
     if (g16)
         hipLaunchKernelGGL(k_head_conv1x1<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w32_dev,
                            (const float *)bias32_f32_dev, (_Float16 *)pol_dev, (_Float16 *)val_dev, (int)n_boards, (const int *)live_boards_dev);
@@ -967,12 +967,12 @@ int ccz_fc_f16(void *stream, const void *a_dev, int32_t lda, const void *w_dev, 
     if ((((uintptr_t)a_dev) | ((uintptr_t)w_dev) | ((uintptr_t)bias_f32_dev)) & 15 || ((uintptr_t)c_dev & 3)) return fail(-1, "ccz_fc_f16: a, w, bias must be 16-byte aligned, c 4-byte aligned");
     if (m == 0) return 0;
     const dim3 grid((unsigned)((n + kFcBN - 1) / kFcBN), (unsigned)((m + kFcBM - 1) / kFcBM));
-    if (relu)
+    if (relu & 1)
         hipLaunchKernelGGL(k_fc_f16<true>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16 *)a_dev, (int)lda, (const _Float16 *)w_dev,
-                           (const float *)bias_f32_dev, (_Float16 *)c_dev, (int)ldc, (int)m, (int)n, (int)k, (const int *)live_rows_dev);
+                           (const float *)bias_f32_dev, (_Float16 *)c_dev, (int)ldc, (int)m, (int)n, (int)k, (const int *)live_rows_dev, (int)(relu >> 8));
     else
         hipLaunchKernelGGL(k_fc_f16<false>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16 *)a_dev, (int)lda, (const _Float16 *)w_dev,
-                           (const float *)bias_f32_dev, (_Float16 *)c_dev, (int)ldc, (int)m, (int)n, (int)k, (const int *)live_rows_dev);
+                           (const float *)bias_f32_dev, (_Float16 *)c_dev, (int)ldc, (int)m, (int)n, (int)k, (const int *)live_rows_dev, (int)(relu >> 8));
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -12,8 +12,8 @@
 //     order the tower ran in and writes [board][pos][17] and [board][pos][7] fp16 in BOARD order: the g16 -> board permutation,
 //     bias, ReLU and the policy / value split happen in its epilogue. One wave per 16-row cell, weights (24 x 256, padded to 32)
 //     held in registers as MFMA A fragments for the wave's whole life, the next cell's rows in flight while this one multiplies.
-//   * k_fc_f16 is a plain tiled MFMA GEMM C[m, n] = act(bias[n] + sum_k A[m, k] W[n, k]) (128 x 128 x 64 tiles, double-buffered
-//     LDS, XOR-swizzled rows) for the policy FC (K = 1530 padded to 1536) and the first value FC (K = 630 padded to 640).
+//   * k_fc_f16 is a plain tiled MFMA GEMM C[m, n] = act(bias[n] + sum_k A[m, k] W[n, k]) (128 x 128 tiles, K through a four-stage
+//     LDS ring filled by global_load_lds, XOR-swizzled rows) for the policy FC (K = 1530 padded to 1536) and the first value FC (K = 630 padded to 640).
 //   * k_value_out: the 256 -> 1 layer + tanh, one wave per board.
 //
 // All three take the device-side live-row count of the planned evaluator boundary (ccz_eval_plan): rows past it are not computed.
@@ -112,42 +112,56 @@ __global__ __launch_bounds__(256) void k_head_conv1x1(const _Float16 *__restrict
 
 // C[m, n] = act(bias[n] + sum_k A[m, k] W[n, k]); A [M][lda] fp16, W [ceil(N / 128) * 128][K] fp16 (rows past N zero), K a
 // multiple of 64, bias float [ceil(N / 128) * 128], C [M][ldc] fp16 (N and ldc even). grid (ceil(N / 128), ceil(M / 128)).
-constexpr int kFcBM = 128, kFcBN = 128, kFcBK = 64;
-constexpr int kFcTile = kFcBN * kFcBK * 2; // bytes of one operand tile (128 rows of 128 B)
+// 128 x 128 output tile per workgroup, 4 waves of 64 x 64 (4 x 4 MFMA tiles); K in steps of 32 through a ring of FOUR 16 KB LDS
+// stages filled by global_load_lds three steps ahead (the first version staged through registers one step ahead: at 16 MFMAs per
+// wave and step the loop waited a memory round trip per step, 48 us for the policy layer). Rows are 64 bytes in LDS: chunk c
+// of row r sits at position c ^ ((r >> 2) & 3) -- applied to the SOURCE address of the DMA, whose LDS side is lane-linear, and to
+// the fragment reads, which are then conflict-free. One raw s_barrier per step, counted vmcnt (never 0 inside the loop).
+constexpr int kFcBM = 128, kFcBN = 128, kFcBK = 32, kFcStages = 4;
+constexpr int kFcTile = 128 * kFcBK * 2;  // bytes of one operand tile of a stage: 128 rows of 64 B
+constexpr int kFcStage = 2 * kFcTile;     // [W tile | A tile]
+constexpr int kFcERow = 144;              // epilogue transpose: bytes per row of a wave's 64 x 64 fp16 block (128 + pad)
+static_assert(4 * 64 * kFcERow <= kFcStages * kFcStage, "the epilogue blocks live in the operand ring");
+#ifdef CCZ_FC_DIAG // ablation switches of the diagnostic build (make ab NAME=fcdiag ABFLAGS=-DCCZ_FC_DIAG; profiles/fc_microbench.py)
+#define FC_DBG(bit) (dbg & (bit))
+#else
+#define FC_DBG(bit) 0
+#endif
 template <bool RELU>
 __global__ __launch_bounds__(256) void k_fc_f16(const _Float16 *__restrict__ A, int lda, const _Float16 *__restrict__ W,
                                                   const float *__restrict__ bias, _Float16 *__restrict__ C, int ldc, int M, int N,
-                                                  int K, const int *__restrict__ live)
+                                                  int K, const int *__restrict__ live, [[maybe_unused]] int dbg)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * kFcTile]; // [buffer][W tile | A tile]
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kFcStages * kFcStage];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q4 = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wv & 1, wm = wv >> 1;
-    const int n0 = blockIdx.x * kFcBN, m0 = blockIdx.y * kFcBM;
     int Ml = M;
     if (live) { const int l = *live; Ml = l < Ml ? l : Ml; }
+    const int n0 = blockIdx.x * kFcBN, m0 = blockIdx.y * kFcBM;
     if (m0 >= Ml) return;
-    // staging: thread t moves chunks j * 256 + t (j = 0..3) of each operand tile: row = idx >> 3, 16-byte chunk c = idx & 7,
-    // stored at chunk c ^ ((row >> 1) & 7) of its 128-byte row: the 16 rows a fragment read touches land on 16 distinct granules
-    const _Float16 *wsrc[4], *asrc[4];
-    int dst[4];
+    // (An XCD-aware tile order -- XCD x owning the m tiles x, x + 8, ... and walking all n tiles over them, so that an XCD's L2
+    // holds its rows of A and every slice of W is fetched once per XCD -- was measured and dropped: 56.6 against 50.8 us for the
+    // policy layer. 29 m tiles over 8 XCDs put 68 tiles on the 64 workgroup slots of five XCDs: a second round for four tiles.)
+    // DMA: per stage and operand 512 sixteen-byte granules = 2 per thread. Instruction j of wave wv fills LDS granules
+    // (j * 4 + wv) * 64 + lane (lane-linear); granule p holds row p >> 2, position p & 3 = source chunk (p & 3) ^ ((row >> 2) & 3)
+    const _Float16 *wsrc[2], *asrc[2];
+    int wdst[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int idx = j * 256 + tid, row = idx >> 3, c = idx & 7;
+    for (int j = 0; j < 2; ++j) {
+        const int row = (j * 4 + wv) * 16 + (lane >> 2), c = (lane & 3) ^ ((lane >> 4) & 3);
         wsrc[j] = W + (long)(n0 + row) * K + c * 8;
         int m = m0 + row;
         m = m < Ml ? m : Ml - 1; // (rows past the live ones are computed from a clamped row and not stored)
         asrc[j] = A + (long)m * lda + c * 8;
-        dst[j] = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
+        wdst[j] = (j * 4 + wv) * 1024;
     }
-    cv_half8 gw[4], ga[4];
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { gw[j] = *(const cv_half8 *)(wsrc[j] + k0); ga[j] = *(const cv_half8 *)(asrc[j] + k0); }
-    };
-    auto lstore = [&](int buf) {
-        unsigned char *base = lds + buf * 2 * kFcTile;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { *(cv_half8 *)(base + dst[j]) = gw[j]; *(cv_half8 *)(base + kFcTile + dst[j]) = ga[j]; }
+    auto issue = [&](int kt) {
+        unsigned char *st = lds + (kt & (kFcStages - 1)) * kFcStage;
+        const int k0 = kt * kFcBK;
+        cv_glds16(wsrc[0] + k0, st + wdst[0]);
+        cv_glds16(wsrc[1] + k0, st + wdst[1]);
+        cv_glds16(asrc[0] + k0, st + kFcTile + wdst[0]);
+        cv_glds16(asrc[1] + k0, st + kFcTile + wdst[1]);
     };
     // accumulators start at the bias: acc[i][j] = n tile i (rows n0 + wn * 64 + i * 16 + 4 q4 .. + 3) x m tile j (column m0 + wm * 64 + j * 16 + r)
     cv_f32x4 acc[4][4];
@@ -158,49 +172,67 @@ __global__ __launch_bounds__(256) void k_fc_f16(const _Float16 *__restrict__ A, 
         for (int j = 0; j < 4; ++j) { acc[i][j][0] = bv.x; acc[i][j][1] = bv.y; acc[i][j][2] = bv.z; acc[i][j][3] = bv.w; }
     }
     const int nk = K / kFcBK;
-    gload(0);
-    lstore(0);
-    __syncthreads();
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
+    // this lane's fragment offset inside a tile: row (wn | wm) * 64 + i * 16 + r, position q4 ^ ((r >> 2) & 3)
+    const int foff = r * 64 + ((q4 ^ ((r >> 2) & 3)) << 4);
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) gload((kt + 1) * kFcBK);
-        const unsigned char *wb = lds + (kt & 1) * 2 * kFcTile, *ab = wb + kFcTile;
+        // stage kt has landed when at most the loads of the two younger stages are outstanding (4 per stage and thread)
+        if (kt + 2 < nk) cv_wait_vm<8>();
+        else if (kt + 1 < nk) cv_wait_vm<4>();
+        else cv_wait_vm<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        if (!FC_DBG(16)) __builtin_amdgcn_s_barrier(); // ... for every wave's part of it; and every wave is done reading stage kt - 1
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 3 < nk && !FC_DBG(4)) issue(kt + 3); // into the slot of stage kt - 1
+        const unsigned char *wb = lds + (kt & (kFcStages - 1)) * kFcStage + wn * 4096 + foff;
+        const unsigned char *ab = lds + (kt & (kFcStages - 1)) * kFcStage + kFcTile + wm * 4096 + foff;
+        cv_half8 fa[4], fb[4];
+        if (!FC_DBG(2) || kt == 0) {
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {
-            cv_half8 fa[4], fb[4];
-            const int c = kh * 4 + q4;
+            for (int i = 0; i < 4; ++i) fa[i] = *(const cv_half8 *)(wb + i * 1024);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = wn * 64 + i * 16 + r;
-                fa[i] = *(const cv_half8 *)(wb + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = wm * 64 + j * 16 + r;
-                fb[j] = *(const cv_half8 *)(ab + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-            }
+            for (int j = 0; j < 4; ++j) fb[j] = *(const cv_half8 *)(ab + j * 1024);
+        }
+        if (!FC_DBG(1)) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][0] += (cv_f32x4){(float)fa[i][0], (float)fb[i][0], 0.0f, 0.0f}; // keep the reads alive
         }
-        if (kt + 1 < nk) lstore((kt + 1) & 1);
-        __syncthreads();
     }
+    if (FC_DBG(8)) { if (acc[0][0][0] == 12345.678f) C[0] = (_Float16)1; return; }
+    // epilogue: a lane holds 4 consecutive n of ONE row m per tile -- stored straight from the registers that is 64 different
+    // cache lines per store instruction, 32 instructions per wave, and the CU's one address unit spent ~8 us on them (ablation:
+    // profiles/r04_fc_microbench.json). So each wave transposes its 64 x 64 block through its own 9 KB of LDS (rows of 144 bytes:
+    // the 8-byte writes of 16 rows fall on different banks) and writes whole 128-byte row segments, two rows per instruction.
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier(); // every wave is done reading the operand stages
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        unsigned char *tb = lds + wv * (64 * kFcERow);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + wm * 64 + j * 16 + r;
-        if (m >= Ml) continue;
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = n0 + wn * 64 + i * 16 + 4 * q4;
-            typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-            half2_t lo, hi;
-            float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
-            if (RELU) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f); }
-            lo[0] = (_Float16)v0; lo[1] = (_Float16)v1; hi[0] = (_Float16)v2; hi[1] = (_Float16)v3;
-            _Float16 *out = C + (long)m * ldc + n;
-            if (n + 1 < N) *(half2_t *)out = lo;
-            if (n + 3 < N) *(half2_t *)(out + 2) = hi;
+            for (int i = 0; i < 4; ++i) {
+                float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+                if (RELU) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f); }
+                cv_half4 o;
+                o[0] = (_Float16)v0; o[1] = (_Float16)v1; o[2] = (_Float16)v2; o[3] = (_Float16)v3;
+                *(cv_half4 *)(tb + (j * 16 + r) * kFcERow + (i * 16 + 4 * q4) * 2) = o;
+            }
+        wave_sync(); // (the block is this wave's own)
+        const int half = lane >> 5, dw = lane & 31;
+        const int n = n0 + wn * 64 + 2 * dw;
+#pragma unroll 4
+        for (int it = 0; it < 32; ++it) {
+            const int row = it * 2 + half, m = m0 + wm * 64 + row;
+            const uint32_t v = *(const uint32_t *)(tb + row * kFcERow + dw * 4);
+            if (m < Ml && n + 1 < N) *(uint32_t *)(C + (long)m * ldc + n) = v;
         }
     }
 }

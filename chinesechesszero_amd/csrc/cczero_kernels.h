@@ -576,7 +576,7 @@ template <typename T, bool PLANNED>
 __global__ __launch_bounds__(64) void k_softmax_gather(Dev D, const T *logits, const float *vcompact)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
-    __shared__ float row[kNMoves + 2];
+    __shared__ __attribute__((aligned(16))) float row[kNMoves + 2];
     if (D.leaf_status[b] != CCZ_LEAF_EXPAND) return;
     int src = b;
     if (PLANNED) {
@@ -588,14 +588,34 @@ __global__ __launch_bounds__(64) void k_softmax_gather(Dev D, const T *logits, c
     const int id0 = ids[lane], id1 = ids[64 + lane];
     const T *srcrow = logits + (size_t)src * kNMoves;
     float mx = -__builtin_huge_valf();
-    for (int i = lane; i < kNMoves; i += 64) {
-        const float x = (float)srcrow[i];
-        row[i] = x;
-        mx = fmaxf(mx, x);
-    }
-    mx = wave_max_f32(mx);
     float sum = 0.0f;
-    for (int i = lane; i < kNMoves; i += 64) sum += __expf(row[i] - mx);
+    if constexpr (sizeof(T) == 2) {
+        // fp16 logits: a row is 1043 dwords (4-byte aligned: 2086 is even), two logits per load -- half the loads, LDS writes and
+        // loop trips of the element-wise form. A lane adds its exponentials in ascending element order (2j, 2j + 1, 2j + 128, ...).
+        static_assert(kNMoves % 2 == 0, "dword rows");
+        const uint32_t *src32 = (const uint32_t *)srcrow;
+        for (int j = lane; j < kNMoves / 2; j += 64) {
+            const uint32_t w = src32[j];
+            const float x0 = (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu));
+            const float x1 = (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16));
+            *(float2 *)(row + 2 * j) = make_float2(x0, x1);
+            mx = fmaxf(mx, fmaxf(x0, x1));
+        }
+        mx = wave_max_f32(mx);
+        for (int j = lane; j < kNMoves / 2; j += 64) {
+            const float2 x = *(const float2 *)(row + 2 * j);
+            sum += __expf(x.x - mx);
+            sum += __expf(x.y - mx);
+        }
+    } else {
+        for (int i = lane; i < kNMoves; i += 64) {
+            const float x = (float)srcrow[i];
+            row[i] = x;
+            mx = fmaxf(mx, x);
+        }
+        mx = wave_max_f32(mx);
+        for (int i = lane; i < kNMoves; i += 64) sum += __expf(row[i] - mx);
+    }
     sum = wave_sum_f32(sum);
     wave_sync();
     float *out = D.prior128 + (size_t)b * kMaxLegal;
@@ -687,45 +707,75 @@ __global__ __launch_bounds__(1024) void k_cache_plan(Dev D, int32_t *miss_rows, 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) s_base = 0;
     __syncthreads();
-    for (int b0 = 0; b0 < D.B; b0 += 1024) {
-        const int b = b0 + tid;
-        int isrep = 0;
-        if (b < D.B && D.cstate[b] == 0) {
-            const int w = D.claim[D.cslot[b]];
-            const bool same = w >= 0 && w < D.B && D.cstate[w] == 0 && D.leaf_key[w] == D.leaf_key[b];
-            const int rep = same ? w : b;
-            D.crep[b] = rep;
-            D.cins[b] = (uint8_t)(w == b);
-            isrep = rep == b;
-            if (!isrep) D.stats[b].cache_shared += 1u;
-        }
-        // exclusive position of every representative: ballot inside the wave, 16 wave totals through LDS
-        const uint64_t m = __ballot(isrep);
-        const int in_wave = __popcll(m & lanemask_lt(lane)), wave_total = __popcll(m);
-        if (lane == 0) s_wave[wv] = wave_total;
-        __syncthreads();
-        int before = 0, total = 0;
+    // 4096 boards per pass: a thread looks after boards b0 + tid + 1024 i, i = 0..3. The three dependent load rounds (state / slot /
+    // key -> claim -> the claimant's state and key) are issued for all four boards before any is used, so a pass costs three memory
+    // round trips instead of twelve (this kernel is one workgroup: nothing else hides its latency)
+    for (int b0 = 0; b0 < D.B; b0 += 4096) {
+        int st[4], w[4], rep[4];
+        uint32_t slot[4];
+        uint64_t key[4];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int t = s_wave[i];
-            before += i < wv ? t : 0;
-            total += t;
+        for (int i = 0; i < 4; ++i) {
+            const int b = b0 + i * 1024 + tid;
+            st[i] = 3;
+            slot[i] = 0;
+            key[i] = 0;
+            if (b < D.B) { st[i] = D.cstate[b]; slot[i] = D.cslot[b]; key[i] = D.leaf_key[b]; }
         }
-        const int base = s_base;
-        if (isrep) {
-            const int pos = base + before + in_wave;
-            D.row_of[b] = pos;
-            miss_rows[pos] = b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = st[i] == 0 ? D.claim[slot[i]] : -1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int b = b0 + i * 1024 + tid;
+            rep[i] = b;
+            if (st[i] == 0 && w[i] >= 0 && w[i] < D.B && w[i] != b) {
+                const bool same = D.cstate[w[i]] == 0 && D.leaf_key[w[i]] == key[i];
+                rep[i] = same ? w[i] : b;
+            }
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int b = b0 + i * 1024 + tid;
+            int isrep = 0;
+            if (st[i] == 0) {
+                D.crep[b] = rep[i];
+                D.cins[b] = (uint8_t)(w[i] == b);
+                isrep = rep[i] == b;
+                if (!isrep) D.stats[b].cache_shared += 1u;
+            }
+            // exclusive position of every representative: ballot inside the wave, 16 wave totals through LDS
+            const uint64_t m = __ballot(isrep);
+            const int in_wave = __popcll(m & lanemask_lt(lane)), wave_total = __popcll(m);
+            if (lane == 0) s_wave[wv] = wave_total;
+            __syncthreads();
+            int before = 0, total = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int t = s_wave[j];
+                before += j < wv ? t : 0;
+                total += t;
+            }
+            const int base = s_base;
+            if (isrep) {
+                const int pos = base + before + in_wave;
+                D.row_of[b] = pos;
+                miss_rows[pos] = b;
+            }
+            __syncthreads();
+            if (tid == 0) s_base = base + total;
+            __syncthreads();
+        }
+        // boards that use another board's row: the representative is the slot's claim winner, i.e. a LOWER board index -- its row
+        // was assigned above, in this pass or an earlier one (straight from the registers of this pass: one load round)
+        __threadfence_block();
         __syncthreads();
-        if (tid == 0) s_base = base + total;
-        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int b = b0 + i * 1024 + tid;
+            if (st[i] == 0 && rep[i] != b) // (read past this CU's L1: the row was written a moment ago by another wave)
+                D.row_of[b] = __hip_atomic_load(D.row_of + rep[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-    __threadfence_block();
-    __syncthreads();
-    for (int b = tid; b < D.B; b += 1024)
-        if (D.cstate[b] == 0 && D.crep[b] != b) // (read past this CU's L1: the row was written a moment ago by another wave)
-            D.row_of[b] = __hip_atomic_load(D.row_of + D.crep[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid == 0) *n_miss = s_base;
 }
 

@@ -29,27 +29,37 @@ __global__ __launch_bounds__(256) void k_bias_act(half8_t *__restrict__ y, const
 
 // The evaluator input [B, 17, 7, 10, 9] fp16 (reference net.py:174-177) has 21 planes that can be non-zero on the
 // search path (groups 7, 15, 16 = planes 49..55 and 105..118, net.py:160-173): pack them as NHWC rows of 64 channels
-// (21 live + 43 zeros), the stem input of the tower convolution kernel. One workgroup per board, 16 B per lane.
+// (21 live + 43 zeros), the stem input of the tower convolution kernel. One workgroup per board.
 // rows != nullptr (planned evaluator boundary, ccz_eval_plan): output row i is board rows[i], for i < *n_rows only.
-// g16: output rows in the group-of-16 layout (row (b / 16 * 90 + p) * 16 + b % 16, cczero_conv_g16.h) instead of b * 90 + p.
+// flags bit 0 (g16): output rows in the group-of-16 layout (row (b / 16 * 90 + p) * 16 + b % 16, cczero_conv_g16.h) instead of
+// b * 90 + p; bit 1: the caller's buffer already holds zeros in channels 24..63 (a persistent buffer zeroed once): only the three
+// 16-byte chunks that can be non-zero are written (48 of 128 bytes per row).
+// The two plane runs of a board (630 + 1260 fp16, both 4-byte aligned) are staged in LDS with dword loads and transposed from
+// there (round 3 gathered them with 2-byte global loads: 7.7 M of them per step, 22 us).
 __global__ __launch_bounds__(256) void k_pack_live_planes(const _Float16 *__restrict__ leaf, half8_t *__restrict__ out, int n_boards,
-                                                          const int *__restrict__ rows, const int *__restrict__ n_rows, int g16)
+                                                          const int *__restrict__ rows, const int *__restrict__ n_rows, int flags)
 {
+    __shared__ uint32_t s_w[946]; // planes 49..55 (315 dwords) then 105..118 (630 dwords); + 1 pad
     const long b = blockIdx.x;
     long sb = b;
     if (rows) {
         if (b >= *n_rows) return;
         sb = rows[b];
     }
-    const _Float16 *src = leaf + sb * (119 * 90);
-    for (int i = threadIdx.x; i < 90 * 8; i += 256) {
-        const int p = i >> 3, cpos = i & 7;
+    const uint32_t *src = (const uint32_t *)(leaf + sb * (119 * 90)); // a board is 21,420 B: dword-aligned
+    for (int i = threadIdx.x; i < 945; i += 256) s_w[i] = src[i < 315 ? (49 * 45) + i : (105 * 45) + (i - 315)];
+    __syncthreads();
+    const _Float16 *s_h = (const _Float16 *)s_w; // live channel ch (0..20), pixel p at s_h[ch * 90 + p]
+    const bool g16 = flags & 1;
+    const int ncp = (flags & 2) ? 3 : 8;
+    for (int i = threadIdx.x; i < 90 * ncp; i += 256) {
+        const int p = i / ncp, cpos = i - p * ncp;
         half8_t v = (half8_t)(_Float16)0;
         if (cpos < 3) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int ch = cpos * 8 + e;
-                if (ch < 21) v[e] = src[(ch < 7 ? 49 + ch : 98 + ch) * 90 + p];
+                if (ch < 21) v[e] = s_h[ch * 90 + p];
             }
         }
         const long row = g16 ? ((b >> 4) * 90 + p) * 16 + (b & 15) : b * 90 + p;

@@ -400,7 +400,8 @@ int ccz_pack_live_planes_g16_f16(void *stream, const void *leaf_dev, void *x64_d
 
 /* The same three for the planned evaluator boundary (ccz_eval_plan): the number of rows to compute is a DEVICE value, so that
  * no host sync stands between the plan and the evaluator. ccz_pack_live_planes_rows_f16: output row i = board rows_dev[i] for
- * i < *n_rows_dev (the rest is left alone). The *_live convolutions take the pointers of the WHOLE batch: the first *live_rows_dev
+ * i < *n_rows_dev (the rest is left alone). The planned forms (rows_dev != NULL, either layout) write channels 0..23 of a row
+ * only: x64 must be a buffer whose channels 24..63 are ZERO (zeroed once and reused step after step: what the evaluator does). The *_live convolutions take the pointers of the WHOLE batch: the first *live_rows_dev
  * boards are live and are cut into n_parts equal ranges (multiples of 8 boards; of 16 with CCZ_CONV_G16) of which this launch
  * computes range `part` -- so that concurrent launch chains stay balanced whatever the live count is; n_pixels = the largest
  * range a launch may get (ceil(boards / n_parts) rounded up to 8 (16) boards, x 90): the grid is sized for it, tiles past the

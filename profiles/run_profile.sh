@@ -11,7 +11,7 @@
 # Raw profiler output goes to /tmp (it exceeds what gpurun copies back); summaries are merged into profiles/ and copied to
 # gpurun_out/profiles_TAG/. A heartbeat line per minute keeps the run visibly alive.
 set -eo pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 shift || true
 PASSES=${*:-trace fetch write sq cfetch cwrite csq}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}

@@ -30,7 +30,7 @@ def main():
     stats = find(os.path.join(out_dir, "trace"), "*kernel_stats.csv")
     if stats:
         rows = list(csv.DictReader(open(stats)))
-        keep = rows[:25]
+        keep = rows[:48]
         with open(os.path.join(root, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
             w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
             w.writeheader()
@@ -42,6 +42,27 @@ def main():
                     summary.setdefault(k, {})["avg_ns"] = float(r.get("AverageNs", 0) or 0)
                     summary[k]["calls"] = int(float(r.get("Calls", 0) or 0))
                     summary[k]["pct"] = float(r.get("Percentage", 0) or 0)
+        # the evaluator's NON-tower kernels per step: every planned step launches k_cache_plan exactly once, so a kernel's launches
+        # per step = its calls / k_cache_plan's calls (template instantiations of one kernel are added up)
+        plan_calls = sum(int(float(r.get("Calls", 0) or 0)) for r in rows if "k_cache_plan" in r.get("Name", ""))
+        if plan_calls:
+            tail = {}
+            for k in ("k_cache_probe", "k_cache_plan", "k_pack_live_planes", "k_head_conv1x1", "k_fc_f16", "k_value_out", "k_softmax_gather"):
+                tot = sum(float(r.get("TotalDurationNs", 0) or 0) for r in rows if k in r.get("Name", ""))
+                calls = sum(int(float(r.get("Calls", 0) or 0)) for r in rows if k in r.get("Name", ""))
+                if calls:
+                    tail[k] = {"us_per_step": tot / plan_calls * 1e-3, "launches_per_step": calls / plan_calls, "avg_us": tot / calls * 1e-3}
+            # whatever torch still launches inside a step (elementwise / GEMM kernels of the library): everything that is not ours
+            other = [(r.get("Name", ""), float(r.get("TotalDurationNs", 0) or 0), int(float(r.get("Calls", 0) or 0))) for r in rows
+                     if "ccz" not in r.get("Name", "")]   # (ccz:: in demangled names, 3ccz in mangled ones)
+            summary["evaluator_tail"] = {"kernels": tail, "us_per_step_ours": sum(v["us_per_step"] for v in tail.values()),
+                                         "library_kernels_total_us_per_step": sum(t for _, t, _ in other) / plan_calls * 1e-3,
+                                         "library_kernels_top": [{"name": n[:90], "us_per_step": t / plan_calls * 1e-3, "calls": c} for n, t, c in sorted(other, key=lambda x: -x[1])[:8]],
+                                         "steps": plan_calls,
+                                         "what": "non-tower evaluator work per lockstep step (rocprofv3 --kernel-trace --stats of bench.py --steps 120): cache probe + plan, "
+                                                 "pack of the live planes, head convolutions, FC layers, value head, softmax + gather + cache store. "
+                                                 "library_kernels_*: kernels that are not this library's (torch elementwise / GEMM / copies), whole run "
+                                                 "(set-up, preroll and the CPU-side bookkeeping included) divided by the number of steps"}
     def bench_line(name):
         p = os.path.join(out_dir, name)
         if not os.path.exists(p):
