@@ -1039,7 +1039,9 @@ __global__ __launch_bounds__(64) void k_finish_move(Dev D, const int32_t *forced
     // other side's did not loses. Only outcome().winner changes (game.py:210-216): in the search the same leaf is
     // "end and is_tie" -> 0.0 either way (mcts.py:120-122), so visit counts do not depend on this flag.
     int perpetual_winner = -1;
-    if ((D.rule_flags & 1u) && L.n_legal > 0 && !L.insufficient && L.rep >= 4) {
+    // (the host view and the reference order of checks, game.py:208-214: insufficient material, then the sixty-move rule, then the
+    // repetition -- a game that the sixty-move rule ends at the same ply is a DRAW, whatever the repetition window holds)
+    if ((D.rule_flags & 1u) && L.n_legal > 0 && !L.insufficient && !(halfmove >= 120) && L.rep >= 4) {
         const int last = chain_len - 1;
         bool miss_mover = false, miss_other = false, any_other = false; // mover = the side that just moved (turn ^ 1)
 #pragma unroll

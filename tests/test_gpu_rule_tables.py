@@ -375,6 +375,65 @@ def test_perpetual_check_rule_decides_a_fourfold_repetition(checker_is_red):
     assert results == {"perpetual": 0 if loser_is_red else 1, "flag off": -1, "no checks": -1}
 
 
+def test_perpetual_check_that_coincides_with_the_sixty_move_draw_is_a_draw():
+    """with CCZ_RULE_PERPETUAL_CHECK a repetition that completes at the very ply the sixty-move clock reaches 120 is a
+    DRAW -- the order of the reference's checks (game.py:208-214: insufficient material, sixty moves, then repetition), which the
+    host Board always followed; k_finish_move and the oracle adjudicated a perpetual-check winner there. z follows."""
+    import oracle
+    from golden_cases import sq as S
+    from oracle import OracleBoard
+    from chinesechesszero_amd import tools
+    from chinesechesszero_amd.game import Board
+    L = oracle.lib()
+    uid = lambda u: L.xq_move_id(S(u[:2]), S(u[2:]))
+    pos, turn, cycle = _perpetual_case(True)
+    try:
+        oracle.set_rules(perpetual_check=True)
+        tools.set_rules(perpetual_check=True)
+        for clock0, want_winner in ((108, -1), (100, 0)):     # 12 plies later the clock stands at 120 (draw first) / at 112 (red, the checker, loses)
+            e = _engine(1, 8, seed=3)
+            e.set_position(0, pos, turn, clock0)
+            ob, hb = OracleBoard.from_array(pos, turn, clock0), Board(pos, bool(turn), clock0)
+            for ply in range(12):
+                u = cycle[ply % 4]
+                e.finish_move(forced_moves=np.array([uid(u)], np.int32), keep_tree=False)
+                ob.push(u)
+                hb.push(u)
+            st = e.game_status()
+            assert st["over"][0] and ob.is_game_over() and hb.is_game_over()
+            o, h = ob.outcome(), hb.outcome()
+            got = (int(st["winner"][0]), -1 if o.winner is None else int(o.winner), -1 if h.winner is None else int(h.winner))
+            assert got == (want_winner,) * 3, (clock0, got)
+            _, _, z = e.harvest()
+            assert (float(z.abs().max()) == 0.0) == (want_winner < 0)
+            e.check_healthy()
+    finally:
+        oracle.set_rules()
+        tools.set_rules()
+
+
+def test_probe_cchess_round_trip_on_the_products_own_board():
+    """tools/probe_cchess.py run against the PRODUCT's host Board (rules answered by the HIP movegen kernel) duck-typed as
+    `cchess`: it reads back the canonical preset with nothing unsupported, and its golden file replays on the oracle -- i.e. the
+    kernels and the oracle give the probe the same answers on its ~200 positions and crafted endings."""
+    import importlib.util
+    import os
+    import oracle
+    from fake_cchess import make_module
+    from test_oracle_rules import _replay_golden_on_oracle
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("probe_cchess", os.path.join(root, "tools", "probe_cchess.py"))
+    P = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(P)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        got, golden = P.probe(make_module("host"), d, n_games=6, plies=26)
+        assert got["unsupported_differences"] == [] and got["move_rank"] is None and got["type_rank"] is None
+        assert tuple(got["plane_of_type"]) == (0, 0, 1, 2, 3, 4, 5, 6) and not got["perpetual_check"] and not got["pawn_move_resets_clock"]
+        oracle.set_rules()
+        assert _replay_golden_on_oracle(os.path.join(d, "cchess_golden.npz")) == len(golden) > 140
+
+
 def test_rule_presets_install_tables_in_every_layer():
     """tools.set_rules(preset=...): "canonical" and the unverified "python-chess-lineage" guess (planes P,R,N,B,A,K,C; piece-set
     scan order with pawns last; perpetual check). The engine, the host Board and -- given the same tables -- the oracle agree

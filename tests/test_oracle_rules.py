@@ -3,11 +3,16 @@
 Rules parity with the reference's third-party `cchess` is unpinned (source absent); these tests
 anchor the restatement to the published Xiangqi start-position perft and to properties.
 """
+import json
+import os
+
 import numpy as np
 import pytest
 
 import oracle
 from oracle import OracleBoard
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 PERFT = {1: 44, 2: 1920, 3: 79666, 4: 3290240}
 
@@ -153,3 +158,122 @@ def test_perpetual_check_rule_of_the_oracle():
     finally:
         oracle.set_rules()
     assert got == {"perpetual": False, "off": None, "quiet": None}     # RED checked throughout: BLACK wins
+
+
+# ---------------------------------------------------------------- tools/probe_cchess.py: "unpinned" -> one command to pin
+def _probe_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("probe_cchess", os.path.join(ROOT, "tools", "probe_cchess.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+LINEAGE_NUMBERING = {1: 1, 3: 2, 4: 3, 5: 4, 6: 5, 7: 6, 2: 7}   # build type -> PAWN 1, ROOK 2, KNIGHT 3, BISHOP 4, ADVISOR 5, KING 6, CANNON 7
+
+
+@pytest.mark.parametrize("preset", ["canonical", "python-chess-lineage"])
+def test_probe_round_trip_reads_back_the_installed_rule_preset(preset, tmp_path):
+    """The probe a user with a real `cchess` runs ONCE, run here against this build's own rules duck-typed as `cchess` (the CPU
+    oracle) with a known profile installed: it must read that profile back -- piece numbering, legal_moves order (closed form,
+    extrapolated to all 2086 ids), clock rule, perpetual check -- with no unsupported difference; and the golden file it writes
+    replays on the oracle once its preset.json is installed from disk."""
+    from fake_cchess import make_module
+    from chinesechesszero_amd import tools
+    P = _probe_module()
+    want = tools.rule_presets()[preset]
+    oracle.set_rules(move_rank=want.get("move_rank"), type_rank=want.get("type_rank"), perpetual_check=want.get("perpetual_check", False))
+    try:
+        mod = make_module("oracle", LINEAGE_NUMBERING if preset != "canonical" else None)
+        got, golden = P.probe(mod, str(tmp_path))
+    finally:
+        oracle.set_rules()
+    assert got["unsupported_differences"] == [], got["unsupported_differences"]
+    assert tuple(got["plane_of_type"]) == tuple(want.get("plane_of_type", (0, 0, 1, 2, 3, 4, 5, 6)))
+    assert got["perpetual_check"] == bool(want.get("perpetual_check", False)) and got["pawn_move_resets_clock"] is False
+    assert got["legal_moves_order"]["extrapolated"] is True and len(golden) > 180
+    if preset == "canonical":
+        assert got["move_rank"] is None and got["type_rank"] is None and "id ascending" in got["legal_moves_order"]["fit"]
+    else:
+        assert np.array_equal(np.asarray(got["move_rank"]), want["move_rank"]) and "from descending, to descending" in got["legal_moves_order"]["fit"]
+        tr = got["type_rank"]
+        assert tr[1] > tr[3] and len({tr[t] for t in (2, 3, 4, 5, 6, 7)}) == 1        # pawn moves after every other piece's
+    # ---- consumers: the file installs into the product's tables and into the oracle, and the golden file replays
+    kw, _ = P.load_preset(str(tmp_path / "preset.json"))
+    tools.set_rules(preset=str(tmp_path / "preset.json"))
+    try:
+        cur = tools.current_rules()
+        assert cur["plane_of_type"] == tuple(kw["plane_of_type"]) and cur["perpetual_check"] == kw["perpetual_check"]
+        assert (cur["move_rank"] is None) == (kw["move_rank"] is None) and tools.PRESET.endswith("preset.json")
+    finally:
+        tools.set_rules()
+    oracle.set_rules_from_file(str(tmp_path / "preset.json"))
+    try:
+        n = _replay_golden_on_oracle(str(tmp_path / "cchess_golden.npz"))
+    finally:
+        oracle.set_rules()
+    assert n == len(golden)
+
+
+def _replay_golden_on_oracle(path):
+    """Every record of a probe's golden file against the oracle (the preset already installed): legal moves IN ORDER, the four
+    predicates, the winner."""
+    from fake_cchess import parse_fen
+    g = np.load(path)
+    meta = json.loads(str(g["meta"]))
+    for j, rec in enumerate(meta):
+        sq, red, half = parse_fen(rec["fen"])
+        b = OracleBoard.from_array(sq, 1 if red else 0, half)
+        for mv in rec["moves"]:
+            b.push(mv)
+        k = int(g["k"][j])
+        assert b.legal_ids() == g["ids"][j][:k].tolist(), rec["label"]
+        assert np.array_equal(b.squares(), g["squares"][j]) and int(b.turn) == int(g["turn"][j])
+        fl = g["flags"][j]
+        assert [int(b.is_game_over()), int(b.is_insufficient_material()), int(b.is_fourfold_repetition()), int(b.is_sixty_moves())] == fl.tolist(), rec["label"]
+        o = b.outcome()
+        w = -2 if o is None else (-1 if o.winner is None else int(bool(o.winner)))
+        assert w == int(g["winner"][j]), rec["label"]
+    return len(meta)
+
+
+def test_probe_reports_what_no_table_can_express():
+    """A "cchess" that scores stalemate as a draw and needs five repetitions (what an unmodified python-chess port would do): the
+    probe must SAY so, not emit a preset that looks complete."""
+    from fake_cchess import make_module
+    P = _probe_module()
+    mod = make_module("oracle")
+    Base = mod.Board
+
+    class Lax(Base):
+        def outcome(self):
+            o = super().outcome()
+            if o is not None and not self.legal_moves and not self.b.in_check():
+                o.winner = None          # stalemate = draw
+            return o
+
+        def is_fourfold_repetition(self):
+            return False                 # never claims the draw at four occurrences
+
+    mod.Board = Lax
+    got, _ = P.probe(mod, None, n_games=2, plies=8)
+    text = " | ".join(got["unsupported_differences"])
+    assert "no legal move without check" in text and "is_fourfold_repetition()" in text
+
+
+def test_perpetual_check_yields_to_the_sixty_move_draw_at_the_same_ply():
+    """Order of the reference's checks (game.py:208-214): insufficient material, sixty moves, then repetition. A perpetual-check
+    repetition that completes at the ply the clock reaches 120 is a draw; eight plies of clock earlier the checker loses."""
+    from fake_cchess import parse_fen
+    oracle.set_rules(perpetual_check=True)
+    try:
+        for clock0, want in ((108, None), (100, False)):
+            sq, red, half = parse_fen(f"4k4/R8/9/9/9/9/9/9/9/3K5 w - - {clock0} 60")
+            b = OracleBoard.from_array(sq, 1, half)
+            for ply in range(12):
+                assert not b.is_game_over()
+                b.push(["a8a9", "e9e8", "a9a8", "e8e9"][ply % 4])
+            assert b.is_game_over() and b.is_fourfold_repetition() and b.is_sixty_moves() == (clock0 == 108)
+            assert b.outcome().winner is want
+    finally:
+        oracle.set_rules()
