@@ -18,15 +18,6 @@
 #include "cczero_conv_small.h"
 #include "cczero_conv_g16.h"
 #include "cczero_heads.h"
-#ifdef CCZ_CONV3 // round 3's form without a barrier per half-step: measured slower, A-B builds only (make ab NAME=v3 ABFLAGS=-DCCZ_CONV3)
-#include "../../profiles/experiments/cczero_conv3.h"
-#endif
-#ifdef CCZ_CONV4 // group-of-16 layout, off-board taps skipped: A-B builds only (make ab NAME=v4 ABFLAGS=-DCCZ_CONV4)
-#include "../../profiles/experiments/cczero_conv4.h"
-#endif
-#ifdef CCZ_CONV2 // experimental second form of the tower kernel: diagnostic / A-B builds only (make ab NAME=v2 ABFLAGS=-DCCZ_CONV2)
-#include "../../profiles/experiments/cczero_conv2.h"
-#endif
 
 using namespace ccz;
 
@@ -800,44 +791,6 @@ static int conv3x3_launch(const char *who, void *stream, const void *x_dev, cons
         return 0;
     }
     const unsigned tiles = (unsigned)((n_pixels + kCvBM - 1) / kCvBM);
-#ifdef CCZ_CONV2
-    if (relu & 4) { // bit 2: the two-workgroups-per-CU form (cczero_conv2.h): same results up to float32 summation order
-        const unsigned grid = ((tiles + 7) / 8) * 16;
-        if (residual_dev)
-            hipLaunchKernelGGL(k_conv3x3_v2<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev,
-                               (const float *)bias_f32_dev, (const _Float16 *)residual_dev, (_Float16 *)y_dev, (int)n_pixels, (int)(relu & 3), cin, (int)tiles);
-        else
-            hipLaunchKernelGGL(k_conv3x3_v2<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev,
-                               (const float *)bias_f32_dev, (const _Float16 *)nullptr, (_Float16 *)y_dev, (int)n_pixels, (int)(relu & 3), cin, (int)tiles);
-        HIP_TRY(hipGetLastError());
-        return 0;
-    }
-#endif
-#ifdef CCZ_CONV3
-    if (relu & 8) { // bit 3: the form without a barrier per half-step (profiles/experiments/cczero_conv3.h)
-        if (residual_dev)
-            hipLaunchKernelGGL(k_conv3x3_v3<true>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev,
-                               (const float *)bias_f32_dev, (const _Float16 *)residual_dev, (_Float16 *)y_dev, (int)n_pixels, (int)(relu & 3), cin);
-        else
-            hipLaunchKernelGGL(k_conv3x3_v3<false>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev,
-                               (const float *)bias_f32_dev, (const _Float16 *)nullptr, (_Float16 *)y_dev, (int)n_pixels, (int)(relu & 3), cin);
-        HIP_TRY(hipGetLastError());
-        return 0;
-    }
-#endif
-#ifdef CCZ_CONV4
-    if (relu & 1024) { // bit 6: rows in the group-of-16 layout (profiles/experiments/cczero_conv4.h)
-        if (n_pixels % 1440) return fail(-1, "%s: the group-of-16 layout needs a multiple of 16 boards", who);
-        if (residual_dev)
-            hipLaunchKernelGGL(k_conv3x3_v4<true>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev,
-                               (const float *)bias_f32_dev, (const _Float16 *)residual_dev, (_Float16 *)y_dev, (int)n_pixels, (int)(relu & 3), cin);
-        else
-            hipLaunchKernelGGL(k_conv3x3_v4<false>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev,
-                               (const float *)bias_f32_dev, (const _Float16 *)nullptr, (_Float16 *)y_dev, (int)n_pixels, (int)(relu & 3), cin);
-        HIP_TRY(hipGetLastError());
-        return 0;
-    }
-#endif
 #ifndef CCZ_STAMPS
     relu &= 3; // bit 0: ReLU, bit 1: descending tile order; the diagnostic build passes ablation switches in bits 8.. (profiles/conv_microbench.py)
 #endif

@@ -1,12 +1,12 @@
 #!/bin/bash
 # SQ counters of the two forms of the tower convolution on the same data (one process, interleaved): where do the waves wait?
-# needs build/diag/libcczero_ab_v2.so: make -C chinesechesszero_amd/csrc ab NAME=v2 ABFLAGS=-DCCZ_CONV2
+# needs build/diag/libcczero_experiments.so: make -C chinesechesszero_amd/csrc experiments
 set -eo pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_conv2
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d $OUT -o sq -- python3 $ROOT/profiles/conv_ab.py libcczero.so:1 libcczero_ab_v2.so:5 --boards 4096 --rounds 2 --iters 3 > $OUT/run.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d $OUT -o sq -- python3 $ROOT/profiles/conv_ab.py libcczero.so:1 libcczero_experiments.so:5 --boards 4096 --rounds 2 --iters 3 > $OUT/run.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob("$OUT/**/*counter_collection.csv", recursive=True)[0]
