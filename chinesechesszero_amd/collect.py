@@ -318,7 +318,7 @@ def write_games_hdf5(records: torch.Tensor, h5_path: str, flags: int = 0, plane_
 class CollectPipeline:
     def __init__(self, init_model=None, n_boards: int = 1, n_playout: int = PLAYOUT, device: int = 0, seed: int = 0,
                  data_dir: str = DATA_DIR, reference_quirks: bool = False, num_channels: int = 256, resblocks_num: int = 40,
-                 finalize_every: int = 0, on_playout=None, max_plies: int = 0):
+                 finalize_every: int = 0, on_playout=None, max_plies: int = 0, eval_cache_log2: int | None = None):
         self.board = Board()                       # collect.py:28 (never advanced: source of the turn-plane quirk)
         self.game = Game(self.board, reference_quirks=reference_quirks)
         self.temp = 1.0
@@ -336,6 +336,8 @@ class CollectPipeline:
         self.sink = TupleSink(data_dir)
         self.iters = self.sink.games
         self.episode_len = 0
+        # batched path: evaluation cache of 2^n positions (528 B each: 2^24 = 8.9 GB of the GPU's 288); None = 24 from 192 boards on, else none
+        self.eval_cache_log2 = eval_cache_log2
         self.max_plies = max_plies  # batched path: games adjudicated as draws at this many plies (0 = the engine's 2048)
         self.finalize_every = finalize_every
         self._finalized_at = self.sink.games
@@ -420,7 +422,7 @@ class CollectPipeline:
             # compact evaluator boundary (logits in, the engine gathers the legal priors) and, on the fused evaluator path (>= 192
             # boards), the evaluation cache: positions evaluated before skip the network (same results)
             self.selfplay = BatchedSelfPlay(self.policy_value_net.evaluate_leaves_logits, self.n_boards, n_playout=self.n_playout,
-                                            eval_cache_log2=24 if self.n_boards >= 192 else 0,
+                                            eval_cache_log2=(24 if self.n_boards >= 192 else 0) if self.eval_cache_log2 is None else int(self.eval_cache_log2),
                                             c_puct=self.c_puct, temp=self.temp, seed=self.seed, board_id_base=rank * self.n_boards,
                                             device=self.device, reference_quirks=self.reference_quirks, max_plies=self.max_plies)
             if getattr(self, "_viewer", None) is not None:
@@ -504,10 +506,12 @@ if __name__ == "__main__":
     parser.add_argument("--playout", type=int, default=PLAYOUT)
     parser.add_argument("--moves", type=int, default=0, help="stop after this many collect_data calls (0 = until interrupted, as the reference)")
     parser.add_argument("--max-plies", type=int, default=0, help="batched path: adjudicate games at this many plies (0 = 2048)")
+    parser.add_argument("--eval-cache-log2", type=int, default=None, help="batched path: evaluation cache of 2^n positions, 528 B each (0 = none; default 24 = 8.9 GB from 192 boards on)")
     parser.add_argument("--data-dir", type=str, default=DATA_DIR)
     parser.add_argument("--channels", type=int, default=256)
     parser.add_argument("--blocks", type=int, default=40)
     parser.add_argument("--seed", type=int, default=0)
     args = parser.parse_args()
     CollectPipeline(init_model=args.model, n_boards=args.boards, n_playout=args.playout, data_dir=args.data_dir, seed=args.seed,
-                    num_channels=args.channels, resblocks_num=args.blocks, max_plies=args.max_plies).run(is_shown=args.show, max_calls=args.moves)
+                    num_channels=args.channels, resblocks_num=args.blocks, max_plies=args.max_plies,
+                    eval_cache_log2=args.eval_cache_log2).run(is_shown=args.show, max_calls=args.moves)

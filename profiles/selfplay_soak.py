@@ -22,7 +22,8 @@ dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 pvn = PolicyValueNet(device=dev)
 cache_log2 = int(os.environ.get("CCZ_EVAL_CACHE_LOG2", "24"))
-sp = BatchedSelfPlay(pvn.evaluate_leaves_logits, B, n_playout=n, seed=0, max_plies=max_plies, eval_cache_log2=cache_log2)
+verify = os.environ.get("CCZ_CACHE_VERIFY", "1") == "1" and cache_log2 > 0   # CCZ_FLAG_CACHE_VERIFY: ~1 hit in 128 evaluated again and compared
+sp = BatchedSelfPlay(pvn.evaluate_leaves_logits, B, n_playout=n, seed=0, max_plies=max_plies, eval_cache_log2=cache_log2, cache_verify=verify)
 e = sp.engine
 rows = games = decisive = truncated = 0
 lengths = []
@@ -59,5 +60,7 @@ out = {"boards": B, "sims_per_move": n, "moves_played_per_board": moves, "wall_s
        "max_plies_cap": max_plies,
        "eval_cache": {"entries_log2": cache_log2, "leaves_needing_the_net": st["cache_probes"], "hits": st["cache_hits"],
                       "served_by_another_boards_row": st["cache_shared_rows"], "stores": st["cache_stores"],
-                      "fraction_skipped": (st["cache_hits"] + st["cache_shared_rows"]) / max(1, st["cache_probes"])} if cache_log2 else None}
+                      "fraction_skipped": (st["cache_hits"] + st["cache_shared_rows"]) / max(1, st["cache_probes"]),
+                      "verify": {"hits_evaluated_again": st["cache_verified"], "mismatches": st["cache_verify_mismatches"]} if verify else None} if cache_log2 else None}
+assert st["cache_verify_mismatches"] == 0
 print(json.dumps(out))
