@@ -17,6 +17,7 @@
 #include "cczero_conv.h"
 #include "cczero_conv_small.h"
 #include "cczero_conv_g16.h"
+#include "cczero_conv_g16e.h"
 #include "cczero_heads.h"
 
 using namespace ccz;
@@ -763,15 +764,37 @@ static int conv3x3_launch(const char *who, void *stream, const void *x_dev, cons
     if (n_pixels == 0) return 0;
     if (relu & CCZ_CONV_G16) { // rows in the group-of-16 layout: whole-rank tiles, off-board taps skipped (cczero_conv_g16.h)
         if (n_pixels % 1440) return fail(-1, "%s: CCZ_CONV_G16 needs a multiple of 16 boards", who);
-        const unsigned t16 = (unsigned)(n_pixels / kG5Rows);
+        const int groups = (int)(n_pixels / 1440);
         const int fl = relu & 3;
-        if (residual_dev)
-            hipLaunchKernelGGL(k_conv3x3_g16<true>, dim3(t16), dim3(512), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev,
-                               (const float *)bias_f32_dev, (const _Float16 *)residual_dev, (_Float16 *)y_dev, (int)n_pixels, fl, cin, (const int *)live_rows_dev, (int)row0);
-        else
-            hipLaunchKernelGGL(k_conv3x3_g16<false>, dim3(t16), dim3(512), 0, (hipStream_t)stream, (const _Float16 *)x_dev, (const _Float16 *)w_dev,
-                               (const float *)bias_f32_dev, (const _Float16 *)nullptr, (_Float16 *)y_dev, (int)n_pixels, fl, cin, (const int *)live_rows_dev, (int)row0);
+        hipStream_t s = (hipStream_t)stream;
+#define CCZ_G16(KERNEL_, GRID_, STREAM_, FLAGS_)                                                                                   \
+        do {                                                                                                                       \
+            if (residual_dev)                                                                                                      \
+                hipLaunchKernelGGL(KERNEL_<true>, dim3((unsigned)(GRID_)), dim3(512), 0, STREAM_, (const _Float16 *)x_dev, (const _Float16 *)w_dev, \
+                                   (const float *)bias_f32_dev, (const _Float16 *)residual_dev, (_Float16 *)y_dev, (int)n_pixels, (int)(FLAGS_), cin, (const int *)live_rows_dev, (int)row0); \
+            else                                                                                                                   \
+                hipLaunchKernelGGL(KERNEL_<false>, dim3((unsigned)(GRID_)), dim3(512), 0, STREAM_, (const _Float16 *)x_dev, (const _Float16 *)w_dev, \
+                                   (const float *)bias_f32_dev, (const _Float16 *)nullptr, (_Float16 *)y_dev, (int)n_pixels, (int)(FLAGS_), cin, (const int *)live_rows_dev, (int)row0); \
+        } while (0)
+        // Default: ONE launch of five two-rank tiles per group. CCZ_CONV_G16_EDGE_TILES (flag bit 7, round 4): the edge ranks (0 and 9)
+        // of two groups at a time are their own tiles on their own kernel (six live taps instead of nine, cczero_conv_g16e.h) and the
+        // middle launch covers ranks 1..8 with four two-rank tiles per group -- two ordinary launches back to back in the caller's
+        // stream (no gap between them in the kernel trace). Same values. Measured (profiles/r04_conv_g16.json): -3 % per layer at 4096
+        // boards in isolation (1024 middle tiles = four full rounds of 256 CUs, 256 edge tiles = one round ~24 % shorter), but +0.7 %
+        // on the step in the workload: two launch chains of ~116 live groups each make it 464 + 116 tiles per launch, and the extra
+        // launch boundary per layer and chain costs more than the six taps save. Hence opt-in. (The edge launch on a helper stream
+        // beside the middle one put two event packets per layer on the main stream -- a 12.7 us gap between layers;
+        // hipExtAnyOrderLaunch is ignored on gfx9: the trace shows the kernels one after the other.)
+        if (!(relu & CCZ_CONV_G16_EDGE_TILES) || groups < 2) {
+            CCZ_G16(k_conv3x3_g16, groups * 5, s, fl);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
+        CCZ_G16(k_conv3x3_g16, groups * 4, s, fl | 4);
         HIP_TRY(hipGetLastError());
+        CCZ_G16(k_conv3x3_g16_edge, 2 * ((groups + 1) / 2), s, fl);
+        HIP_TRY(hipGetLastError());
+#undef CCZ_G16
         return 0;
     }
     // Small batches (one game at a time; up to kSmallMaxPixels): the 16-channel x 64-pixel-block kernel spreads them over the chip

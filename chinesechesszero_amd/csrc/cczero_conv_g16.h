@@ -210,7 +210,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_g16(const _Float16 *__restrict_
         live = live < 0 ? 0 : (live > per ? per : live);
         live = live > M / 1440 ? M / 1440 : live;
         M = live * 1440;
-        tiles = live * 5;
+        tiles = live * ((relu & 4) ? 4 : 5);
         if ((int)blockIdx.x >= tiles) return;
         const long off = (long)first * 1440 * kCvC;
         X += (long)first * 1440 * cin;
@@ -230,8 +230,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_g16(const _Float16 *__restrict_
     }
     // flags bit 1: tiles in descending order (the tiles written last by the previous layer are then read first)
     tile = __builtin_amdgcn_readfirstlane((relu & 2) ? tiles - 1 - tile : tile);
-    const int k = tile % 5;                  // ranks 2k, 2k + 1 of the tile's group
-    const long p0 = (long)tile * kG5Rows;    // = (group * 90 + 18 k) * 16
+    // flags bit 2 ("middle" mode, round 4): the launch covers ranks 1..8 only, four tiles per group (ranks 1-2, 3-4, 5-6, 7-8: every
+    // neighbour rank exists, nothing is zeroed); ranks 0 and 9 are k_conv3x3_g16_edge's (cczero_conv_g16e.h)
+    const int mid = relu & 4;
+    const int k = mid ? 2 : tile % 5;        // ranks 2k, 2k + 1 of the tile's group (middle mode: any k without an edge)
+    const long p0 = mid ? (long)(tile >> 2) * 1440 + 144 + (long)(tile & 3) * kG5Rows
+                        : (long)tile * kG5Rows;    // = (group * 90 + 18 k) * 16
     relu &= 1;
 
     G5Ctx c;

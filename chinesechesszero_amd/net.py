@@ -100,9 +100,11 @@ class EvalOptions:
     ``CCZ_FUSED_STEM=0`` (fused_stem): the stem through torch; ``CCZ_FUSED_HEADS=0`` (fused_heads): heads and FC layers through
     torch GEMMs; ``CCZ_CONV_LAYOUT=auto|nhwc|g16`` (layout): activation row layout (auto: group-of-16 from 640 boards on);
     ``CCZ_CONV_FORCE=small|tile`` (force): one convolution kernel whatever the batch size; ``CCZ_TOWER_GROUPS`` / ``CCZ_TOWER_CHAINS``
-    (groups, chains): launch structure of the tower; ``CCZ_CONV_ZIGZAG=0`` (zigzag): no alternating tile order."""
+    (groups, chains): launch structure of the tower; ``CCZ_CONV_ZIGZAG=0`` (zigzag): no alternating tile order;
+    ``CCZ_CONV_EDGE_TILES=1`` (edge_tiles): the group-of-16 convolution as a middle launch + an edge-pair launch (six live taps on the
+    edge ranks; same values; -3 % per layer in isolation, +0.7 % on the step with two launch chains: off by default)."""
 
-    FIELDS = ("fused_conv", "fused_stem", "fused_heads", "layout", "force", "groups", "chains", "zigzag")
+    FIELDS = ("fused_conv", "fused_stem", "fused_heads", "layout", "force", "groups", "chains", "zigzag", "edge_tiles")
 
     def __init__(self, env=None):
         env = os.environ if env is None else env
@@ -114,6 +116,7 @@ class EvalOptions:
         self.groups = int(env.get("CCZ_TOWER_GROUPS", "0"))
         self.chains = int(env.get("CCZ_TOWER_CHAINS", "0"))   # 0 = InferenceNet.TOWER_CHAINS
         self.zigzag = env.get("CCZ_CONV_ZIGZAG", "1") == "1"
+        self.edge_tiles = env.get("CCZ_CONV_EDGE_TILES", "0") == "1"   # group-of-16 layout: ranks 0 / 9 on the edge-pair kernel (round 4; opt-in)
         if self.layout not in ("auto", "nhwc", "g16"):
             raise ValueError("CCZ_CONV_LAYOUT must be auto, nhwc or g16")
 
@@ -343,7 +346,7 @@ class InferenceNet(nn.Module):
             cap = -(-(B // 16) // n_parts) * 1440            # whole 16-board groups (B is padded to a multiple of 16)
         else:
             cap = -(-(-(-B // n_parts)) // 8) * 8 * 90       # pixels of the largest range a launch may get
-        lay = _lib.CONV_G16 if g16 else 0
+        lay = (_lib.CONV_G16 | (_lib.CONV_G16_EDGE_TILES if self.opt.edge_tiles else 0)) if g16 else 0
         if chains > 1:
             pool = getattr(self, "_chain_streams", None)
             if pool is None or pool[0] != x.device or len(pool[1]) < chains - 1:
@@ -400,7 +403,7 @@ class InferenceNet(nn.Module):
         # alternates from layer to layer: what the previous layer wrote last (still in the Infinity Cache) is read
         # first (-0.7 % on the step; zigzag=False / CCZ_CONV_ZIGZAG=0 switches it off).
         down = 2 if self.opt.zigzag else 0
-        v2 = self.opt.force | (_lib.CONV_G16 if g16 else 0)
+        v2 = self.opt.force | ((_lib.CONV_G16 | (_lib.CONV_G16_EDGE_TILES if self.opt.edge_tiles else 0)) if g16 else 0)
         wsrc = self.ws_g16 if g16 else self.ws
         for i in range(0, len(self.ws), 2):
             w1, b1_, w2, b2_ = (C.c_void_p(t.data_ptr()) for t in (wsrc[i], self.bs32[i], wsrc[i + 1], self.bs32[i + 1]))
@@ -430,7 +433,7 @@ class InferenceNet(nn.Module):
             g16 = self._g16(B)
         s = C.c_void_p(torch.cuda.current_stream(leaf_input.device).cuda_stream)
         Bp = -(-B // 16) * 16 if g16 else B          # group-of-16 layout: whole groups; the padding boards hold zeros
-        lay = _lib.CONV_G16 if g16 else 0
+        lay = (_lib.CONV_G16 | (_lib.CONV_G16_EDGE_TILES if self.opt.edge_tiles else 0)) if g16 else 0
         if plan is None:
             x64 = (torch.zeros if Bp != B else torch.empty)((Bp, 90, 64), dtype=torch.float16, device=leaf_input.device)
             y = torch.empty((Bp, 256, 10, 9), dtype=torch.float16, device=leaf_input.device, memory_format=torch.channels_last)

@@ -286,7 +286,7 @@ def _from_g16(t, B):
     return t.reshape(B // 16, 90, 16, Cn).permute(0, 2, 1, 3).reshape(B, 10, 9, Cn).permute(0, 3, 1, 2)
 
 
-@pytest.mark.parametrize("boards", [16, 80, 272])
+@pytest.mark.parametrize("boards", [16, 80, 96, 272])
 def test_group_of_16_kernel_gives_the_tile_kernels_values(boards):
     """k_conv3x3_g16 (rows in the CCZ_CONV_G16 layout: tiles of two whole ranks of 16 boards, the taps that leave the board
     skipped instead of multiplied by zero rows) adds the same products in the same order as the 256-pixel tile kernel and
@@ -313,6 +313,13 @@ def test_group_of_16_kernel_gives_the_tile_kernels_values(boards):
                                           relu | _lib.CONV_G16))
         got = _from_g16(yg, boards)
         assert torch.equal(got, y_tile), (boards, res is not None, relu, (got.float() - y_tile.float()).abs().max().item())
+        # round 4's middle launch (ranks 1..8) + edge-pair launch (ranks 0 / 9 of two groups per tile, six live taps) against the
+        # single launch of five tiles per group (one group: a single launch either way; 5 and 17 groups: the last pair is one group twice)
+        y1 = torch.full_like(xg, float("nan"))
+        _lib.check(L.ccz_conv3x3_c256_f16(s, C.c_void_p(xg.data_ptr()), C.c_void_p(wp.data_ptr()), C.c_void_p(b.data_ptr()),
+                                          C.c_void_p(rg.data_ptr()) if res is not None else None, C.c_void_p(y1.data_ptr()), boards * 90,
+                                          relu | _lib.CONV_G16 | _lib.CONV_G16_EDGE_TILES))
+        assert torch.equal(y1, yg)
         want = ref if res is None else ref + r.float()
         if relu & 1:
             want = F.relu(want)
@@ -342,8 +349,9 @@ def test_group_of_16_kernel_gives_the_tile_kernels_values(boards):
                                   (boards - 1) * 90, 1 | _lib.CONV_G16) != 0
 
 
+@pytest.mark.parametrize("edge", [0, 1])
 @pytest.mark.parametrize("live,n_parts", [(0, 1), (1, 1), (16, 2), (17, 1), (100, 3), (160, 4)])
-def test_group_of_16_kernel_live_rows(live, n_parts):
+def test_group_of_16_kernel_live_rows(live, n_parts, edge):
     """The planned boundary in the group-of-16 layout: the first `live` boards (a device value) are cut into n_parts equal ranges
     of whole groups; the parts together compute exactly the groups that hold live boards, nothing else is written."""
     from chinesechesszero_amd import _lib
@@ -367,7 +375,7 @@ def test_group_of_16_kernel_live_rows(live, n_parts):
     cap = -(-(boards // 16) // n_parts) * 1440
     for part in range(n_parts):
         _lib.check(L.ccz_conv3x3_c256_f16_live(s, C.c_void_p(xg.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(rg.data_ptr()),
-                                               C.c_void_p(yg.data_ptr()), cap, 1 | _lib.CONV_G16 | (2 if part & 1 else 0), C.c_void_p(n_live.data_ptr()), part, n_parts))
+                                               C.c_void_p(yg.data_ptr()), cap, 1 | _lib.CONV_G16 | (2 if part & 1 else 0) | (_lib.CONV_G16_EDGE_TILES if edge else 0), C.c_void_p(n_live.data_ptr()), part, n_parts))
     groups = -(-live // 16)
     assert torch.equal(yg[:groups], full[:groups])
     assert torch.isnan(yg[groups:].float()).all()

@@ -235,14 +235,15 @@ def test_both_row_layouts_give_the_same_evaluation(monkeypatch):
     rows = torch.randperm(4096, device=dev)[:3000].to(torch.int32).contiguous()
     n_rows = torch.tensor([3000], dtype=torch.int32, device=dev)
     out = {}
-    for layout in ("g16", "nhwc"):
-        pvn._infer.set_options(layout=layout)
+    for layout in ("g16", "nhwc", "g16+edge"):   # "+edge": the opt-in middle + edge-pair launches of the group-of-16 kernel (round 4)
+        pvn._infer.set_options(layout=layout.split("+")[0], edge_tiles=layout.endswith("+edge"))
         full = pvn.evaluate_leaves_logits(x)
         part = pvn._infer.tower_activations(x[:3990].contiguous())
         plan = pvn.evaluate_leaves_logits(x, plan=(rows, n_rows))
         out[layout] = [t.clone() for t in (*full, part, plan[0][:3000], plan[1][:3000])]
-    for a, b in zip(out["g16"], out["nhwc"]):
-        assert torch.equal(a, b)
+    for a, b, c in zip(out["g16"], out["nhwc"], out["g16+edge"]):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    pvn._infer.set_options(layout="auto", edge_tiles=False)
     # the planned rows are the rows of the full batch
     assert torch.equal(out["g16"][3], out["g16"][0][rows.long()]) and torch.equal(out["g16"][4], out["g16"][1][rows.long()])
     assert out["g16"][2].shape == (3990, 256, 10, 9)
