@@ -609,8 +609,10 @@ def tower_roofline(a, pvn, e, sp, B, ev, tower_probe, rows_per_step, ms_per_step
     flops_per_row_layer = 2.0 * 90 * 256 * 256 * 9           # 106.17 MFLOP: one 3x3 256->256 layer on one board
     g16 = inf._g16(B)
     groups = inf.tower_groups(B, g16)
-    chains = inf.tower_chains(B, groups)
-    nr = {"bound": "mfma", "kernel": ("k_conv3x3_g16" if g16 else "k_conv3x3_c256") + " (tower conv3x3 256->256 + bias + residual + ReLU, fp16 in / fp32 acc)",
+    edge = inf._edge(B, g16)
+    chains = inf.tower_chains(B, groups, edge)
+    nr = {"bound": "mfma", "kernel": (("k_conv3x3_g16 (ranks 1..8) + k_conv3x3_g16_edge (ranks 0 / 9 of two groups per tile)" if edge else "k_conv3x3_g16") if g16 else "k_conv3x3_c256")
+                                     + " (tower conv3x3 256->256 + bias + residual + ReLU, fp16 in / fp32 acc)",
           "row_layout": "group-of-16 (whole-rank tiles, off-board taps skipped)" if g16 else "nhwc (256-pixel tiles)",
           "peak": MFMA_PEAK_F16 / 1e12, "unit": "TFLOP/s", "traffic": None, "launches_per_step": layers, "groups": groups, "chains": chains,
           "note": "a 'launch' is one layer over the step's live rows, issued as groups x chains kernel launches over board ranges "
@@ -623,7 +625,7 @@ def tower_roofline(a, pvn, e, sp, B, ev, tower_probe, rows_per_step, ms_per_step
                    "duration_source": f"HIP events around the tower of each of the {len(tower_probe)} timed steps, / {layers} layers (live, in the window)",
                    # the algorithmic count is the convention for a padded 3x3 convolution (9 taps for every pixel); the group-of-16
                    # kernel does not issue the MFMAs of taps with dx off the board (150 of 162 per pair of ranks)
-                   "mfma_flops_issued_per_launch": fl * (150.0 / 162.0 if g16 else 1.0)})
+                   "mfma_flops_issued_per_launch": fl * ((150.0 / 162.0 if not edge else 150.0 / 162.0 * (1.0 - 0.2 / 3.0)) if g16 else 1.0)})
         # a figure that cannot fit in the step it describes must not be printed
         assert layers * nr["avg_launch_us"] <= ms_per_step * 1e3 * 1.001, (layers * nr["avg_launch_us"], ms_per_step)
     # post-window: the whole batch through the tower (no plan), three times on real activations

@@ -101,8 +101,10 @@ class EvalOptions:
     torch GEMMs; ``CCZ_CONV_LAYOUT=auto|nhwc|g16`` (layout): activation row layout (auto: group-of-16 from 640 boards on);
     ``CCZ_CONV_FORCE=small|tile`` (force): one convolution kernel whatever the batch size; ``CCZ_TOWER_GROUPS`` / ``CCZ_TOWER_CHAINS``
     (groups, chains): launch structure of the tower; ``CCZ_CONV_ZIGZAG=0`` (zigzag): no alternating tile order;
-    ``CCZ_CONV_EDGE_TILES=1`` (edge_tiles): the group-of-16 convolution as a middle launch + an edge-pair launch (six live taps on the
-    edge ranks; same values; -3 % per layer in isolation, +0.7 % on the step with two launch chains: off by default)."""
+    ``CCZ_CONV_EDGE_TILES=0|1|auto`` (edge_tiles): the group-of-16 convolution as a middle launch + an edge-pair launch (six live taps on
+    the edge ranks; same values). auto (default): from 4096 boards on, with THREE launch chains -- +0.7...0.8 % sims/s there (three
+    interleaved pairs on one box, profiles/r04_conv_g16.json); below, the launches get too small: -1.4 % at 3072 boards, -5 % at 2048,
+    -14 % at 1024 (where round 3's single launch per layer stays)."""
 
     FIELDS = ("fused_conv", "fused_stem", "fused_heads", "layout", "force", "groups", "chains", "zigzag", "edge_tiles")
 
@@ -116,7 +118,8 @@ class EvalOptions:
         self.groups = int(env.get("CCZ_TOWER_GROUPS", "0"))
         self.chains = int(env.get("CCZ_TOWER_CHAINS", "0"))   # 0 = InferenceNet.TOWER_CHAINS
         self.zigzag = env.get("CCZ_CONV_ZIGZAG", "1") == "1"
-        self.edge_tiles = env.get("CCZ_CONV_EDGE_TILES", "0") == "1"   # group-of-16 layout: ranks 0 / 9 on the edge-pair kernel (round 4; opt-in)
+        # group-of-16 layout: ranks 0 / 9 on the edge-pair kernel (round 4): "auto" = from 4096 boards on, together with three launch chains
+        self.edge_tiles = {"0": False, "1": True}.get(env.get("CCZ_CONV_EDGE_TILES", "auto"), "auto")
         if self.layout not in ("auto", "nhwc", "g16"):
             raise ValueError("CCZ_CONV_LAYOUT must be auto, nhwc or g16")
 
@@ -234,9 +237,17 @@ class InferenceNet(nn.Module):
         """Sequential board groups of the tower for a batch of B boards (Infinity-Cache residency, :meth:`_tower_fused`)."""
         return self.opt.groups or -(-B // (self.TOWER_GROUP_BOARDS_G16 if g16 else self.TOWER_GROUP_BOARDS))
 
-    def tower_chains(self, B: int, groups: int = 1) -> int:
+    EDGE_TILES_MIN_BOARDS = 4096   # "auto": the edge-pair kernel + three chains from here on (measured crossover between 3072 and 4096)
+    TOWER_CHAINS_EDGE = 3
+
+    def _edge(self, B: int, g16: bool = True) -> bool:
+        """Does a batch of B boards run the group-of-16 convolution as middle launch + edge-pair launch (cczero_conv_g16e.h)?"""
+        et = self.opt.edge_tiles
+        return bool(g16 and (et is True or (et == "auto" and B >= self.EDGE_TILES_MIN_BOARDS)))
+
+    def tower_chains(self, B: int, groups: int = 1, edge: bool = False) -> int:
         """Concurrent launch chains per group (one HIP stream each)."""
-        return max(1, min(self.opt.chains or self.TOWER_CHAINS, 8, -(-B // groups) // 256))
+        return max(1, min(self.opt.chains or (self.TOWER_CHAINS_EDGE if edge else self.TOWER_CHAINS), 8, -(-B // groups) // 256))
 
     @torch.no_grad()
     def repack_derived(self):
@@ -295,7 +306,7 @@ class InferenceNet(nn.Module):
 
     TOWER_GROUP_BOARDS_G16 = 4096
     TOWER_GROUP_BOARDS = 2048  # boards per sequential group (working set of a group fits the Infinity Cache); env CCZ_TOWER_GROUPS
-    TOWER_CHAINS = 2  # independent board ranges run as concurrent launch chains (one HIP stream each); env CCZ_TOWER_CHAINS (<= 8)
+    TOWER_CHAINS = 2  # independent board ranges run as concurrent launch chains (one HIP stream each); env CCZ_TOWER_CHAINS (<= 8); three with the edge-pair kernel (TOWER_CHAINS_EDGE)
 
     def _tower_fused(self, x, plan=None, g16=None):
         """40 residual blocks = 80 launches of one kernel: conv3x3 + bias [+ x] + ReLU each (reference net.py:20-43).
@@ -340,13 +351,14 @@ class InferenceNet(nn.Module):
         from . import _lib
         B = x.shape[0]
         cur = torch.cuda.current_stream(x.device)
-        chains = 1 if torch.cuda.is_current_stream_capturing() else self.tower_chains(B, groups)
+        edge = self._edge(B, g16)
+        chains = 1 if torch.cuda.is_current_stream_capturing() else self.tower_chains(B, groups, edge)
         n_parts = groups * chains
         if g16:
             cap = -(-(B // 16) // n_parts) * 1440            # whole 16-board groups (B is padded to a multiple of 16)
         else:
             cap = -(-(-(-B // n_parts)) // 8) * 8 * 90       # pixels of the largest range a launch may get
-        lay = (_lib.CONV_G16 | (_lib.CONV_G16_EDGE_TILES if self.opt.edge_tiles else 0)) if g16 else 0
+        lay = (_lib.CONV_G16 | (_lib.CONV_G16_EDGE_TILES if edge else 0)) if g16 else 0
         if chains > 1:
             pool = getattr(self, "_chain_streams", None)
             if pool is None or pool[0] != x.device or len(pool[1]) < chains - 1:
@@ -379,7 +391,8 @@ class InferenceNet(nn.Module):
         from . import _lib
         B = hi - lo
         cur = torch.cuda.current_stream(x.device)
-        parts = 1 if torch.cuda.is_current_stream_capturing() else self.tower_chains(B)
+        edge = self._edge(x.shape[0], g16)
+        parts = 1 if torch.cuda.is_current_stream_capturing() else self.tower_chains(B, 1, edge)
         step = -(-B // parts)
         if parts > 1:
             step = -(-step // 128) * 128  # 128 boards = 45 whole tiles: no partial tile inside the batch
@@ -403,7 +416,7 @@ class InferenceNet(nn.Module):
         # alternates from layer to layer: what the previous layer wrote last (still in the Infinity Cache) is read
         # first (-0.7 % on the step; zigzag=False / CCZ_CONV_ZIGZAG=0 switches it off).
         down = 2 if self.opt.zigzag else 0
-        v2 = self.opt.force | ((_lib.CONV_G16 | (_lib.CONV_G16_EDGE_TILES if self.opt.edge_tiles else 0)) if g16 else 0)
+        v2 = self.opt.force | ((_lib.CONV_G16 | (_lib.CONV_G16_EDGE_TILES if edge else 0)) if g16 else 0)
         wsrc = self.ws_g16 if g16 else self.ws
         for i in range(0, len(self.ws), 2):
             w1, b1_, w2, b2_ = (C.c_void_p(t.data_ptr()) for t in (wsrc[i], self.bs32[i], wsrc[i + 1], self.bs32[i + 1]))
@@ -433,7 +446,7 @@ class InferenceNet(nn.Module):
             g16 = self._g16(B)
         s = C.c_void_p(torch.cuda.current_stream(leaf_input.device).cuda_stream)
         Bp = -(-B // 16) * 16 if g16 else B          # group-of-16 layout: whole groups; the padding boards hold zeros
-        lay = (_lib.CONV_G16 | (_lib.CONV_G16_EDGE_TILES if self.opt.edge_tiles else 0)) if g16 else 0
+        lay = _lib.CONV_G16 if g16 else 0   # (the stem is one launch over the whole batch, not chained: the single-kernel form)
         if plan is None:
             x64 = (torch.zeros if Bp != B else torch.empty)((Bp, 90, 64), dtype=torch.float16, device=leaf_input.device)
             y = torch.empty((Bp, 256, 10, 9), dtype=torch.float16, device=leaf_input.device, memory_format=torch.channels_last)

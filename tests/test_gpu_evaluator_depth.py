@@ -243,7 +243,7 @@ def test_both_row_layouts_give_the_same_evaluation(monkeypatch):
         out[layout] = [t.clone() for t in (*full, part, plan[0][:3000], plan[1][:3000])]
     for a, b, c in zip(out["g16"], out["nhwc"], out["g16+edge"]):
         assert torch.equal(a, b) and torch.equal(a, c)
-    pvn._infer.set_options(layout="auto", edge_tiles=False)
+    pvn._infer.set_options(layout="auto", edge_tiles="auto")
     # the planned rows are the rows of the full batch
     assert torch.equal(out["g16"][3], out["g16"][0][rows.long()]) and torch.equal(out["g16"][4], out["g16"][1][rows.long()])
     assert out["g16"][2].shape == (3990, 256, 10, 9)
