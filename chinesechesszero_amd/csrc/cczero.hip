@@ -776,15 +776,15 @@ static int conv3x3_launch(const char *who, void *stream, const void *x_dev, cons
                 hipLaunchKernelGGL(KERNEL_<false>, dim3((unsigned)(GRID_)), dim3(512), 0, STREAM_, (const _Float16 *)x_dev, (const _Float16 *)w_dev, \
                                    (const float *)bias_f32_dev, (const _Float16 *)nullptr, (_Float16 *)y_dev, (int)n_pixels, (int)(FLAGS_), cin, (const int *)live_rows_dev, (int)row0); \
         } while (0)
-        // Default: ONE launch of five two-rank tiles per group. CCZ_CONV_G16_EDGE_TILES (flag bit 7, round 4): the edge ranks (0 and 9)
-        // of two groups at a time are their own tiles on their own kernel (six live taps instead of nine, cczero_conv_g16e.h) and the
-        // middle launch covers ranks 1..8 with four two-rank tiles per group -- two ordinary launches back to back in the caller's
+        // Without the flag: ONE launch of five two-rank tiles per group. CCZ_CONV_G16_EDGE_TILES (flag bit 7, round 4): the edge ranks (0
+        // and 9) of two groups at a time are their own tiles on their own kernel (six live taps instead of nine, cczero_conv_g16e.h) and
+        // the middle launch covers ranks 1..8 with four two-rank tiles per group -- two ordinary launches back to back in the caller's
         // stream (no gap between them in the kernel trace). Same values. Measured (profiles/r04_conv_g16.json): -3 % per layer at 4096
-        // boards in isolation (1024 middle tiles = four full rounds of 256 CUs, 256 edge tiles = one round ~24 % shorter), but +0.7 %
-        // on the step in the workload: two launch chains of ~116 live groups each make it 464 + 116 tiles per launch, and the extra
-        // launch boundary per layer and chain costs more than the six taps save. Hence opt-in. (The edge launch on a helper stream
-        // beside the middle one put two event packets per layer on the main stream -- a 12.7 us gap between layers;
-        // hipExtAnyOrderLaunch is ignored on gfx9: the trace shows the kernels one after the other.)
+        // boards in isolation (1024 middle tiles = four full rounds of 256 CUs, 256 edge tiles = one round ~24 % shorter); in the
+        // workload +0.7 % on the step with two launch chains (the extra launch boundary per layer and chain costs more than the six
+        // taps save) but -0.7...-0.9 % with three: the evaluator sets the flag from 4096 boards on and runs three chains then. (The
+        // edge launch on a helper stream beside the middle one put two event packets per layer on the main stream -- a 12.7 us gap
+        // between layers; hipExtAnyOrderLaunch is ignored on gfx9: the trace shows the kernels one after the other.)
         if (!(relu & CCZ_CONV_G16_EDGE_TILES) || groups < 2) {
             CCZ_G16(k_conv3x3_g16, groups * 5, s, fl);
             HIP_TRY(hipGetLastError());

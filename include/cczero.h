@@ -379,8 +379,9 @@ int ccz_bias_act_f16(void *stream, void *y_dev, const void *bias_dev, const void
 #define CCZ_CONV_G16_EDGE_TILES 128 /* with CCZ_CONV_G16 (round 4, opt-in): the middle launch (ranks 1..8, four two-rank tiles per group) followed
                                        by the edge-pair launch (ranks 0 and 9 of two groups per tile, six live taps instead of nine:
                                        csrc/cczero_conv_g16e.h) instead of ONE launch of five tiles per group whose edge tiles multiply
-                                       zeroed ranks. Same values; -3 % per layer at 4096 boards in isolation, +0.7 % on the step in the
-                                       two-chain workload (an extra launch boundary per layer): off by default */
+                                       zeroed ranks. Same values; -3 % per layer at 4096 boards in isolation; in the workload it pays only
+                                       with three launch chains and from ~4096 boards on (+0.7...0.9 % sims/s), where the evaluator
+                                       sets it (InferenceNet edge_tiles=auto); smaller launches lose (profiles/r04_conv_g16.json) */
 int ccz_conv3x3_c256_f16(void *stream, const void *x_dev, const void *w_dev, const void *bias_f32_dev,
                          const void *residual_dev, void *y_dev, int64_t n_pixels, int32_t relu);
 /* Weights for the CCZ_CONV_G16 form, once per weight set: w [256, 3, 3, cin] fp16 (cin = 256: tower, 64: stem) ->
