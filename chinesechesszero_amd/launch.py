@@ -64,6 +64,14 @@ def preflight(n_ranks: int, share_gpu: bool = False, gpus: int | None = None) ->
     why not -- the parent prints it and exits non-zero before any child exists."""
     have = visible_gpus() if gpus is None else int(gpus)
     need = 1 if share_gpu else int(n_ranks)
+    if have < need and gpus is None:
+        # second opinion before refusing: a container may show less of the KFD topology than its processes can open. Counting
+        # devices through PyTorch-ROCm enumerates without creating a context (and a parent that only spawns children may hold one).
+        try:
+            import torch
+            have = max(have, int(torch.cuda.device_count()))
+        except Exception:
+            pass
     if have < need:
         return (f"bench: --gpus {n_ranks} needs {need} visible GPU(s), this node shows {have} "
                 f"(KFD topology / *_VISIBLE_DEVICES); not starting any rank")
