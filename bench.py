@@ -503,7 +503,9 @@ def main():
                 traffic_source = f"profiles/pmc_summary.json ({pm.get('run', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, separate runs')}), replayed, not live"
                 if net_roofline is not None:  # HBM bytes of one convolution launch (PMC passes of profiles/run_profile.sh)
                     per_kernel = pm.get("k_conv3x3", {}).get("hbm_bytes_per_launch")
-                    net_roofline["traffic"] = per_kernel * net_roofline["chains"] * net_roofline["groups"] if per_kernel else None
+                    # one layer over the live rows = groups x chains launches of the tower kernel(s), two per chain with the edge-pair
+                    # kernel; the committed counter is the average over ALL k_conv3x3* launches (middle and edge alike)
+                    net_roofline["traffic"] = per_kernel * net_roofline["chains"] * net_roofline["groups"] * net_roofline["kernel_launches_per_chain_and_layer"] if per_kernel else None
                     net_roofline["traffic_source"] = traffic_source
             except Exception:
                 traffic = None
@@ -615,6 +617,7 @@ def tower_roofline(a, pvn, e, sp, B, ev, tower_probe, rows_per_step, ms_per_step
                                      + " (tower conv3x3 256->256 + bias + residual + ReLU, fp16 in / fp32 acc)",
           "row_layout": "group-of-16 (whole-rank tiles, off-board taps skipped)" if g16 else "nhwc (256-pixel tiles)",
           "peak": MFMA_PEAK_F16 / 1e12, "unit": "TFLOP/s", "traffic": None, "launches_per_step": layers, "groups": groups, "chains": chains,
+          "kernel_launches_per_chain_and_layer": 2 if edge else 1,
           "note": "a 'launch' is one layer over the step's live rows, issued as groups x chains kernel launches over board ranges "
                   "(groups one after the other, the chains of a group concurrently)"}
     if tower_probe:
