@@ -35,13 +35,17 @@ def main():
             w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
             w.writeheader()
             w.writerows(keep)
-        for r in rows:
-            name = r.get("Name", "")
-            for k in ("k_step", "k_softmax_gather", "k_select", "k_expand_backup", "k_finish_move", "k_harvest", "k_bias_act", "k_conv3x3"):
-                if k in name:
-                    summary.setdefault(k, {})["avg_ns"] = float(r.get("AverageNs", 0) or 0)
-                    summary[k]["calls"] = int(float(r.get("Calls", 0) or 0))
-                    summary[k]["pct"] = float(r.get("Percentage", 0) or 0)
+        for k in ("k_step", "k_softmax_gather", "k_select", "k_expand_backup", "k_finish_move", "k_harvest", "k_bias_act", "k_conv3x3"):
+            # every instantiation / variant of a kernel family added up (k_conv3x3: g16 with and without residual, the edge-pair kernel)
+            hit = [r for r in rows if k in r.get("Name", "")]
+            if hit:
+                calls = sum(int(float(r.get("Calls", 0) or 0)) for r in hit)
+                tot = sum(float(r.get("TotalDurationNs", 0) or 0) for r in hit)
+                summary.setdefault(k, {})["avg_ns"] = tot / max(1, calls)
+                summary[k]["calls"] = calls
+                summary[k]["pct"] = sum(float(r.get("Percentage", 0) or 0) for r in hit)
+                if len(hit) > 1:
+                    summary[k]["variants"] = {r["Name"][:80]: {"calls": int(float(r["Calls"])), "avg_ns": float(r["AverageNs"])} for r in hit}
         # the evaluator's NON-tower kernels per step: every planned step launches k_cache_plan exactly once, so a kernel's launches
         # per step = its calls / k_cache_plan's calls (template instantiations of one kernel are added up)
         plan_calls = sum(int(float(r.get("Calls", 0) or 0)) for r in rows if "k_cache_plan" in r.get("Name", ""))
