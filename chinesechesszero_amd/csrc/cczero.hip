@@ -790,7 +790,7 @@ static int conv3x3_launch(const char *who, void *stream, const void *x_dev, cons
             HIP_TRY(hipGetLastError());
             return 0;
         }
-        CCZ_G16(k_conv3x3_g16, groups * 4, s, fl | 4);
+        CCZ_G16(k_conv3x3_g16, groups * 4, s, fl | 4);   // (edge launch first: measured the same, 194.4 / 194.3 k against 194.8 / 194.0 k sims/s)
         HIP_TRY(hipGetLastError());
         CCZ_G16(k_conv3x3_g16_edge, 2 * ((groups + 1) / 2), s, fl);
         HIP_TRY(hipGetLastError());
