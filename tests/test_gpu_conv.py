@@ -344,6 +344,10 @@ def test_group_of_16_kernel_gives_the_tile_kernels_values(boards):
     _lib.check(L.ccz_conv3x3_stem_f16(s, C.c_void_p(x64g.data_ptr()), C.c_void_p(_pack_w(w64, 64).data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(ysg.data_ptr()),
                                       boards * 90, 1 | _lib.CONV_G16))
     assert torch.equal(ysg.view(boards // 16, 90, 16, 256).permute(0, 2, 1, 3).reshape(boards * 90, 256), ys)
+    ysg2 = torch.full_like(ysg, float("nan"))   # the stem shape through the middle + edge-pair launches as well
+    _lib.check(L.ccz_conv3x3_stem_f16(s, C.c_void_p(x64g.data_ptr()), C.c_void_p(_pack_w(w64, 64).data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(ysg2.data_ptr()),
+                                      boards * 90, 1 | _lib.CONV_G16 | _lib.CONV_G16_EDGE_TILES))
+    assert torch.equal(ysg2, ysg)
     # not a multiple of 16 boards: refused
     assert L.ccz_conv3x3_c256_f16(s, C.c_void_p(xg.data_ptr()), C.c_void_p(wp.data_ptr()), C.c_void_p(b.data_ptr()), None, C.c_void_p(yg.data_ptr()),
                                   (boards - 1) * 90, 1 | _lib.CONV_G16) != 0

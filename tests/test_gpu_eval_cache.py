@@ -38,10 +38,10 @@ class LogitsEvaluator:
         return (x @ self.W).contiguous(), torch.tanh(x @ self.w).contiguous()
 
 
-def _play(B, n, moves, cache_log2, dev, seed=3, max_plies=40):
+def _play(B, n, moves, cache_log2, dev, seed=3, max_plies=40, **engine_kw):
     from chinesechesszero_amd.selfplay import BatchedSelfPlay
     ev = LogitsEvaluator(dev, seed=1)
-    sp = BatchedSelfPlay(ev, B, n_playout=n, seed=seed, max_plies=max_plies, eval_cache_log2=cache_log2)
+    sp = BatchedSelfPlay(ev, B, n_playout=n, seed=seed, max_plies=max_plies, eval_cache_log2=cache_log2, **engine_kw)
     assert sp.planned == (cache_log2 > 0)
     trace = []
     for _ in range(moves):
@@ -89,6 +89,33 @@ def test_cached_search_is_bit_identical_and_skips_repeated_positions():
     computed = s1["cache_probes"] - s1["cache_hits"] - s1["cache_shared_rows"]
     assert ev1.rows_asked == computed and ev0.rows_asked == B * n * moves
     assert computed < 0.8 * s1["cache_probes"]
+
+
+@pytest.mark.parametrize("variant", ["python-chess-lineage", "value_f16"])
+def test_cached_search_under_another_rule_preset_and_with_the_float16_value(variant):
+    """The cache under the options that change what an entry means or how it is consumed: a rule preset with another `legal_moves`
+    order (the priors of an entry are stored IN that order, and its 24-bit tag is a hash of that ordered list) and another plane
+    numbering; the float16 value arithmetic of the reference's CUDA path (the table keeps the float32 value, the backup rounds).
+    Cached and uncached searches stay identical."""
+    from chinesechesszero_amd import tools
+    dev = torch.device("cuda", 0)
+    kw = {"value_f16": True} if variant == "value_f16" else {}
+    try:
+        if variant != "value_f16":
+            tools.set_rules(preset=variant)
+        sp0, _, t0 = _play(40, 36, 5, 0, dev, seed=11, **kw)
+        sp1, _, t1 = _play(40, 36, 5, 14, dev, seed=11, **kw)
+    finally:
+        tools.set_rules()
+    if variant != "value_f16":
+        assert sp1.engine.move_rank is not None and sp1.engine.type_rank is not None
+    for (a, ma), (b, mb) in zip(t0, t1):
+        for key in ("k", "acts", "visits", "root_visits"):
+            assert np.array_equal(a[key], b[key]), key
+        assert np.array_equal(a["q"].view(np.uint32), b["q"].view(np.uint32)) and np.array_equal(a["prior"].view(np.uint32), b["prior"].view(np.uint32))
+        assert np.array_equal(ma, mb)
+    s1 = sp1.engine.stats()
+    assert s1["cache_hits"] > 0 and s1["cache_shared_rows"] > 0 and s1["error_flags"] == 0
 
 
 def test_transpositions_within_one_board_hit_the_cache():
