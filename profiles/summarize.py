@@ -81,7 +81,8 @@ def main():
     if both_here:
         for key in ("k_bar", "d_bar", "warning"):
             summary.get("k_step", {}).get("window", {}).pop(key, None)
-    for kind, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("pmc_cfetch", "FETCH_SIZE"), ("pmc_cwrite", "WRITE_SIZE")):
+    for kind, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("pmc_cfetch", "FETCH_SIZE"), ("pmc_cwrite", "WRITE_SIZE"),
+                          ("pmc_hfetch", "FETCH_SIZE"), ("pmc_hwrite", "WRITE_SIZE")):   # h*: the evaluator's tail kernels (round 4)
         cc = find(os.path.join(out_dir, kind), "*counter_collection.csv")
         if not cc:
             continue
@@ -91,7 +92,8 @@ def main():
             if r.get("Counter_Name") != counter:
                 continue
             name = r.get("Kernel_Name", "")
-            for k in ("k_step", "k_softmax_gather", "k_select", "k_expand_backup", "k_finish_move", "k_conv3x3"):
+            for k in ("k_step", "k_softmax_gather", "k_select", "k_expand_backup", "k_finish_move", "k_conv3x3", "k_head_conv1x1", "k_fc_f16",
+                      "k_pack_live_planes", "k_cache_plan", "k_cache_probe", "k_value_out"):
                 if k in name:
                     acc[k][0] += float(r.get("Counter_Value", 0) or 0)
                     acc[k][1] += 1
