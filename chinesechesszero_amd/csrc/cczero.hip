@@ -942,7 +942,8 @@ int ccz_fc_f16(void *stream, const void *a_dev, int32_t lda, const void *w_dev, 
     if ((k & 63) || (lda & 7) || lda < k || (n & 1) || (ldc & 1) || ldc < n) return fail(-1, "ccz_fc_f16: k must be a multiple of 64, lda a multiple of 8 and >= k, n and ldc even, ldc >= n");
     if ((((uintptr_t)a_dev) | ((uintptr_t)w_dev) | ((uintptr_t)bias_f32_dev)) & 15 || ((uintptr_t)c_dev & 3)) return fail(-1, "ccz_fc_f16: a, w, bias must be 16-byte aligned, c 4-byte aligned");
     if (m == 0) return 0;
-    const dim3 grid((unsigned)((n + kFcBN - 1) / kFcBN), (unsigned)((m + kFcBM - 1) / kFcBM));
+    const int tiles = ((n + kFcBN - 1) / kFcBN) * ((m + kFcBM - 1) / kFcBM);
+    const dim3 grid((unsigned)(8 * ((tiles + 7) / 8))); // XCD x = block mod 8 takes the x-th contiguous eighth of the tile order: see k_fc_f16
     if (relu & 1)
         hipLaunchKernelGGL(k_fc_f16<true>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16 *)a_dev, (int)lda, (const _Float16 *)w_dev,
                            (const float *)bias_f32_dev, (_Float16 *)c_dev, (int)ldc, (int)m, (int)n, (int)k, (const int *)live_rows_dev, (int)(relu >> 8));

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_head_conv1x1(const _Float16 *__restrict
 }
 
 // C[m, n] = act(bias[n] + sum_k A[m, k] W[n, k]); A [M][lda] fp16, W [ceil(N / 128) * 128][K] fp16 (rows past N zero), K a
-// multiple of 64, bias float [ceil(N / 128) * 128], C [M][ldc] fp16 (N and ldc even). grid (ceil(N / 128), ceil(M / 128)).
+// multiple of 64, bias float [ceil(N / 128) * 128], C [M][ldc] fp16 (N and ldc even). grid 8 * ceil(tiles / 8), tiles = ceil(N / 128) * ceil(M / 128), one-dimensional.
 // 128 x 128 output tile per workgroup, 4 waves of 64 x 64 (4 x 4 MFMA tiles); K in steps of 32 through a ring of FOUR 16 KB LDS
 // stages filled by global_load_lds three steps ahead (the first version staged through registers one step ahead: at 16 MFMAs per
 // wave and step the loop waited a memory round trip per step, 48 us for the policy layer). Rows are 64 bytes in LDS: chunk c
@@ -137,11 +137,26 @@ __global__ __launch_bounds__(256) void k_fc_f16(const _Float16 *__restrict__ A, 
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wv & 1, wm = wv >> 1;
     int Ml = M;
     if (live) { const int l = *live; Ml = l < Ml ? l : Ml; }
-    const int n0 = blockIdx.x * kFcBN, m0 = blockIdx.y * kFcBM;
-    if (m0 >= Ml) return;
-    // (An XCD-aware tile order -- XCD x owning the m tiles x, x + 8, ... and walking all n tiles over them, so that an XCD's L2
-    // holds its rows of A and every slice of W is fetched once per XCD -- was measured and dropped: 56.6 against 50.8 us for the
-    // policy layer. 29 m tiles over 8 XCDs put 68 tiles on the 64 workgroup slots of five XCDs: a second round for four tiles.)
+    // XCD-aware tile order. Workgroup b runs on XCD b mod 8 (round-robin dispatch), every XCD has its own 4 MB L2, and with the plain
+    // (n, m) grid every tile pair fetched both operands from past the L2: PMC 190 MB per launch of the policy layer against 36 MB
+    // algorithmic -- the kernel ran at the fabric's ~4 TB/s, not at the matrix pipe (ablation: MFMA-only 23 us, DMA-only 49 us). Here
+    // the tiles are put in an order in which neighbours share operands -- blocks of four m tiles, inside a block n-major (the four m
+    // tiles of one n tile next to each other) -- and XCD x takes the x-th CONTIGUOUS eighth of that order: it then holds <= 2 blocks
+    // of A rows (8 x 393 KB) and walks W once. Eighths differ by at most one tile (61-62 of 493: one round on the 64 workgroup slots
+    // of an XCD; a first attempt that gave XCD x the m tiles x, x + 8, ... put 68 tiles on five XCDs and lost 6 us to the second round).
+    const int mt = (Ml + kFcBM - 1) / kFcBM, nt = (N + kFcBN - 1) / kFcBN, tiles = mt * nt;
+    int n0, m0;
+    {
+        const int b = blockIdx.x, x = b & 7, per = tiles >> 3, rem = tiles & 7;
+        if ((b >> 3) >= per + (x < rem ? 1 : 0)) return;
+        const int t = x * per + (x < rem ? x : rem) + (b >> 3);
+        const int full = (mt >> 2) * 4 * nt;          // tiles of the complete four-m-tile blocks
+        const int blk = t < full ? t / (4 * nt) : (mt >> 2);
+        const int r_ = t < full ? t % (4 * nt) : t - full;
+        const int cnt = t < full ? 4 : mt - 4 * blk;
+        n0 = (r_ / cnt) * kFcBN;
+        m0 = (4 * blk + r_ % cnt) * kFcBM;
+    }
     // DMA: per stage and operand 512 sixteen-byte granules = 2 per thread. Instruction j of wave wv fills LDS granules
     // (j * 4 + wv) * 64 + lane (lane-linear); granule p holds row p >> 2, position p & 3 = source chunk (p & 3) ^ ((row >> 2) & 3)
     const _Float16 *wsrc[2], *asrc[2];
