@@ -112,6 +112,7 @@ PROTOTYPES = {
     "ccz_pack_conv_weights_g16_f16": (C.c_int, [_P, _P, _P, C.c_int32]),
     "ccz_conv3x3_c256_f16_live": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, _P, C.c_int32, C.c_int32]),
     "ccz_conv3x3_stem_f16_live": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int32, _P, C.c_int32, C.c_int32]),
+    "ccz_conv3x3_c256_heads_f16": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, _P, C.c_int32, C.c_int32]),
     "ccz_heads_conv1x1_f16": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
     "ccz_fc_f16": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "ccz_value_out_f32": (C.c_int, [_P, _P, _P, C.c_float, _P, C.c_int32, _P]),

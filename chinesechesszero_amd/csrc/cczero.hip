@@ -833,6 +833,45 @@ int ccz_conv3x3_c256_f16(void *stream, const void *x_dev, const void *w_dev, con
     return conv3x3_launch("ccz_conv3x3_c256_f16", stream, x_dev, w_dev, bias_f32_dev, residual_dev, y_dev, n_pixels, relu, 256);
 }
 
+int ccz_conv3x3_c256_heads_f16(void *stream, const void *x_dev, const void *w_dev, const void *bias_f32_dev, const void *residual_dev,
+                               const void *head_w32_dev, const void *head_b32_dev, void *pol_dev, void *val_dev, int64_t n_pixels, int32_t flags,
+                               const int32_t *live_rows_dev, int32_t part, int32_t n_parts)
+{
+    const char *who = "ccz_conv3x3_c256_heads_f16";
+    if (!x_dev || !w_dev || !bias_f32_dev || !residual_dev || !head_w32_dev || !head_b32_dev || !pol_dev || !val_dev || n_pixels < 0 || n_pixels % 1440 ||
+        n_pixels > (int64_t)INT32_MAX / kCvC)
+        return fail(-1, "%s: bad arguments (n_pixels must be a multiple of 16 boards * 90, at most 93200 boards per call)", who);
+    if (!(flags & CCZ_CONV_G16)) return fail(-1, "%s: rows must be in the group-of-16 layout (CCZ_CONV_G16)", who);
+    if ((((uintptr_t)x_dev) | ((uintptr_t)w_dev) | ((uintptr_t)bias_f32_dev) | ((uintptr_t)residual_dev) | ((uintptr_t)head_w32_dev) | ((uintptr_t)head_b32_dev)) & 15)
+        return fail(-1, "%s: pointers must be 16-byte aligned", who);
+    if ((((uintptr_t)pol_dev) | ((uintptr_t)val_dev)) & 1) return fail(-1, "%s: outputs must be 2-byte aligned", who);
+    if (live_rows_dev && (n_parts < 1 || n_parts > 256 || part < 0 || part >= n_parts)) return fail(-1, "%s: bad part / n_parts", who);
+    if (n_pixels == 0) return 0;
+    const int groups = (int)(n_pixels / 1440);
+    const int fl = flags & 3, row0 = live_rows_dev ? (part | (n_parts << 16)) : 0;
+    G5Heads ha;
+    ha.w32 = (const _Float16 *)head_w32_dev;
+    ha.b32 = (const float *)head_b32_dev;
+    ha.pol = (_Float16 *)pol_dev;
+    ha.val = (_Float16 *)val_dev;
+    ha.nb = (int)(n_pixels / 90);
+    hipStream_t s = (hipStream_t)stream;
+#define CCZ_G16H(KERNEL_, GRID_, FLAGS_)                                                                                                \
+    hipLaunchKernelGGL(KERNEL_, dim3((unsigned)(GRID_)), dim3(512), 0, s, (const _Float16 *)x_dev, (const _Float16 *)w_dev, (const float *)bias_f32_dev, \
+                       (const _Float16 *)residual_dev, (_Float16 *)nullptr, (int)n_pixels, (int)(FLAGS_), 256, (const int *)live_rows_dev, row0, ha)
+    if (!(flags & CCZ_CONV_G16_EDGE_TILES) || groups < 2) {
+        CCZ_G16H(k_conv3x3_g16_heads, groups * 5, fl);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    CCZ_G16H(k_conv3x3_g16_heads, groups * 4, fl | 4);
+    HIP_TRY(hipGetLastError());
+    CCZ_G16H(k_conv3x3_g16_edge_heads, 2 * ((groups + 1) / 2), fl);
+    HIP_TRY(hipGetLastError());
+#undef CCZ_G16H
+    return 0;
+}
+
 int ccz_conv3x3_stem_f16(void *stream, const void *x64_dev, const void *w_dev, const void *bias_f32_dev, void *y_dev, int64_t n_pixels, int32_t relu)
 {
     return conv3x3_launch("ccz_conv3x3_stem_f16", stream, x64_dev, w_dev, bias_f32_dev, nullptr, y_dev, n_pixels, relu, 64);

@@ -186,12 +186,71 @@ __device__ __forceinline__ void g5_step(const G5Ctx &c, cv_f32x4 (&acc)[4][9], i
 #undef G5_CELL
 }
 
-template <bool RES>
-__global__ __launch_bounds__(512) void k_conv3x3_g16(const _Float16 *__restrict__ X, const _Float16 *__restrict__ W,
-                                                         const float *__restrict__ bias, const _Float16 *R,
-                                                         _Float16 *Y, int M, int relu, int cin, const int *live_rows, int row0)
+// ---- the heads fused into the LAST tower layer (round 4) ------------------------------------------------------------------------------
+// The tower's last layer writes 170 MB of activations that only the two 1x1 head convolutions read (k_head_conv1x1: 46 us, HBM-bound).
+// In the HEADS instantiation the layer's epilogue keeps its finished rows (conv + bias + residual, ReLU) in the LDS image instead of
+// storing them, and the workgroup multiplies them with the 24 head channels right there: per 16-row cell 16 MFMAs against the 72 x 36
+// of the tile's own loop. The output tensor of the layer is never written; the head outputs leave in board order exactly as
+// k_head_conv1x1 writes them (cczero_heads.h) -- same operands, same chain of MFMAs over k = 0, 32, ...: the same bits.
+struct G5Heads {
+    const _Float16 *w32; // [32][256]: rows 0..16 policy, 17..23 value, 24..31 zero
+    const float *b32;    // [32]
+    _Float16 *pol, *val; // [boards][1536], [boards][640] (cczero_heads.h kHdPolStride / kHdValStride)
+    int nb;              // boards that hold rows (compact live count or the batch size): stores past it are skipped
+};
+
+// `board0[wnr]` / `pos0[wnr]`: first board (group * 16) and first position (rank * 9) of image rows 144 wnr .. 144 wnr + 143 (wnr = 0, 1);
+// `skip1`: image rows 144..287 are a duplicate (edge kernel, odd group count). Called by every wave after the barrier that publishes the
+// image of FINISHED rows.
+__device__ __forceinline__ void g5_heads_phase(const unsigned char *lds, int w, int lane, const G5Heads &ha, const long (&board0)[2],
+                                               const int (&pos0)[2], bool skip1)
+{
+    const int r = lane & 15, q4 = lane >> 4;
+    cv_half8 a[2][8];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) a[m][s] = *(const cv_half8 *)(ha.w32 + (m * 16 + r) * 256 + s * 32 + q4 * 8);
+    const float4 b0 = *(const float4 *)(ha.b32 + 4 * q4), b1 = *(const float4 *)(ha.b32 + 16 + 4 * q4);
+    for (int cell = w; cell < 18; cell += 8) { // 18 cells of 16 rows over 8 waves
+        const unsigned char *row = lds + (cell * 16 + r) * kG5ERow + q4 * 16;
+        cv_f32x4 acc0, acc1;
+        acc0[0] = b0.x; acc0[1] = b0.y; acc0[2] = b0.z; acc0[3] = b0.w;
+        acc1[0] = b1.x; acc1[1] = b1.y; acc1[2] = b1.z; acc1[3] = b1.w;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const cv_half8 b = *(const cv_half8 *)(row + s * 64);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][s], b, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1][s], b, acc1, 0, 0, 0);
+        }
+        const int wnr = cell >= 9 ? 1 : 0, n = cell - 9 * wnr;
+        const long board = board0[wnr] + r;
+        if (board < ha.nb && !(skip1 && wnr)) {
+            const int pos = pos0[wnr] + n;
+            _Float16 *po = ha.pol + board * 1536 + pos * 17;
+            _Float16 *vo = ha.val + board * 640 + pos * 7;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) po[4 * q4 + e] = (_Float16)fmaxf(acc0[e], 0.0f);
+            if (q4 == 0) {
+                po[16] = (_Float16)fmaxf(acc1[0], 0.0f);
+                vo[0] = (_Float16)fmaxf(acc1[1], 0.0f);
+                vo[1] = (_Float16)fmaxf(acc1[2], 0.0f);
+                vo[2] = (_Float16)fmaxf(acc1[3], 0.0f);
+            } else if (q4 == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vo[3 + e] = (_Float16)fmaxf(acc1[e], 0.0f);
+            }
+        }
+    }
+}
+
+template <bool RES, bool HEADS>
+__device__ __forceinline__ void g5_tile(const _Float16 *__restrict__ X, const _Float16 *__restrict__ W,
+                                        const float *__restrict__ bias, const _Float16 *R,
+                                        _Float16 *Y, int M, int relu, int cin, const int *live_rows, int row0, const G5Heads &ha)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kG5Lds];
+    [[maybe_unused]] long first_board = 0; // (HEADS) global index of this launch's first board: the live parts offset their pointers
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q4 = lane >> 4;
@@ -216,6 +275,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_g16(const _Float16 *__restrict_
         X += (long)first * 1440 * cin;
         Y += off;
         if (RES) R += off;
+        first_board = (long)first * 16;
     }
     // XCD-aware order: workgroup b runs on XCD b % 8 (round-robin dispatch), and the five tiles of a group read each other's
     // ranks as halo -- so XCD x takes the x-th CONTIGUOUS eighth of the tiles, in order: a halo rank is then in that XCD's L2
@@ -356,15 +416,45 @@ __global__ __launch_bounds__(512) void k_conv3x3_g16(const _Float16 *__restrict_
     __builtin_amdgcn_sched_barrier(0);
     {
         const cv_half8 zero = (cv_half8)(_Float16)0;
-        const unsigned char *eb = lds + (w * 36 + prow) * kG5ERow + piece * 16;
+        unsigned char *eb = lds + (w * 36 + prow) * kG5ERow + piece * 16;
 #pragma unroll
         for (int it = 0; it < 18; ++it) {
             cv_half8 v = *(const cv_half8 *)(eb + it * 2 * kG5ERow);
             if (RES) v = v + rv[it];
             if (relu) v = __builtin_elementwise_max(v, zero);
-            *(cv_half8 *)(Y + (pbase + it * 2) * kCvC + piece * 8) = v;
+            if constexpr (HEADS) *(cv_half8 *)(eb + it * 2 * kG5ERow) = v;   // the finished row stays in the image; Y is not written
+            else *(cv_half8 *)(Y + (pbase + it * 2) * kCvC + piece * 8) = v;
         }
     }
+    if constexpr (HEADS) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier(); // every finished row is in the image
+        __builtin_amdgcn_sched_barrier(0);
+        // image rows 0..143 = the tile's first rank, 144..287 = its second: tensor row p0 + i = (group * 90 + 9 * rank + cell) * 16 + board
+        const long grp = p0 / 1440;
+        const int rank0 = (int)((p0 - grp * 1440) / 144);
+        const long board0[2] = {first_board + grp * 16, first_board + grp * 16};
+        const int pos0[2] = {rank0 * 9, rank0 * 9 + 9};
+        g5_heads_phase(lds, w, lane, ha, board0, pos0, false);
+    }
+}
+
+template <bool RES>
+__global__ __launch_bounds__(512) void k_conv3x3_g16(const _Float16 *__restrict__ X, const _Float16 *__restrict__ W,
+                                                         const float *__restrict__ bias, const _Float16 *R,
+                                                         _Float16 *Y, int M, int relu, int cin, const int *live_rows, int row0)
+{
+    g5_tile<RES, false>(X, W, bias, R, Y, M, relu, cin, live_rows, row0, G5Heads{});
+}
+
+// The last layer of the tower with the heads in its epilogue (always with residual; Y may be null: nothing is stored to it).
+__global__ __launch_bounds__(512) void k_conv3x3_g16_heads(const _Float16 *__restrict__ X, const _Float16 *__restrict__ W,
+                                                             const float *__restrict__ bias, const _Float16 *R, _Float16 *Y, int M,
+                                                             int relu, int cin, const int *live_rows, int row0, G5Heads ha)
+{
+    if (live_rows) ha.nb = *live_rows; // planned boundary: the pointers are the whole batch's, M only the capacity of this part
+    g5_tile<true, true>(X, W, bias, R, Y, M, relu, cin, live_rows, row0, ha);
 }
 
 // Weights for k_conv3x3_g16: [co][tap][ci] (the memory of a channels-last [co, ci, 3, 3] tensor) -> [ci / 32][tap][co][32], each

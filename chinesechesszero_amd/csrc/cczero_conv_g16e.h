@@ -105,12 +105,13 @@ __device__ __forceinline__ void g5e_step(const G5Ctx &c, cv_f32x4 (&acc)[4][9], 
 
 // X, Y, R: rows in the group-of-16 layout, M rows (a multiple of 1440); W packed (k_pack_conv_weights_g16). grid = 2 * ceil(groups
 // / 2): workgroup e = pair e / 2 of groups, side e & 1 (0: rank 0, 1: rank 9). live_rows / row0: as k_conv3x3_g16 (planned boundary).
-template <bool RES>
-__global__ __launch_bounds__(512) void k_conv3x3_g16_edge(const _Float16 *__restrict__ X, const _Float16 *__restrict__ W,
-                                                            const float *__restrict__ bias, const _Float16 *R, _Float16 *Y, int M,
-                                                            int relu, int cin, const int *live_rows, int row0)
+template <bool RES, bool HEADS>
+__device__ __forceinline__ void g5e_tile(const _Float16 *__restrict__ X, const _Float16 *__restrict__ W,
+                                         const float *__restrict__ bias, const _Float16 *R, _Float16 *Y, int M,
+                                         int relu, int cin, const int *live_rows, int row0, const G5Heads &ha)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kG5Lds];
+    [[maybe_unused]] long first_board = 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q4 = lane >> 4;
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_g16_edge(const _Float16 *__rest
         X += (long)first * 1440 * cin;
         Y += off;
         if (RES) R += off;
+        first_board = (long)first * 16;
     }
     const int e = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
     if (e >= 2 * ((groups + 1) >> 1)) return;
@@ -240,15 +242,41 @@ __global__ __launch_bounds__(512) void k_conv3x3_g16_edge(const _Float16 *__rest
     __builtin_amdgcn_sched_barrier(0);
     if (store) {
         const cv_half8 zero = (cv_half8)(_Float16)0;
-        const unsigned char *eb = lds + (w * 36 + prow) * kG5ERow + piece * 16;
+        unsigned char *eb = lds + (w * 36 + prow) * kG5ERow + piece * 16;
 #pragma unroll
         for (int it = 0; it < 18; ++it) {
             cv_half8 v = *(const cv_half8 *)(eb + it * 2 * kG5ERow);
             if (RES) v = v + rv[it];
             if (relu) v = __builtin_elementwise_max(v, zero);
-            *(cv_half8 *)(Y + (pbase + it * 2) * kCvC + piece * 8) = v;
+            if constexpr (HEADS) *(cv_half8 *)(eb + it * 2 * kG5ERow) = v;   // the finished row stays in the image; Y is not written
+            else *(cv_half8 *)(Y + (pbase + it * 2) * kCvC + piece * 8) = v;
         }
     }
+    if constexpr (HEADS) { // the heads on the finished rows (cczero_conv_g16.h g5_heads_phase): image rows 0..143 group A's edge rank, 144..287 group B's
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const long board0[2] = {first_board + (long)gA * 16, first_board + (long)gB * 16};
+        const int pos0[2] = {side ? 81 : 0, side ? 81 : 0};
+        g5_heads_phase(lds, w, lane, ha, board0, pos0, dup);
+    }
+}
+
+template <bool RES>
+__global__ __launch_bounds__(512) void k_conv3x3_g16_edge(const _Float16 *__restrict__ X, const _Float16 *__restrict__ W,
+                                                            const float *__restrict__ bias, const _Float16 *R, _Float16 *Y, int M,
+                                                            int relu, int cin, const int *live_rows, int row0)
+{
+    g5e_tile<RES, false>(X, W, bias, R, Y, M, relu, cin, live_rows, row0, G5Heads{});
+}
+
+__global__ __launch_bounds__(512) void k_conv3x3_g16_edge_heads(const _Float16 *__restrict__ X, const _Float16 *__restrict__ W,
+                                                                  const float *__restrict__ bias, const _Float16 *R, _Float16 *Y,
+                                                                  int M, int relu, int cin, const int *live_rows, int row0, G5Heads ha)
+{
+    if (live_rows) ha.nb = *live_rows; // planned boundary: the pointers are the whole batch's, M only the capacity of this part
+    g5e_tile<true, true>(X, W, bias, R, Y, M, relu, cin, live_rows, row0, ha);
 }
 
 } // namespace ccz

@@ -104,15 +104,18 @@ class EvalOptions:
     ``CCZ_CONV_EDGE_TILES=0|1|auto`` (edge_tiles): the group-of-16 convolution as a middle launch + an edge-pair launch (six live taps on
     the edge ranks; same values). auto (default): from 4096 boards on, with THREE launch chains -- +0.7...0.8 % sims/s there (three
     interleaved pairs on one box, profiles/r04_conv_g16.json); below, the launches get too small: -1.4 % at 3072 boards, -5 % at 2048,
-    -14 % at 1024 (where round 3's single launch per layer stays)."""
+    -14 % at 1024 (where round 3's single launch per layer stays);
+    ``CCZ_FUSED_LAST=0`` (fused_last): the head convolutions as a pass of their own over the stored output of the tower instead of in
+    the last layer's epilogue (group-of-16 rows; same bits either way)."""
 
-    FIELDS = ("fused_conv", "fused_stem", "fused_heads", "layout", "force", "groups", "chains", "zigzag", "edge_tiles")
+    FIELDS = ("fused_conv", "fused_stem", "fused_heads", "fused_last", "layout", "force", "groups", "chains", "zigzag", "edge_tiles")
 
     def __init__(self, env=None):
         env = os.environ if env is None else env
         self.fused_conv = env.get("CCZ_FUSED_CONV", "1") != "0"
         self.fused_stem = env.get("CCZ_FUSED_STEM", "1") != "0"
         self.fused_heads = env.get("CCZ_FUSED_HEADS", "1") != "0"
+        self.fused_last = env.get("CCZ_FUSED_LAST", "1") != "0"
         self.layout = env.get("CCZ_CONV_LAYOUT", "auto")
         self.force = {"small": 16, "tile": 32}.get(env.get("CCZ_CONV_FORCE", ""), 0)
         self.groups = int(env.get("CCZ_TOWER_GROUPS", "0"))
@@ -308,7 +311,7 @@ class InferenceNet(nn.Module):
     TOWER_GROUP_BOARDS = 2048  # boards per sequential group (working set of a group fits the Infinity Cache); env CCZ_TOWER_GROUPS
     TOWER_CHAINS = 2  # independent board ranges run as concurrent launch chains (one HIP stream each); env CCZ_TOWER_CHAINS (<= 8); three with the edge-pair kernel (TOWER_CHAINS_EDGE)
 
-    def _tower_fused(self, x, plan=None, g16=None):
+    def _tower_fused(self, x, plan=None, g16=None, heads=None):
         """40 residual blocks = 80 launches of one kernel: conv3x3 + bias [+ x] + ReLU each (reference net.py:20-43).
         ``plan`` = (rows, n_rows) of the planned evaluator boundary: only the first ``n_rows`` (a device value) boards of ``x``
         are live; every launch skips the tiles past them (``ccz_conv3x3_c256_f16_live``).
@@ -319,7 +322,9 @@ class InferenceNet(nn.Module):
         8: 28.6 (same-weights microbench profiles/conv_streams.py: 352 -> 319 -> 311 us per layer for 1 / 2 / 8 chains); round 3,
         group-of-16 rows with the evaluation cache: 1 chain 24.9, 2 chains 23.5, 3: 23.3-24.0, 4: 24.4 (profiles/r03_conv_g16.json).
         Inside a stream capture (hipGraph) one chain is used. ``g16``: the rows of ``x`` are in the group-of-16 order
-        (``None``: as :meth:`_stem_fused` lays out a batch of this size)."""
+        (``None``: as :meth:`_stem_fused` lays out a batch of this size). ``heads`` = (pol, val) buffers of :meth:`_head_buffers`
+        (group-of-16 rows only): the LAST layer runs as ``ccz_conv3x3_c256_heads_f16`` -- both head convolutions in its epilogue,
+        its own output never stored: the returned tensor then holds the input of the last block, not the tower's output."""
         import ctypes as C
         from . import _lib
         L = _lib.lib()
@@ -336,14 +341,14 @@ class InferenceNet(nn.Module):
         if torch.cuda.is_current_stream_capturing():
             groups = 1
         if plan is not None:
-            self._tower_planned(L, C, x, y, plan, groups, g16)
+            self._tower_planned(L, C, x, y, plan, groups, g16, heads)
             return x
         gstep = -(-(-(-Bt // groups)) // 128) * 128 if groups > 1 else Bt
         for g0 in range(0, Bt, gstep):
-            self._tower_range(L, C, x, y, g0, min(Bt, g0 + gstep), g16)
+            self._tower_range(L, C, x, y, g0, min(Bt, g0 + gstep), g16, heads)
         return x
 
-    def _tower_planned(self, L, C, x, y, plan, groups, g16=False):
+    def _tower_planned(self, L, C, x, y, plan, groups, g16=False, heads=None):
         """The tower on the LIVE rows of a planned batch (``ccz_eval_plan``): the live rows -- a device-side count -- are cut
         into groups x chains EQUAL ranges by the kernel itself (``ccz_conv3x3_c256_f16_live``: part / n_parts), so that the
         concurrent chains of a group stay balanced whatever the live count is. Launch structure as in :meth:`_tower_range`:
@@ -379,6 +384,11 @@ class InferenceNet(nn.Module):
                 w1, b1_, w2, b2_ = (C.c_void_p(t.data_ptr()) for t in (wsrc[i], self.bs32[i], wsrc[i + 1], self.bs32[i + 1]))
                 for k, st in enumerate(streams):
                     _lib.check(L.ccz_conv3x3_c256_f16_live(C.c_void_p(st.cuda_stream), xp, w1, b1_, None, yp, cap, 1 | down | lay, live, g * chains + k, n_parts))
+                if heads is not None and i == len(self.ws) - 2:   # the last layer: heads in the epilogue, no output tensor
+                    hw, hb, hp, hv = (C.c_void_p(t.data_ptr()) for t in (self.head_w32, self.head_b32, heads[0], heads[1]))
+                    for k, st in enumerate(streams):
+                        _lib.check(L.ccz_conv3x3_c256_heads_f16(C.c_void_p(st.cuda_stream), yp, w2, b2_, xp, hw, hb, hp, hv, cap, 1 | lay, live, g * chains + k, n_parts))
+                    continue
                 for k, st in enumerate(streams):
                     _lib.check(L.ccz_conv3x3_c256_f16_live(C.c_void_p(st.cuda_stream), yp, w2, b2_, xp, xp, cap, 1 | lay, live, g * chains + k, n_parts))
             for st in streams[1:]:
@@ -386,7 +396,7 @@ class InferenceNet(nn.Module):
                 join.record(st)
                 cur.wait_event(join)
 
-    def _tower_range(self, L, C, x, y, lo, hi, g16=False):
+    def _tower_range(self, L, C, x, y, lo, hi, g16=False, heads=None):
         """Boards [lo, hi) through all 80 layers, as TOWER_CHAINS concurrent launch chains."""
         from . import _lib
         B = hi - lo
@@ -422,6 +432,13 @@ class InferenceNet(nn.Module):
             w1, b1_, w2, b2_ = (C.c_void_p(t.data_ptr()) for t in (wsrc[i], self.bs32[i], wsrc[i + 1], self.bs32[i + 1]))
             for _, s, xp, yp, n_pixels, _b0 in chains:
                 _lib.check(L.ccz_conv3x3_c256_f16(s, xp, w1, b1_, None, yp, n_pixels, 1 | down | v2))
+            if heads is not None and i == len(self.ws) - 2:   # the last layer: heads in the epilogue, no output tensor
+                hw, hb = C.c_void_p(self.head_w32.data_ptr()), C.c_void_p(self.head_b32.data_ptr())
+                for _, s, xp, yp, n_pixels, b0 in chains:
+                    hp = C.c_void_p(heads[0].data_ptr() + b0 * heads[0].stride(0) * 2)
+                    hv = C.c_void_p(heads[1].data_ptr() + b0 * heads[1].stride(0) * 2)
+                    _lib.check(L.ccz_conv3x3_c256_heads_f16(s, yp, w2, b2_, xp, hw, hb, hp, hv, n_pixels, 1 | v2, None, 0, 1))
+                continue
             for _, s, xp, yp, n_pixels, _b0 in chains:
                 _lib.check(L.ccz_conv3x3_c256_f16(s, yp, w2, b2_, xp, xp, n_pixels, 1 | v2))  # output written over the residual input
         for st, *_ in chains[1:]:  # every side stream is joined into the current stream
@@ -521,10 +538,14 @@ class InferenceNet(nn.Module):
             if probe is not None:   # (recorded on the current stream: the chains fork from it and join it)
                 p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 p0.record()
-            x = self._tower_fused(x, plan, g16)
+            # group-of-16 rows: the head convolutions ride in the last tower layer's epilogue (fused_last; CCZ_FUSED_LAST=0: a pass of their own)
+            heads = self._head_buffers(x.shape[0], x.device)[:2] if (g16 and self.opt.fused_last and self._fused_heads_ok(x)) else None
+            x = self._tower_fused(x, plan, g16, heads)
             if probe is not None:
                 p1.record()
                 probe.append((p0, p1))
+            if heads is not None:
+                return self._heads(x, B, g16, plan, return_logits, conv_done=True)
         else:
             x = leaf_input.view(B, PLAYS * PIECES, 10, 9)
             if self.live_only:
@@ -547,7 +568,23 @@ class InferenceNet(nn.Module):
                     x = self._epilogue(F.conv2d(y, self.ws[i + 1], None, padding=1), self.bs[i + 1], x)
         return self._heads(x, B, g16, plan, return_logits)
 
-    def _heads_fused(self, x, B, g16, plan):
+    def _fused_heads_ok(self, x) -> bool:
+        return bool(self.opt.fused_heads and hasattr(self, "head_w32") and x.is_cuda and x.dtype == torch.float16 and x.shape[1] == 256
+                    and x.is_contiguous(memory_format=torch.channels_last))
+
+    def _head_buffers(self, Bx, dev):
+        """(pol [Bx, 1536], val [Bx, 640], h1 [Bx, 256]) fp16: the head convolutions' outputs in board order and the hidden value
+        layer. The pad columns of pol / val are never written and must be zero: allocated once per batch shape, zeroed once."""
+        from . import _lib
+        bufs = self.__dict__.setdefault("_head_bufs", {})
+        key = (Bx, dev)
+        if key not in bufs:
+            bufs[key] = (torch.zeros((Bx, _lib.HEAD_POL_STRIDE), dtype=torch.float16, device=dev),
+                         torch.zeros((Bx, _lib.HEAD_VAL_STRIDE), dtype=torch.float16, device=dev),
+                         torch.empty((Bx, 256), dtype=torch.float16, device=dev))
+        return bufs[key]
+
+    def _heads_fused(self, x, B, g16, plan, conv_done=False):
         """The evaluator's tail on the hand-written kernels (csrc/cczero_heads.h): both 1x1 head convolutions + ReLU + the
         group-of-16 -> board permutation in ONE pass over the tower's rows, the two big FC layers as MFMA GEMMs, value_fc2 + tanh
         -- on the LIVE rows only (``plan``: a device-side count), the same bits for a board at every batch size. Returns
@@ -556,19 +593,14 @@ class InferenceNet(nn.Module):
         from . import _lib
         L = _lib.lib()
         Bx, dev = x.shape[0], x.device
-        bufs = self.__dict__.setdefault("_head_bufs", {})
-        key = (Bx, dev)
-        if key not in bufs:   # the pad columns (never written) must be zero: allocated once, zeroed once
-            bufs[key] = (torch.zeros((Bx, _lib.HEAD_POL_STRIDE), dtype=torch.float16, device=dev),
-                         torch.zeros((Bx, _lib.HEAD_VAL_STRIDE), dtype=torch.float16, device=dev),
-                         torch.empty((Bx, 256), dtype=torch.float16, device=dev))
-        pol, val, h1 = bufs[key]
+        pol, val, h1 = self._head_buffers(Bx, dev)
         logits = torch.empty((B, 2086), dtype=torch.float16, device=dev)
         v = torch.empty((B,), dtype=torch.float32, device=dev)
         s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         live = C.c_void_p(plan[1].data_ptr()) if plan is not None else None
         P = lambda t: C.c_void_p(t.data_ptr())
-        _lib.check(L.ccz_heads_conv1x1_f16(s, P(x), P(self.head_w32), P(self.head_b32), P(pol), P(val), Bx, _lib.CONV_G16 if g16 else 0, live))
+        if not conv_done:   # (conv_done: the last tower layer wrote pol / val from its epilogue, ``x`` is not the tower's output)
+            _lib.check(L.ccz_heads_conv1x1_f16(s, P(x), P(self.head_w32), P(self.head_b32), P(pol), P(val), Bx, _lib.CONV_G16 if g16 else 0, live))
         _lib.check(L.ccz_fc_f16(s, P(pol), _lib.HEAD_POL_STRIDE, P(self.policy_fc_wp), P(self.policy_fc_b32), P(logits), 2086, B, 2086, 1536, 0, live))
         _lib.check(L.ccz_fc_f16(s, P(val), _lib.HEAD_VAL_STRIDE, P(self.value_fc1_wp), P(self.value_fc1_b32), P(h1), 256, B, 256, 640, 1, live))
         _lib.check(L.ccz_value_out_f32(s, P(h1), P(self.value_fc2_w), self._value_b2(), P(v), B, live))
@@ -581,12 +613,11 @@ class InferenceNet(nn.Module):
             b2 = self.__dict__["_b2"] = float(self.value_fc2_b.detach().float().cpu().item())
         return b2
 
-    def _heads(self, x, B, g16, plan, return_logits):
+    def _heads(self, x, B, g16, plan, return_logits, conv_done=False):
         """Policy / value heads and FC layers (reference net.py:96-109) on the tower's output ``x`` (channels-last rows in memory
         order; ``g16``: group-of-16 row order, padded to whole groups)."""
-        if (self.opt.fused_heads and hasattr(self, "head_w32") and x.is_cuda and x.dtype == torch.float16 and x.shape[1] == 256
-                and x.is_contiguous(memory_format=torch.channels_last)):
-            logits, v = self._heads_fused(x, B, g16, plan)
+        if self._fused_heads_ok(x):
+            logits, v = self._heads_fused(x, B, g16, plan, conv_done)
             if return_logits:
                 return logits, v
             return torch.exp(F.log_softmax(logits.float(), dim=1)).contiguous(), v

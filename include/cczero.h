@@ -447,6 +447,18 @@ int ccz_fc_f16(void *stream, const void *a_dev, int32_t lda, const void *w_dev, 
 int ccz_value_out_f32(void *stream, const void *h_dev, const void *w2_dev, float b2, float *v_dev, int32_t m,
                       const int32_t *live_rows_dev);
 
+/* The LAST residual layer of the tower with both head convolutions in its epilogue (group-of-16 rows only: flags must hold
+ * CCZ_CONV_G16; bit 0 ReLU, CCZ_CONV_G16_EDGE_TILES as ccz_conv3x3_c256_f16): computes relu(conv3x3(x) + bias + residual) like
+ * ccz_conv3x3_c256_f16 but does NOT store it -- each tile multiplies its finished rows with w32 while they are still in LDS and
+ * writes pol / val exactly as ccz_heads_conv1x1_f16 would from the stored tensor (same operands, same MFMA chain: the same bits).
+ * Saves one write and one read of the activation tensor (2 x 189 MB at 4096 boards). live_rows_dev == NULL: n_pixels rows at
+ * x_dev / residual_dev, boards 0 .. n_pixels / 90 - 1 at pol_dev / val_dev (part / n_parts ignored). live_rows_dev != NULL: the
+ * pointers of the WHOLE batch and part / n_parts as ccz_conv3x3_c256_f16_live; boards past *live_rows_dev are not written. */
+int ccz_conv3x3_c256_heads_f16(void *stream, const void *x_dev, const void *w_dev, const void *bias_f32_dev,
+                               const void *residual_dev, const void *head_w32_dev, const void *head_bias32_f32_dev,
+                               void *pol_dev, void *val_dev, int64_t n_pixels, int32_t flags,
+                               const int32_t *live_rows_dev, int32_t part, int32_t n_parts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -385,6 +385,59 @@ def test_group_of_16_kernel_live_rows(live, n_parts, edge):
     assert torch.isnan(yg[groups:].float()).all()
 
 
+@pytest.mark.parametrize("edge", [0, 1])
+@pytest.mark.parametrize("boards,live,n_parts", [(16, None, 1), (80, None, 1), (96, None, 1), (160, 0, 1), (160, 1, 1), (160, 17, 1),
+                                                 (160, 100, 3), (160, 160, 4), (160, 150, 2)])
+def test_last_layer_with_heads_in_its_epilogue_is_bit_identical(boards, live, n_parts, edge):
+    """ccz_conv3x3_c256_heads_f16 (the tower's last layer, its output never stored, both head convolutions on the rows while they
+    are in LDS) writes the same bits as the layer followed by ccz_heads_conv1x1_f16 -- whole batch, an odd number of groups (the
+    edge kernel's duplicated half), and the planned boundary cut into parts; boards past the live count are left alone."""
+    from chinesechesszero_amd import _lib
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(1700 + boards + (live or 0))
+    cl = torch.channels_last
+    L = _lib.lib()
+    s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    x = torch.relu(torch.randn(boards, 256, 10, 9, generator=g) * 0.7).to(dev).half().contiguous(memory_format=cl)
+    r = torch.relu(torch.randn(boards, 256, 10, 9, generator=g) * 0.7).to(dev).half().contiguous(memory_format=cl)
+    w = (torch.randn(256, 256, 3, 3, generator=g) * 0.03).to(dev).half().contiguous(memory_format=cl)
+    b = (torch.randn(256, generator=g) * 0.2).to(dev)
+    w32 = torch.zeros(32, 256, dtype=torch.float16)
+    w32[:24] = (torch.randn(24, 256, generator=g) * 0.08).half()
+    b32 = torch.zeros(32)
+    b32[:24] = torch.randn(24, generator=g) * 0.2
+    w32, b32 = w32.to(dev), b32.to(dev)
+    xg, rg = _to_g16(x), _to_g16(r)
+    wp = _pack_w(w.permute(0, 2, 3, 1), 256)
+    fl = 1 | _lib.CONV_G16 | (_lib.CONV_G16_EDGE_TILES if edge else 0)
+    full = torch.empty_like(xg)
+    _lib.check(L.ccz_conv3x3_c256_f16(s, P(xg), P(wp), P(b), P(rg), P(full), boards * 90, fl))
+    n_live = None if live is None else torch.tensor([live], dtype=torch.int32, device=dev)
+    pol0 = torch.full((boards, 1536), 3.0, dtype=torch.float16, device=dev)
+    val0 = torch.full((boards, 640), 3.0, dtype=torch.float16, device=dev)
+    _lib.check(L.ccz_heads_conv1x1_f16(s, P(full), P(w32), P(b32), P(pol0), P(val0), boards, _lib.CONV_G16, None if live is None else P(n_live)))
+    pol1, val1 = torch.full_like(pol0, 3.0), torch.full_like(val0, 3.0)
+    keep = rg.clone()
+    if live is None:
+        _lib.check(L.ccz_conv3x3_c256_heads_f16(s, P(xg), P(wp), P(b), P(rg), P(w32), P(b32), P(pol1), P(val1), boards * 90, fl, None, 0, 1))
+    else:
+        cap = -(-(boards // 16) // n_parts) * 1440
+        for part in range(n_parts):
+            _lib.check(L.ccz_conv3x3_c256_heads_f16(s, P(xg), P(wp), P(b), P(rg), P(w32), P(b32), P(pol1), P(val1), cap, fl | (2 if part & 1 else 0),
+                                                    P(n_live), part, n_parts))
+    torch.cuda.synchronize()
+    assert torch.equal(rg, keep)   # the residual operand is read, nothing is stored over it
+    assert torch.equal(pol1, pol0) and torch.equal(val1, val0)
+    n = boards if live is None else live
+    assert float((pol1[n:] - 3.0).abs().max() if n < boards else 0) == 0 and float((pol1[:n, 1530:] - 3.0).abs().max() if n else 0) == 0
+    if n:
+        assert float((pol1[:n, :1530] - 3.0).abs().max()) > 0
+    # argument checks: board-major rows, no residual
+    assert L.ccz_conv3x3_c256_heads_f16(s, P(xg), P(wp), P(b), P(rg), P(w32), P(b32), P(pol1), P(val1), boards * 90, 1, None, 0, 1) != 0
+    assert L.ccz_conv3x3_c256_heads_f16(s, P(xg), P(wp), P(b), None, P(w32), P(b32), P(pol1), P(val1), boards * 90, fl, None, 0, 1) != 0
+
+
 @pytest.mark.parametrize("B,g16", [(1, False), (7, False), (200, False), (48, True), (1040, True)])
 def test_head_kernels_against_float32(B, g16):
     """csrc/cczero_heads.h against plain float32 torch: both 1x1 head convolutions + bias + ReLU with the board-order output

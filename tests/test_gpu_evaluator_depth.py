@@ -235,15 +235,21 @@ def test_both_row_layouts_give_the_same_evaluation(monkeypatch):
     rows = torch.randperm(4096, device=dev)[:3000].to(torch.int32).contiguous()
     n_rows = torch.tensor([3000], dtype=torch.int32, device=dev)
     out = {}
-    for layout in ("g16", "nhwc", "g16+edge"):   # "+edge": the opt-in middle + edge-pair launches of the group-of-16 kernel (round 4)
-        pvn._infer.set_options(layout=layout.split("+")[0], edge_tiles=layout.endswith("+edge"))
+    # "+edge": the middle + edge-pair launches of the group-of-16 kernel; "-sep": the head convolutions as a pass of their own over
+    # the stored output of the tower instead of in the last layer's epilogue (round 4; the default fuses them on group-of-16 rows)
+    variants = ("g16", "nhwc", "g16+edge", "g16-sep", "g16+edge-sep")
+    for layout in variants:
+        pvn._infer.set_options(layout=layout[:3] if layout.startswith("g16") else layout, edge_tiles="+edge" in layout, fused_last="-sep" not in layout)
         full = pvn.evaluate_leaves_logits(x)
         part = pvn._infer.tower_activations(x[:3990].contiguous())
         plan = pvn.evaluate_leaves_logits(x, plan=(rows, n_rows))
-        out[layout] = [t.clone() for t in (*full, part, plan[0][:3000], plan[1][:3000])]
-    for a, b, c in zip(out["g16"], out["nhwc"], out["g16+edge"]):
-        assert torch.equal(a, b) and torch.equal(a, c)
-    pvn._infer.set_options(layout="auto", edge_tiles="auto")
+        odd = pvn.evaluate_leaves_logits(x[:3976].contiguous())     # 249 groups (the edge kernel pairs them: one left over), the last one 8 boards
+        out[layout] = [t.clone() for t in (*full, part, plan[0][:3000], plan[1][:3000], *odd)]
+    for v in variants[1:]:
+        for a, b in zip(out["g16"], out[v]):
+            assert torch.equal(a, b), v
+    pvn._infer.set_options(layout="auto", edge_tiles="auto", fused_last=True)
+    assert torch.equal(out["g16"][5], out["g16"][0][:3976]) and torch.equal(out["g16"][6], out["g16"][1][:3976])
     # the planned rows are the rows of the full batch
     assert torch.equal(out["g16"][3], out["g16"][0][rows.long()]) and torch.equal(out["g16"][4], out["g16"][1][rows.long()])
     assert out["g16"][2].shape == (3990, 256, 10, 9)
