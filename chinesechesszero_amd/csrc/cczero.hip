@@ -896,7 +896,7 @@ int ccz_pack_live_planes_rows_f16(void *stream, const void *leaf_dev, void *x64_
     if (!leaf_dev || !x64_dev || n_boards < 0 || !rows_dev || !n_rows_dev) return fail(-1, "ccz_pack_live_planes_rows_f16: bad arguments");
     if ((uintptr_t)x64_dev & 15) return fail(-1, "ccz_pack_live_planes_rows_f16: output must be 16-byte aligned");
     if (n_boards == 0) return 0;
-    hipLaunchKernelGGL(k_pack_live_planes, dim3((unsigned)n_boards), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)leaf_dev, (half8_t *)x64_dev, (int)n_boards,
+    hipLaunchKernelGGL(k_pack_live_planes, dim3((unsigned)n_boards), dim3(kPackThreads), 0, (hipStream_t)stream, (const _Float16 *)leaf_dev, (half8_t *)x64_dev, (int)n_boards,
                        (const int *)rows_dev, (const int *)n_rows_dev, 2); // planned form: only the chunks that can be non-zero are written
     HIP_TRY(hipGetLastError());
     return 0;
@@ -917,7 +917,7 @@ int ccz_pack_live_planes_g16_f16(void *stream, const void *leaf_dev, void *x64_d
     if (!leaf_dev || !x64_dev || n_boards < 0 || (!rows_dev) != (!n_rows_dev)) return fail(-1, "ccz_pack_live_planes_g16_f16: bad arguments");
     if ((uintptr_t)x64_dev & 15) return fail(-1, "ccz_pack_live_planes_g16_f16: output must be 16-byte aligned");
     if (n_boards == 0) return 0;
-    hipLaunchKernelGGL(k_pack_live_planes, dim3((unsigned)n_boards), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)leaf_dev, (half8_t *)x64_dev, (int)n_boards,
+    hipLaunchKernelGGL(k_pack_live_planes, dim3((unsigned)n_boards), dim3(kPackThreads), 0, (hipStream_t)stream, (const _Float16 *)leaf_dev, (half8_t *)x64_dev, (int)n_boards,
                        (const int *)rows_dev, (const int *)n_rows_dev, rows_dev ? 3 : 1); // planned form: as ccz_pack_live_planes_rows_f16
     HIP_TRY(hipGetLastError());
     return 0;
@@ -928,7 +928,7 @@ int ccz_pack_live_planes_f16(void *stream, const void *leaf_dev, void *x64_dev, 
     if (!leaf_dev || !x64_dev || n_boards < 0) return fail(-1, "ccz_pack_live_planes_f16: bad arguments");
     if ((uintptr_t)x64_dev & 15) return fail(-1, "ccz_pack_live_planes_f16: output must be 16-byte aligned");
     if (n_boards == 0) return 0;
-    hipLaunchKernelGGL(k_pack_live_planes, dim3((unsigned)n_boards), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)leaf_dev, (half8_t *)x64_dev, (int)n_boards,
+    hipLaunchKernelGGL(k_pack_live_planes, dim3((unsigned)n_boards), dim3(kPackThreads), 0, (hipStream_t)stream, (const _Float16 *)leaf_dev, (half8_t *)x64_dev, (int)n_boards,
                        (const int *)nullptr, (const int *)nullptr, 0);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -981,6 +981,21 @@ int ccz_fc_f16(void *stream, const void *a_dev, int32_t lda, const void *w_dev, 
     if ((k & 63) || (lda & 7) || lda < k || (n & 1) || (ldc & 1) || ldc < n) return fail(-1, "ccz_fc_f16: k must be a multiple of 64, lda a multiple of 8 and >= k, n and ldc even, ldc >= n");
     if ((((uintptr_t)a_dev) | ((uintptr_t)w_dev) | ((uintptr_t)bias_f32_dev)) & 15 || ((uintptr_t)c_dev & 3)) return fail(-1, "ccz_fc_f16: a, w, bias must be 16-byte aligned, c 4-byte aligned");
     if (m == 0) return 0;
+    // many rows x thousands of columns (the policy layer of a big batch): the 256 x 144 tile kernel; relu bit 1 forces the 128 x 128 kernel,
+    // bit 2 the wide one (tests, A/B) -- same bits from either
+    // (policy shape on one box, us: M 4096: 31.8 against 53.4; 3712: 31.6 / 41.5; 2048: 27.1 / 29.3; 1024: 25.9 / 22.1 -- profiles/r04_fc_microbench_wide.json)
+    if (!(relu & 2) && ((relu & 4) || (m >= 2048 && n >= 1024))) {
+        const int wtiles = ((n + kFwBN - 1) / kFwBN) * ((m + kFwBM - 1) / kFwBM);
+        const dim3 wgrid((unsigned)(8 * ((wtiles + 7) / 8)));
+        if (relu & 1)
+            hipLaunchKernelGGL(k_fc_wide_f16<true>, wgrid, dim3(512), 0, (hipStream_t)stream, (const _Float16 *)a_dev, (int)lda, (const _Float16 *)w_dev,
+                               (const float *)bias_f32_dev, (_Float16 *)c_dev, (int)ldc, (int)m, (int)n, (int)k, (const int *)live_rows_dev, (int)(relu >> 8));
+        else
+            hipLaunchKernelGGL(k_fc_wide_f16<false>, wgrid, dim3(512), 0, (hipStream_t)stream, (const _Float16 *)a_dev, (int)lda, (const _Float16 *)w_dev,
+                               (const float *)bias_f32_dev, (_Float16 *)c_dev, (int)ldc, (int)m, (int)n, (int)k, (const int *)live_rows_dev, (int)(relu >> 8));
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     const int tiles = ((n + kFcBN - 1) / kFcBN) * ((m + kFcBM - 1) / kFcBM);
     const dim3 grid((unsigned)(8 * ((tiles + 7) / 8))); // XCD x = block mod 8 takes the x-th contiguous eighth of the tile order: see k_fc_f16
     if (relu & 1)

@@ -252,16 +252,207 @@ __global__ __launch_bounds__(256) void k_fc_f16(const _Float16 *__restrict__ A, 
     }
 }
 
+// ---- the same GEMM for the policy layer's shape (many rows, N in the thousands): 256 x 144 tiles, 128-byte rows --------------------------
+// k_fc_f16 moves 64 bytes of a row (32 k) per step: HALF a cache line -- the other half is wanted a step later, when the 25-50 KB
+// that passed through the CU's 32 KB L1 in between have long evicted it, so every line crosses the L2 -> L1 path (64 B/clk/CU)
+// twice: 2 x 16 KB x 2 workgroups per CU and step = 1,024 cycles against 256 of MFMA (measured 0.42 us per step; the first form of this kernel,
+// 256 x 144 tiles with 64-byte rows, 0.62 us per step at 2 x 25.6 KB). Here a stage is 64 k: whole 128-byte lines, each fetched
+// once -- 51.2 KB per stage = 800 cycles of L1 fill under 1,152 cycles of MFMA. The tile is 256 (m) x 144 (n) per workgroup of EIGHT
+// waves: 2086 columns are 15 tiles of 144 (against 17 of 128, the last one 38 wide), a batch of 4096 rows 16 x 15 = 240 tiles --
+// ONE round on 256 CUs whatever the live count. Wave (wm, wn) owns rows 64 wm .. + 63 and n-fragments 0..4 (wn = 0) or 5..8
+// (wn = 1): 9 or 8 fragment reads per 20 or 16 MFMAs, and the two waves of a SIMD (wave ids s and s + 4) hold 36 MFMAs per k-step
+// between them. Three stages of 51.2 KB (153.6 KB of LDS); the K loop is software-pipelined across the stage barrier (below).
+// Operands, fragment composition and the chain over k = 0, 32, 64, ... are k_fc_f16's: every output element is the same bits from
+// either kernel (tests/test_gpu_conv.py::test_both_fc_kernels_give_the_same_bits).
+constexpr int kFwBM = 256, kFwBN = 144, kFwStages = 3;
+constexpr int kFwATile = kFwBM * 128, kFwWTile = kFwBN * 128; // bytes per stage: 256 + 144 rows of 128 B (64 k)
+constexpr int kFwStage = kFwATile + kFwWTile;                 // [A tile | W tile] 51,200 B
+constexpr int kFwERow = 176;                                  // epilogue transpose: bytes per row of a wave's 64 x 80 fp16 block (160 + pad)
+static_assert(8 * 64 * kFwERow <= kFwStages * kFwStage, "the epilogue blocks live in the operand ring");
+static_assert(kFwStages * kFwStage <= 160 * 1024, "LDS");
+
+template <bool RELU, int NF, int I0>
+__device__ __forceinline__ void fw_wave(unsigned char *lds, const _Float16 *const (&src)[7], int wv, int wm, int lane,
+                                        const float *__restrict__ bias, int bias_last, _Float16 *__restrict__ C, int ldc, int Ml, int N, int K,
+                                        int m0, int n0, [[maybe_unused]] int dbg)
+{
+    const int r = lane & 15, q4 = lane >> 4;
+    // DMA of one stage: 50 wave-instructions of 64 sixteen-byte granules = 8 whole rows each: q = 0..31 the A tile, q = 32..49 the W
+    // tile; wave wv issues q = wv + 8 t (t = 0..5) and waves 0, 1 also q = 48 + wv: 7 or 6 loads per lane and stage. dma(st, t): the
+    // wave's t-th instruction of stage st (t = 0..3: A rows, 4..6: W rows)
+    auto dma = [&](int st_, int t) {
+        unsigned char *st = lds + (st_ % kFwStages) * kFwStage;
+        if (FC_DBG(4) && st_ > 2) return;
+        if (t < 4) cv_glds16(src[t] + st_ * 64, st + (wv + 8 * t) * 1024);
+        else if (t < 6 || wv < 2) cv_glds16(src[t] + st_ * 64, st + kFwATile + (wv + 8 * (t - 4)) * 1024);
+    };
+    auto wait_vm = [&](int whole, bool plus_a) { // this lane's loads that may stay outstanding: `whole` stages (0, 1) [+ the A part (4) of one more]
+        if (wv < 2) {
+            if (whole && plus_a) cv_wait_vm<11>();
+            else if (whole) cv_wait_vm<7>();
+            else cv_wait_vm<0>();
+        } else {
+            if (whole && plus_a) cv_wait_vm<10>();
+            else if (whole) cv_wait_vm<6>();
+            else cv_wait_vm<0>();
+        }
+    };
+    // acc[i][j] = n-fragment I0 + i (rows n0 + (I0 + i) * 16 + 4 q4 .. + 3) x m-fragment j (column m0 + wm * 64 + j * 16 + r), starting at the bias
+    cv_f32x4 acc[NF][4];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        int at = n0 + (I0 + i) * 16 + 4 * q4;
+        at = at < bias_last ? at : bias_last;
+        const float4 bv = *(const float4 *)(bias + at);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[i][j][0] = bv.x; acc[i][j][1] = bv.y; acc[i][j][2] = bv.z; acc[i][j][3] = bv.w; }
+    }
+    // fragment of row 16 f + r, k-sub ks (32 k): 16-byte chunk 4 ks + q4 of the row, stored at position chunk ^ ((row >> 1) & 7)
+    // (conflict-free for the four 16-lane groups of ds_read_b128: 16 different (row parity, position) pairs each)
+    const int rsw = (r >> 1) & 7;
+    const int foff0 = r * 128 + ((q4 ^ rsw) << 4), foff1 = r * 128 + (((4 + q4) ^ rsw) << 4);
+    auto frags = [&](int st_, int ks, cv_half8 (&fa)[NF], cv_half8 (&fb)[4]) {
+        const unsigned char *base = lds + (st_ % kFwStages) * kFwStage + (ks ? foff1 : foff0);
+        if (FC_DBG(2) && st_ > 0) return;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) fb[jj] = *(const cv_half8 *)(base + (wm * 4 + jj) * 2048);
+#pragma unroll
+        for (int i = 0; i < NF; ++i) fa[i] = *(const cv_half8 *)(base + kFwATile + (I0 + i) * 2048);
+    };
+    // One k-sub: NF groups of four MFMAs; in front of group g the wave issues ONE DMA instruction (t0 + g, while g < nd). An LDS-DMA
+    // costs its wave 60-185 cycles of issue (MI355X_MICROARCH.md, "LDS-DMA piece issue cost"): the first form issued a stage's 6-7 in
+    // a burst behind the barrier -- both waves of a SIMD at once, the matrix pipe idle meanwhile: 1.1 us per stage against 0.5 us of
+    // MFMA. Spread out, one wave's DMA issue hides under the other wave's MFMAs.
+    auto mfmas = [&](const cv_half8 (&fa)[NF], const cv_half8 (&fb)[4], int st_, int t0, int nd) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            if (i < nd) dma(st_, t0 + i);
+            if (FC_DBG(1)) { acc[i][0] += (cv_f32x4){(float)fa[i][0], (float)fb[i & 3][0], 0.0f, 0.0f}; continue; }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[jj], acc[i][jj], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // The K loop, software-pipelined across the stage barrier: the fragments of the NEXT k-sub are requested before the MFMAs of the
+    // current one, so LDS latency and the barrier's skew hide under 20 / 16 MFMAs. Once every wave holds the second half of stage s
+    // in registers (the barrier in the middle of iteration s) the slot of stage s is free: the A part of stage s + 3 is issued into it
+    // during the second k-sub of iteration s, its W part during the first k-sub of iteration s + 1.
+    const int ns = K / 64;
+#pragma unroll
+    for (int t = 0; t < 7; ++t) dma(0, t);
+    if (ns > 1) {
+#pragma unroll
+        for (int t = 0; t < 7; ++t) dma(1, t);
+    }
+    if (ns > 2) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dma(2, t);
+    }
+    cv_half8 fa0[NF], fb0[4], fa1[NF], fb1[4];
+    wait_vm(ns > 1, ns > 2);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    frags(0, 0, fa0, fb0);
+    for (int s_ = 0; s_ < ns; ++s_) {
+        frags(s_, 1, fa1, fb1);
+        mfmas(fa0, fb0, s_ + 2, 4, s_ + 2 < ns ? 3 : 0);
+        if (s_ + 1 < ns) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's fragments of stage s are in registers
+            wait_vm(s_ + 2 < ns, false);                        // stage s + 1 has landed (all of s + 2 may be outstanding)
+            __builtin_amdgcn_sched_barrier(0);
+            if (!FC_DBG(16)) __builtin_amdgcn_s_barrier(); // stage s + 1 is complete (every wave's part of it); every wave is done reading stage s
+            __builtin_amdgcn_sched_barrier(0);
+            frags(s_ + 1, 0, fa0, fb0);
+        }
+        mfmas(fa1, fb1, s_ + 3, 0, s_ + 3 < ns ? 4 : 0);
+    }
+    if (FC_DBG(8)) { if (acc[0][0][0] == 12345.678f) C[0] = (_Float16)1; return; }
+    // epilogue: the wave's 64 (m) x 16 NF (n) block through its own LDS block, whole row segments out (k_fc_f16's epilogue)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier(); // every wave is done reading the operand stages
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned char *tb = lds + wv * (64 * kFwERow);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+            if (RELU) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f); }
+            cv_half4 o;
+            o[0] = (_Float16)v0; o[1] = (_Float16)v1; o[2] = (_Float16)v2; o[3] = (_Float16)v3;
+            *(cv_half4 *)(tb + (j * 16 + r) * kFwERow + (i * 16 + 4 * q4) * 2) = o;
+        }
+    wave_sync(); // (the block is this wave's own)
+    constexpr int NW = NF * 8; // dwords per row of the block
+#pragma unroll 4
+    for (int it = 0; it < NW; ++it) {
+        const int L = it * 64 + lane, row = L / NW, dw = L - row * NW;
+        const int m = m0 + wm * 64 + row, n = n0 + I0 * 16 + 2 * dw;
+        const uint32_t v = *(const uint32_t *)(tb + row * kFwERow + dw * 4);
+        if (m < Ml && n + 1 < N) *(uint32_t *)(C + (long)m * ldc + n) = v;
+    }
+}
+
+// Arguments as k_fc_f16 (W rows padded to a multiple of 128 with zeros: rows past that are never read -- clamped). grid 8 * ceil(tiles / 8).
+template <bool RELU>
+__global__ __launch_bounds__(512) void k_fc_wide_f16(const _Float16 *__restrict__ A, int lda, const _Float16 *__restrict__ W,
+                                                       const float *__restrict__ bias, _Float16 *__restrict__ C, int ldc, int M, int N,
+                                                       int K, const int *__restrict__ live, [[maybe_unused]] int dbg)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kFwStages * kFwStage];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wv & 3, wn = wv >> 2;
+    int Ml = M;
+    if (live) { const int l = *live; Ml = l < Ml ? l : Ml; }
+    // XCD-aware tile order (see k_fc_f16): blocks of TWO m tiles, inside a block n-major; XCD x takes the x-th contiguous eighth:
+    // at 16 x 15 tiles an XCD works on two m tiles (1.5 MB of A rows) and walks W once
+    const int mt = (Ml + kFwBM - 1) / kFwBM, nt = (N + kFwBN - 1) / kFwBN, tiles = mt * nt;
+    int n0, m0;
+    {
+        const int b = blockIdx.x, x = b & 7, per = tiles >> 3, rem = tiles & 7;
+        if ((b >> 3) >= per + (x < rem ? 1 : 0)) return;
+        const int t = x * per + (x < rem ? x : rem) + (b >> 3);
+        const int full = (mt >> 1) * 2 * nt;
+        const int blk = t < full ? t / (2 * nt) : (mt >> 1);
+        const int r_ = t < full ? t % (2 * nt) : t - full;
+        const int cnt = t < full ? 2 : 1;
+        n0 = (r_ / cnt) * kFwBN;
+        m0 = (2 * blk + r_ % cnt) * kFwBM;
+    }
+    // per-lane DMA sources (fw_wave::issue): granule p = lane of instruction q holds row 8 q + (p >> 3), position p & 7 = source chunk
+    // (p & 7) ^ ((row >> 1) & 7); (row >> 1) & 7 = (4 (q & 1) + (lane >> 4)) & 7 and q & 1 = wv & 1 for all of a wave's instructions
+    const int wrows = ((N + 127) >> 7) << 7;
+    const int c = (lane & 7) ^ ((4 * (wv & 1) + (lane >> 4)) & 7), lr = lane >> 3;
+    const _Float16 *src[7];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int m = m0 + (wv + 8 * t) * 8 + lr;
+        m = m < Ml ? m : Ml - 1; // (rows past the live ones are computed from a clamped row and not stored)
+        src[t] = A + (long)m * lda + c * 8;
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        int n = n0 + (wv + 8 * t) * 8 + lr; // (t = 2: waves 0, 1 only)
+        n = n < wrows ? n : wrows - 1;
+        src[4 + t] = W + (long)n * K + c * 8;
+    }
+    if (wn == 0) fw_wave<RELU, 5, 0>(lds, src, wv, wm, lane, bias, wrows - 4, C, ldc, Ml, N, K, m0, n0, dbg);
+    else fw_wave<RELU, 4, 5>(lds, src, wv, wm, lane, bias, wrows - 4, C, ldc, Ml, N, K, m0, n0, dbg);
+}
+
 // v[m] = tanh(fp16(b2 + sum_k h[m, k] w2[k])), h [M][256] fp16 (the first value FC's ReLU output), one wave per board
 // (reference net.py:107-109: value_fc2 -> tanh; the fp16 rounding in front of tanh is the fp16 linear layer's output rounding).
 __global__ __launch_bounds__(256) void k_value_out(const _Float16 *__restrict__ h, const _Float16 *__restrict__ w2, float b2,
                                                     float *__restrict__ v, int M, const int *__restrict__ live)
 {
     const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    // (the row is requested together with the live count: rows up to M exist whether they are live or not)
+    const cv_half4 x = *(const cv_half4 *)(h + (long)m * 256 + lane * 4), w = *(const cv_half4 *)(w2 + lane * 4);
     int Ml = M;
     if (live) { const int l = *live; Ml = l < Ml ? l : Ml; }
     if (m >= Ml) return;
-    const cv_half4 x = *(const cv_half4 *)(h + (long)m * 256 + lane * 4), w = *(const cv_half4 *)(w2 + lane * 4);
     float s = (float)x[0] * (float)w[0];
     s += (float)x[1] * (float)w[1];
     s += (float)x[2] * (float)w[2];

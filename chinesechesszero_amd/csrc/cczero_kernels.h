@@ -577,15 +577,18 @@ __global__ __launch_bounds__(64) void k_softmax_gather(Dev D, const T *logits, c
 {
     const int b = blockIdx.x, lane = threadIdx.x;
     __shared__ __attribute__((aligned(16))) float row[kNMoves + 2];
-    if (D.leaf_status[b] != CCZ_LEAF_EXPAND) return;
-    int src = b;
+    // everything the wave needs to know about its board is requested at once (one memory round trip instead of a chain of four:
+    // status -> state -> row -> logits); a board that turns out to have nothing to do leaves after it
+    const int status = D.leaf_status[b];
+    int cst = 0, src = b;
     if (PLANNED) {
-        if (D.cstate[b] != 0) return; // hit: prior128 / vleaf were filled by the probe
+        cst = D.cstate[b];
         src = D.row_of[b];
     }
     const int k = D.leaf_k[b];
     const uint16_t *ids = D.leaf_ids + (size_t)b * kMaxLegal;
     const int id0 = ids[lane], id1 = ids[64 + lane];
+    if (status != CCZ_LEAF_EXPAND || cst != 0) return; // (cst != 0: a hit -- prior128 / vleaf were filled by the probe)
     const T *srcrow = logits + (size_t)src * kNMoves;
     float mx = -__builtin_huge_valf();
     float sum = 0.0f;
@@ -594,12 +597,23 @@ __global__ __launch_bounds__(64) void k_softmax_gather(Dev D, const T *logits, c
         // loop trips of the element-wise form. A lane adds its exponentials in ascending element order (2j, 2j + 1, 2j + 128, ...).
         static_assert(kNMoves % 2 == 0, "dword rows");
         const uint32_t *src32 = (const uint32_t *)srcrow;
-        for (int j = lane; j < kNMoves / 2; j += 64) {
-            const uint32_t w = src32[j];
-            const float x0 = (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu));
-            const float x1 = (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16));
-            *(float2 *)(row + 2 * j) = make_float2(x0, x1);
-            mx = fmaxf(mx, fmaxf(x0, x1));
+        constexpr int kIt = (kNMoves / 2 + 63) / 64;
+        uint32_t wreg[kIt]; // the whole row in flight before the first use
+#pragma unroll
+        for (int i = 0; i < kIt; ++i) {
+            const int j = lane + 64 * i;
+            wreg[i] = j < kNMoves / 2 ? src32[j] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < kIt; ++i) {
+            const int j = lane + 64 * i;
+            if (j < kNMoves / 2) {
+                const uint32_t w = wreg[i];
+                const float x0 = (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu));
+                const float x1 = (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16));
+                *(float2 *)(row + 2 * j) = make_float2(x0, x1);
+                mx = fmaxf(mx, fmaxf(x0, x1));
+            }
         }
         mx = wave_max_f32(mx);
         for (int j = lane; j < kNMoves / 2; j += 64) {
@@ -664,11 +678,12 @@ __device__ __forceinline__ uint32_t cache_slot(uint64_t key, uint32_t mask) { re
 __global__ __launch_bounds__(64) void k_cache_probe(Dev D)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
-    if (D.leaf_status[b] != CCZ_LEAF_EXPAND) {
+    const int status = D.leaf_status[b];
+    const uint64_t key = D.leaf_key[b]; // (requested together with the status: one round trip less in front of the table access)
+    if (status != CCZ_LEAF_EXPAND) {
         if (lane == 0) D.cstate[b] = 2;
         return;
     }
-    const uint64_t key = D.leaf_key[b];
     const uint32_t slot = cache_slot(key, D.cache_mask);
     const CacheEntry *e = D.cache + slot;
     const uint64_t ekey = e->key;

@@ -36,34 +36,51 @@ __global__ __launch_bounds__(256) void k_bias_act(half8_t *__restrict__ y, const
 // 16-byte chunks that can be non-zero are written (48 of 128 bytes per row).
 // The two plane runs of a board (630 + 1260 fp16, both 4-byte aligned) are staged in LDS with dword loads and transposed from
 // there (round 3 gathered them with 2-byte global loads: 7.7 M of them per step, 22 us).
-__global__ __launch_bounds__(256) void k_pack_live_planes(const _Float16 *__restrict__ leaf, half8_t *__restrict__ out, int n_boards,
-                                                          const int *__restrict__ rows, const int *__restrict__ n_rows, int flags)
+// One WAVE per board (round 4, second form; the first ran 256 threads and a workgroup barrier per board: with four waves a board
+// the chip holds half the batch at a time and every workgroup sits through two memory round trips and a barrier, 14 us at 3,660
+// boards): 15 dword loads per lane in flight, the LDS hand-over needs no barrier inside a wave, and all boards are resident at once.
+constexpr int kPackThreads = 64;
+__global__ __launch_bounds__(kPackThreads) void k_pack_live_planes(const _Float16 *__restrict__ leaf, half8_t *__restrict__ out, int n_boards,
+                                                                   const int *__restrict__ rows, const int *__restrict__ n_rows, int flags)
 {
     __shared__ uint32_t s_w[946]; // planes 49..55 (315 dwords) then 105..118 (630 dwords); + 1 pad
     const long b = blockIdx.x;
+    const int lane = threadIdx.x;
     long sb = b;
     if (rows) {
-        if (b >= *n_rows) return;
-        sb = rows[b];
+        const int nr = *n_rows;
+        sb = rows[b]; // (requested with the count, not after it: rows[] has an entry for every board of the batch)
+        if (b >= nr) return;
     }
     const uint32_t *src = (const uint32_t *)(leaf + sb * (119 * 90)); // a board is 21,420 B: dword-aligned
-    for (int i = threadIdx.x; i < 945; i += 256) s_w[i] = src[i < 315 ? (49 * 45) + i : (105 * 45) + (i - 315)];
-    __syncthreads();
+    constexpr int kIt = (945 + kPackThreads - 1) / kPackThreads;
+    uint32_t v[kIt];
+#pragma unroll
+    for (int j = 0; j < kIt; ++j) {
+        const int i = lane + j * kPackThreads;
+        v[j] = i < 945 ? src[i < 315 ? (49 * 45) + i : (105 * 45) + (i - 315)] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < kIt; ++j) {
+        const int i = lane + j * kPackThreads;
+        if (i < 945) s_w[i] = v[j];
+    }
+    __syncthreads(); // (one wave: no s_barrier is emitted, only the wait for the LDS writes)
     const _Float16 *s_h = (const _Float16 *)s_w; // live channel ch (0..20), pixel p at s_h[ch * 90 + p]
     const bool g16 = flags & 1;
     const int ncp = (flags & 2) ? 3 : 8;
-    for (int i = threadIdx.x; i < 90 * ncp; i += 256) {
+    for (int i = lane; i < 90 * ncp; i += kPackThreads) {
         const int p = i / ncp, cpos = i - p * ncp;
-        half8_t v = (half8_t)(_Float16)0;
+        half8_t o = (half8_t)(_Float16)0;
         if (cpos < 3) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int ch = cpos * 8 + e;
-                if (ch < 21) v[e] = s_h[ch * 90 + p];
+                if (ch < 21) o[e] = s_h[ch * 90 + p];
             }
         }
         const long row = g16 ? ((b >> 4) * 90 + p) * 16 + (b & 15) : b * 90 + p;
-        out[row * 8 + cpos] = v;
+        out[row * 8 + cpos] = o;
     }
 }
 

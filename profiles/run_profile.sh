@@ -44,8 +44,8 @@ for P in $PASSES; do
     cfetch) pmc cfetch FETCH_SIZE "$CV" $SHORT ;;
     cwrite) pmc cwrite WRITE_SIZE "$CV" $SHORT ;;
     csq) pmc csq "$SQ" "$CV" $SHORT ;;
-    hfetch) pmc hfetch FETCH_SIZE "--kernel-include-regex k_head_conv1x1|k_fc_f16|k_pack_live_planes|k_softmax_gather|k_cache_plan|k_cache_probe|k_value_out" $SHORT ;;
-    hwrite) pmc hwrite WRITE_SIZE "--kernel-include-regex k_head_conv1x1|k_fc_f16|k_pack_live_planes|k_softmax_gather|k_cache_plan|k_cache_probe|k_value_out" $SHORT ;;
+    hfetch) pmc hfetch FETCH_SIZE "--kernel-include-regex k_head_conv1x1|k_fc_f16|k_fc_wide_f16|k_pack_live_planes|k_softmax_gather|k_cache_plan|k_cache_probe|k_value_out" $SHORT ;;
+    hwrite) pmc hwrite WRITE_SIZE "--kernel-include-regex k_head_conv1x1|k_fc_f16|k_fc_wide_f16|k_pack_live_planes|k_softmax_gather|k_cache_plan|k_cache_probe|k_value_out" $SHORT ;;
     cmfma) pmc cmfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "$CV" $SHORT ;;
     *) echo "unknown pass $P" >> "$LOG"; exit 2 ;;
   esac

@@ -51,11 +51,32 @@ def main():
         plan_calls = sum(int(float(r.get("Calls", 0) or 0)) for r in rows if "k_cache_plan" in r.get("Name", ""))
         if plan_calls:
             tail = {}
-            for k in ("k_cache_probe", "k_cache_plan", "k_pack_live_planes", "k_head_conv1x1", "k_fc_f16", "k_value_out", "k_softmax_gather"):
+            for k in ("k_cache_probe", "k_cache_plan", "k_pack_live_planes", "k_head_conv1x1", "k_fc_f16", "k_fc_wide_f16", "k_value_out", "k_softmax_gather"):
                 tot = sum(float(r.get("TotalDurationNs", 0) or 0) for r in rows if k in r.get("Name", ""))
                 calls = sum(int(float(r.get("Calls", 0) or 0)) for r in rows if k in r.get("Name", ""))
                 if calls:
                     tail[k] = {"us_per_step": tot / plan_calls * 1e-3, "launches_per_step": calls / plan_calls, "avg_us": tot / calls * 1e-3}
+            # the head convolutions ride in the LAST tower layer's epilogue (k_conv3x3_g16_heads / _edge_heads): what they cost is the
+            # difference between that launch and the same launch of an ordinary residual layer (k_conv3x3_g16<true> / _edge<true>)
+            def fam(pred):
+                hit = [r for r in rows if pred(r.get("Name", ""))]
+                calls = sum(int(float(r.get("Calls", 0) or 0)) for r in hit)
+                tot = sum(float(r.get("TotalDurationNs", 0) or 0) for r in hit)
+                return calls, tot
+            extra, detail = 0.0, {}
+            for name, heads, plain in (("middle", lambda n: "k_conv3x3_g16_heads" in n, lambda n: "k_conv3x3_g16<true>" in n or "k_conv3x3_g16ILb1" in n),
+                                       ("edge", lambda n: "k_conv3x3_g16_edge_heads" in n, lambda n: "k_conv3x3_g16_edge<true>" in n or "k_conv3x3_g16_edgeILb1" in n)):
+                hc, ht = fam(heads)
+                pc, pt = fam(plain)
+                if hc and pc:
+                    d = (ht / hc - pt / pc) * hc / plan_calls * 1e-3
+                    extra += d
+                    detail[name] = {"avg_us_with_heads": ht / hc * 1e-3, "avg_us_plain_residual_layer": pt / pc * 1e-3, "launches_per_step": hc / plan_calls, "extra_us_per_step": d}
+            if detail:
+                tail["heads_in_last_tower_layer"] = {"us_per_step": extra, "launches_per_step": sum(v["launches_per_step"] for v in detail.values()),
+                                                     "avg_us": extra / max(1e-9, sum(v["launches_per_step"] for v in detail.values())), "detail": detail,
+                                                     "what": "launch time of the last layer with the heads in its epilogue minus an ordinary residual layer's, x launches per step "
+                                                             "(the chains run concurrently: an upper bound on what the step pays)"}
             # whatever torch still launches inside a step (elementwise / GEMM kernels of the library): everything that is not ours
             other = [(r.get("Name", ""), float(r.get("TotalDurationNs", 0) or 0), int(float(r.get("Calls", 0) or 0))) for r in rows
                      if "ccz" not in r.get("Name", "")]   # (ccz:: in demangled names, 3ccz in mangled ones)
@@ -92,7 +113,7 @@ def main():
             if r.get("Counter_Name") != counter:
                 continue
             name = r.get("Kernel_Name", "")
-            for k in ("k_step", "k_softmax_gather", "k_select", "k_expand_backup", "k_finish_move", "k_conv3x3", "k_head_conv1x1", "k_fc_f16",
+            for k in ("k_step", "k_softmax_gather", "k_select", "k_expand_backup", "k_finish_move", "k_conv3x3", "k_head_conv1x1", "k_fc_f16", "k_fc_wide_f16",
                       "k_pack_live_planes", "k_cache_plan", "k_cache_probe", "k_value_out"):
                 if k in name:
                     acc[k][0] += float(r.get("Counter_Value", 0) or 0)

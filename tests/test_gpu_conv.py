@@ -438,6 +438,43 @@ def test_last_layer_with_heads_in_its_epilogue_is_bit_identical(boards, live, n_
     assert L.ccz_conv3x3_c256_heads_f16(s, P(xg), P(wp), P(b), None, P(w32), P(b32), P(pol1), P(val1), boards * 90, fl, None, 0, 1) != 0
 
 
+@pytest.mark.parametrize("M,live", [(1040, None), (4096, None), (4096, 3660), (4096, 257), (4000, 1), (300, None)])
+def test_both_fc_kernels_give_the_same_bits(M, live):
+    """ccz_fc_f16 picks the 256 x 144 tile kernel (k_fc_wide_f16) for many rows x thousands of columns and the 128 x 128 one
+    (k_fc_f16) otherwise; relu bits 1 / 2 force one. Same operands, same chain of MFMAs per output element: the same bits, with and
+    without a device-side live count, ReLU or not, for the policy shape and (forced) the value shape; rows past the live count and
+    the columns past n are left alone."""
+    from chinesechesszero_amd import _lib
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(M + (live or 0))
+    s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    n_live = None if live is None else torch.tensor([live], dtype=torch.int32, device=dev)
+    for K, N, relu in ((1536, 2086, 0), (640, 256, 1), (128, 1150, 1)):
+        Np = -(-N // 128) * 128
+        a = torch.relu(torch.randn(M, K, generator=g)).half().to(dev)
+        w = torch.zeros(Np, K, dtype=torch.float16)
+        w[:N] = (torch.randn(N, K, generator=g) * 0.03).half()
+        w = w.to(dev)
+        b = torch.zeros(Np)
+        b[:N] = torch.randn(N, generator=g) * 0.3
+        b = b.to(dev)
+        ldc = N + 10
+        outs = []
+        for force in (2, 4, 0):
+            c = torch.full((M, ldc), 9.0, dtype=torch.float16, device=dev)
+            _lib.check(L.ccz_fc_f16(s, P(a), K, P(w), P(b), P(c), ldc, M, N, K, relu | force, None if live is None else P(n_live)))
+            outs.append(c)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (K, N)
+        n = M if live is None else live
+        assert float((outs[1][:, N:] - 9.0).abs().max()) == 0 and (n == M or float((outs[1][n:] - 9.0).abs().max()) == 0)
+        ref = a[:n].float() @ w[:N].float().t() + b[:N]
+        ref = torch.relu(ref) if relu else ref
+        assert torch.allclose(outs[1][:n, :N].float(), ref, atol=1.5e-2, rtol=4e-3), (K, N)
+
+
 @pytest.mark.parametrize("B,g16", [(1, False), (7, False), (200, False), (48, True), (1040, True)])
 def test_head_kernels_against_float32(B, g16):
     """csrc/cczero_heads.h against plain float32 torch: both 1x1 head convolutions + bias + ReLU with the board-order output
