@@ -23,7 +23,7 @@ PLANES = 10710
 REC_BYTES, REC_HDR, REC_IDS, REC_PI = 880, 96, 112, 368  # compact ply record (include/cczero.h CCZ_REC_*)
 HEAD_POL_STRIDE, HEAD_VAL_STRIDE = 1536, 640  # CCZ_HEAD_*_STRIDE: fp16 elements per board of the head kernels' outputs
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 CONV_RELU, CONV_DESCENDING, CONV_FORCE_SMALL, CONV_FORCE_TILE, CONV_G16, CONV_G16_EDGE_TILES = 1, 2, 16, 32, 64, 128  # CCZ_CONV_* flag bits
 RULE_PERPETUAL_CHECK = 1
 RULE_PAWN_MOVE_RESETS_CLOCK = 2

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define CCZ_ABI_VERSION 5
+#define CCZ_ABI_VERSION 6
 #define CCZ_NSQ 90
 #define CCZ_SQ_STRIDE 96            /* mailbox row stride in bytes (90 squares + 6 pad)         */
 #define CCZ_NMOVES 2086             /* action space, reference tools.py:172-272                 */

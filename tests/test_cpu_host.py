@@ -22,14 +22,14 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(L, name), name
         assert name in _lib.PROTOTYPES, f"{name} not bound in _lib.PROTOTYPES"
     assert set(_lib.PROTOTYPES) == declared
-    assert L.ccz_abi_version() == 5 == _lib.ABI_VERSION   # ABI 5: ccz_leaf_priors, CCZ_FLAG_CACHE_VERIFY + two ccz_stats counters
+    assert L.ccz_abi_version() == 6 == _lib.ABI_VERSION   # ABI 5: ccz_leaf_priors, CCZ_FLAG_CACHE_VERIFY + two ccz_stats counters; ABI 6: ccz_conv3x3_c256_heads_f16, ccz_fc_f16 relu bits 1 / 2
     assert ctypes.sizeof(_lib.Config) == 96 and ctypes.sizeof(_lib.Stats) == 152      # ABI 3: four evaluation-cache counters appended; ABI 5: two verify counters
     # ABI 2 fields sit where include/cczero.h puts them (pointer at 64, plane map at 72, rule flags at 80); ABI 3 gives the word
     # behind rule_flags a meaning (eval_cache_log2) without moving anything
     assert _lib.Config.move_rank_host.offset == 64 and _lib.Config.plane_of_type.offset == 72 and _lib.Config.rule_flags.offset == 80 and _lib.Config.type_rank.offset == 88
     assert _lib.Config.eval_cache_log2.offset == 84 and _lib.Stats.cache_probes.offset == 104
     m = re.search(r"#define CCZ_ABI_VERSION (\d+)", hdr)
-    assert m and int(m.group(1)) == 5
+    assert m and int(m.group(1)) == 6
 
 
 def test_tables_from_library_match_reference_golden(golden):
