@@ -178,6 +178,41 @@ def test_fused_tower_board_ranges_on_several_streams_equal_one_chain(monkeypatch
         assert torch.isfinite(outs[0].float()).all() and outs[0].abs().max().item() > 0
 
 
+def test_heads_in_the_last_layer_under_every_launch_structure():
+    """The whole evaluator (2 blocks x 256, group-of-16 rows) with the head convolutions inside the last tower layer: logits and
+    values are the same bits whatever the launch structure -- 1 / 3 chains, 1 / 2 sequential board groups, edge-pair tiles or not,
+    a batch that pads its last group, whole batch or planned rows -- and the same as with the heads as a pass of their own."""
+    from chinesechesszero_amd.net import InferenceNet, Net
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(8)
+    net = Net(256, 2).to(dev).eval()
+    inf = InferenceNet(net).to(dev).eval()
+    g = torch.Generator().manual_seed(5)
+    for B in (1300, 1296):   # 82 groups, the last one holds 4 boards; 81 whole groups (odd: the edge kernel pairs one with itself)
+        leaf = torch.zeros(B, 17, 7, 10, 9, dtype=torch.float16)
+        leaf.view(B, 119, 90)[:, 49:56] = (torch.rand(B, 7, 90, generator=g) < 0.1).half()
+        leaf.view(B, 119, 90)[:, 105:119] = (torch.rand(B, 14, 90, generator=g) < 0.1).half()
+        leaf = leaf.to(dev)
+        rows = torch.randperm(B, generator=g)[:B - 200].to(torch.int32).to(dev).contiguous()
+        n_rows = torch.tensor([B - 200], dtype=torch.int32, device=dev)
+        want = None
+        for fused_last in (False, True):
+            for chains, groups, edge in ((1, 1, False), (3, 1, True), (2, 2, False), (3, 2, True)):
+                inf.set_options(layout="g16", fused_last=fused_last, chains=chains, groups=groups, edge_tiles=edge)
+                inf._chain_streams = None
+                full = inf(leaf, return_logits=True)
+                plan = inf(leaf, return_logits=True, plan=(rows, n_rows))
+                got = [full[0].clone(), full[1].clone(), plan[0][:B - 200].clone(), plan[1][:B - 200].clone()]
+                torch.cuda.synchronize()
+                if want is None:
+                    want = got
+                    assert torch.isfinite(got[0].float()).all() and float(got[0].float().abs().max()) > 0
+                    assert torch.equal(got[2], got[0][rows.long()]) and torch.equal(got[3], got[1][rows.long()])
+                else:
+                    for a, b in zip(want, got):
+                        assert torch.equal(a, b), (B, fused_last, chains, groups, edge)
+
+
 def test_conv_kernel_full_size_board_permutation_and_sample():
     """BASELINE size (4096 boards = 1440 tiles): (1) boards are independent, so permuting the boards of the input permutes
     the output bit for bit, whatever tile / wave / lane a board lands in; (2) a sample of boards against float32."""
