@@ -785,6 +785,12 @@ static int conv3x3_launch(const char *who, void *stream, const void *x_dev, cons
         // taps save) but -0.7...-0.9 % with three: the evaluator sets the flag from 4096 boards on and runs three chains then. (The
         // edge launch on a helper stream beside the middle one put two event packets per layer on the main stream -- a 12.7 us gap
         // between layers; hipExtAnyOrderLaunch is ignored on gfx9: the trace shows the kernels one after the other.)
+        if (cin == 64) { // the stem: the packed live planes sit in channels 0..20 of 64: ONE 32-channel chunk (k_conv3x3_g16_stem), one launch
+            hipLaunchKernelGGL(k_conv3x3_g16_stem, dim3((unsigned)(groups * 5)), dim3(512), 0, s, (const _Float16 *)x_dev, (const _Float16 *)w_dev,
+                               (const float *)bias_f32_dev, (_Float16 *)y_dev, (int)n_pixels, (int)fl, cin, (const int *)live_rows_dev, (int)row0);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
         if (!(relu & CCZ_CONV_G16_EDGE_TILES) || groups < 2) {
             CCZ_G16(k_conv3x3_g16, groups * 5, s, fl);
             HIP_TRY(hipGetLastError());

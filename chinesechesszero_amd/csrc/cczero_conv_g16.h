@@ -244,7 +244,10 @@ __device__ __forceinline__ void g5_heads_phase(const unsigned char *lds, int w, 
     }
 }
 
-template <bool RES, bool HEADS>
+// ONE: only the first 32 input channels of a row can be non-zero (the stem: 21 live planes in rows of 64 channels) -- the tile runs the
+// nine half-steps of chunk 0 and stops; the second chunk would add products of zeros to accumulators that are never -0 (they start at
+// a bias): the same bits (the board-major and small-batch kernels run both chunks; tests compare them bit for bit).
+template <bool RES, bool HEADS, bool ONE = false>
 __device__ __forceinline__ void g5_tile(const _Float16 *__restrict__ X, const _Float16 *__restrict__ W,
                                         const float *__restrict__ bias, const _Float16 *R,
                                         _Float16 *Y, int M, int relu, int cin, const int *live_rows, int row0, const G5Heads &ha)
@@ -316,7 +319,7 @@ __device__ __forceinline__ void g5_tile(const _Float16 *__restrict__ X, const _F
     c.lane16 = lane * 16;
     c.wave_dst4 = (w < 4 ? 4 : 3) * 8192 + w * 1024;
     c.cin = cin;
-    c.cmask = (cin >> 5) - 1;
+    c.cmask = ONE ? 0 : (cin >> 5) - 1;
     {
         // slab row sr (0..575) = tensor row p0 - 144 + sr: rank 2k - 1 + sr / 144 of the group; 64-byte rows, position pos of
         // row sr holds source chunk pos ^ f(sr), f = (-(sr >> 2)) & 3 (conflict-free for the 16 rows x 4 chunks one ds_read_b128
@@ -377,12 +380,17 @@ __device__ __forceinline__ void g5_tile(const _Float16 *__restrict__ X, const _F
 #pragma unroll
     for (int n = 0; n < 9; ++n) b[n] = *(const cv_half8 *)(lds + c.vb[0] + (9 + n - 9) * 1024); // the rank above this wave's: dy = -1
 #endif
-    for (int chunk = 0; chunk <= c.cmask; chunk += 2) {
 #define G5_S(j) g5_step<j>(c, acc, chunk + (j) / 9, ring_rd, ring_wr, a0, a1, b)
+    if constexpr (ONE) {
+        const int chunk = 0; // (the prefetches past half-step 8 wrap around to chunk 0: valid memory, never read)
         G5_S(0); G5_S(1); G5_S(2); G5_S(3); G5_S(4); G5_S(5); G5_S(6); G5_S(7); G5_S(8);
-        G5_S(9); G5_S(10); G5_S(11); G5_S(12); G5_S(13); G5_S(14); G5_S(15); G5_S(16); G5_S(17);
-#undef G5_S
+    } else {
+        for (int chunk = 0; chunk <= c.cmask; chunk += 2) {
+            G5_S(0); G5_S(1); G5_S(2); G5_S(3); G5_S(4); G5_S(5); G5_S(6); G5_S(7); G5_S(8);
+            G5_S(9); G5_S(10); G5_S(11); G5_S(12); G5_S(13); G5_S(14); G5_S(15); G5_S(16); G5_S(17);
+        }
     }
+#undef G5_S
     cv_wait_vm<0>(); // the wrapped-around DMA loads must land before the LDS is reused / released
 
     // ---- epilogue: every wave writes its 64 channels x 144 rows into the [row][channel] image in LDS; then wave w owns
@@ -446,6 +454,14 @@ __global__ __launch_bounds__(512) void k_conv3x3_g16(const _Float16 *__restrict_
                                                          _Float16 *Y, int M, int relu, int cin, const int *live_rows, int row0)
 {
     g5_tile<RES, false>(X, W, bias, R, Y, M, relu, cin, live_rows, row0, G5Heads{});
+}
+
+// The stem (ccz_conv3x3_stem_f16 with CCZ_CONV_G16): rows of 64 channels of which only 0..31 can be non-zero, one chunk (g5_tile ONE)
+__global__ __launch_bounds__(512) void k_conv3x3_g16_stem(const _Float16 *__restrict__ X, const _Float16 *__restrict__ W,
+                                                            const float *__restrict__ bias, _Float16 *Y, int M, int relu, int cin,
+                                                            const int *live_rows, int row0)
+{
+    g5_tile<false, false, true>(X, W, bias, nullptr, Y, M, relu, cin, live_rows, row0, G5Heads{});
 }
 
 // The last layer of the tower with the heads in its epilogue (always with residual; Y may be null: nothing is stored to it).

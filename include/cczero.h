@@ -392,7 +392,9 @@ int ccz_pack_conv_weights_g16_f16(void *stream, const void *w_dev, void *wp_dev,
 /* The stem convolution (reference net.py:59-66,86-88: conv3x3(119 -> 256) -> BN(folded) -> ReLU) with the same kernel,
  * one 64-channel chunk: x64 [n_pixels, 64] fp16 holds the 21 planes that can be non-zero on the search path in
  * channels 0..20 (ccz_pack_live_planes_f16) and zeros above; w: [256, 3, 3, 64] fp16 (input channels in the same
- * order, zero-padded); bias float32 [256]; y [n_pixels, 256] fp16. Exact: zero inputs contribute nothing. */
+ * order, zero-padded); bias float32 [256]; y [n_pixels, 256] fp16. Exact: zero inputs contribute nothing. With
+ * CCZ_CONV_G16 the kernel takes that at its word: channels 32..63 of x64 are NOT READ (one 32-channel chunk instead of two:
+ * they hold zeros by this contract, and adding products of zeros changes no bit of an accumulator that starts at a bias). */
 int ccz_conv3x3_stem_f16(void *stream, const void *x64_dev, const void *w_dev, const void *bias_f32_dev,
                          void *y_dev, int64_t n_pixels, int32_t relu);
 /* Evaluator input [n_boards, 17, 7, 10, 9] fp16 (the layout ccz_select_leaves / ccz_step write, net.py:174-177)
