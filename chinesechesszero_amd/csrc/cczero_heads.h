@@ -286,14 +286,14 @@ __device__ __forceinline__ void fw_wave(unsigned char *lds, const _Float16 *cons
         if (t < 4) cv_glds16(src[t] + st_ * 64, st + (wv + 8 * t) * 1024);
         else if (t < 6 || wv < 2) cv_glds16(src[t] + st_ * 64, st + kFwATile + (wv + 8 * (t - 4)) * 1024);
     };
-    auto wait_vm = [&](int whole, bool plus_a) { // this lane's loads that may stay outstanding: `whole` stages (0, 1) [+ the A part (4) of one more]
+    auto wait_vm2 = [&](int whole) { // `whole` (0..2) stages of this lane's loads may stay outstanding
         if (wv < 2) {
-            if (whole && plus_a) cv_wait_vm<11>();
-            else if (whole) cv_wait_vm<7>();
+            if (whole >= 2) cv_wait_vm<14>();
+            else if (whole == 1) cv_wait_vm<7>();
             else cv_wait_vm<0>();
         } else {
-            if (whole && plus_a) cv_wait_vm<10>();
-            else if (whole) cv_wait_vm<6>();
+            if (whole >= 2) cv_wait_vm<12>();
+            else if (whole == 1) cv_wait_vm<6>();
             else cv_wait_vm<0>();
         }
     };
@@ -311,6 +311,9 @@ __device__ __forceinline__ void fw_wave(unsigned char *lds, const _Float16 *cons
     // (conflict-free for the four 16-lane groups of ds_read_b128: 16 different (row parity, position) pairs each)
     const int rsw = (r >> 1) & 7;
     const int foff0 = r * 128 + ((q4 ^ rsw) << 4), foff1 = r * 128 + (((4 + q4) ^ rsw) << 4);
+    // (The compiler puts `s_waitcnt lgkmcnt(0)` in front of the first MFMA of a fragment set that was loaded in the previous loop
+    // iteration, which also waits for the reads issued just before it. Issuing the reads as inline asm with hand-counted lgkmcnt(NF + 4)
+    // removed that wait and measured the same, 32.5 against 31.7 us: the exposed LDS latency is not what the loop waits for.)
     auto frags = [&](int st_, int ks, cv_half8 (&fa)[NF], cv_half8 (&fb)[4]) {
         const unsigned char *base = lds + (st_ % kFwStages) * kFwStage + (ks ? foff1 : foff0);
         if (FC_DBG(2) && st_ > 0) return;
@@ -319,14 +322,15 @@ __device__ __forceinline__ void fw_wave(unsigned char *lds, const _Float16 *cons
 #pragma unroll
         for (int i = 0; i < NF; ++i) fa[i] = *(const cv_half8 *)(base + kFwATile + (I0 + i) * 2048);
     };
-    // One k-sub: NF groups of four MFMAs; in front of group g the wave issues ONE DMA instruction (t0 + g, while g < nd). An LDS-DMA
+    // One k-sub: NF groups of four MFMAs; in front of group g the wave issues DMA instructions t0 + 2 g and t0 + 2 g + 1 (while < nd). An LDS-DMA
     // costs its wave 60-185 cycles of issue (MI355X_MICROARCH.md, "LDS-DMA piece issue cost"): the first form issued a stage's 6-7 in
     // a burst behind the barrier -- both waves of a SIMD at once, the matrix pipe idle meanwhile: 1.1 us per stage against 0.5 us of
     // MFMA. Spread out, one wave's DMA issue hides under the other wave's MFMAs.
     auto mfmas = [&](const cv_half8 (&fa)[NF], const cv_half8 (&fb)[4], int st_, int t0, int nd) {
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
-            if (i < nd) dma(st_, t0 + i);
+            if (2 * i < nd) dma(st_, t0 + 2 * i);
+            if (2 * i + 1 < nd) dma(st_, t0 + 2 * i + 1);
             if (FC_DBG(1)) { acc[i][0] += (cv_f32x4){(float)fa[i][0], (float)fb[i & 3][0], 0.0f, 0.0f}; continue; }
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[jj], acc[i][jj], 0, 0, 0);
@@ -335,9 +339,16 @@ __device__ __forceinline__ void fw_wave(unsigned char *lds, const _Float16 *cons
     };
     // The K loop, software-pipelined across the stage barrier: the fragments of the NEXT k-sub are requested before the MFMAs of the
     // current one, so LDS latency and the barrier's skew hide under 20 / 16 MFMAs. Once every wave holds the second half of stage s
-    // in registers (the barrier in the middle of iteration s) the slot of stage s is free: the A part of stage s + 3 is issued into it
-    // during the second k-sub of iteration s, its W part during the first k-sub of iteration s + 1.
+    // in registers (the barrier in the middle of iteration s) the slot of stage s is free: stage s + 3 is issued into it during the
+    // second k-sub of iteration s (one or two DMA instructions in front of each group of MFMAs), a good 1.5 iterations before its
+    // first fragment is read (spreading the stage over two half-iterations, the W part one iteration ahead only, measured the same: 31.8 against 31.7 us).
     const int ns = K / 64;
+#ifdef CCZ_FC_DIAG // dbg bit 5: wave 0 leaves cycle stamps in the pad columns of its first row (ldc >= N + 16): entry, first fragments, loop end, tile end
+#define FW_STAMP(k) if ((dbg & 32) && wv == 0 && lane == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); uint32_t *o_ = (uint32_t *)(C + (long)m0 * ldc + N + 4 * (k) + (n0 / kFwBN) * 0); if (n0 == 0) { o_[0] = (uint32_t)t_; o_[1] = (uint32_t)(t_ >> 32); } }
+#else
+#define FW_STAMP(k)
+#endif
+    FW_STAMP(0)
 #pragma unroll
     for (int t = 0; t < 7; ++t) dma(0, t);
     if (ns > 1) {
@@ -346,27 +357,29 @@ __device__ __forceinline__ void fw_wave(unsigned char *lds, const _Float16 *cons
     }
     if (ns > 2) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) dma(2, t);
+        for (int t = 0; t < 7; ++t) dma(2, t);
     }
     cv_half8 fa0[NF], fb0[4], fa1[NF], fb1[4];
-    wait_vm(ns > 1, ns > 2);
+    wait_vm2(ns - 1 < 2 ? ns - 1 : 2);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     frags(0, 0, fa0, fb0);
+    FW_STAMP(1)
     for (int s_ = 0; s_ < ns; ++s_) {
         frags(s_, 1, fa1, fb1);
-        mfmas(fa0, fb0, s_ + 2, 4, s_ + 2 < ns ? 3 : 0);
+        mfmas(fa0, fb0, 0, 0, 0);
         if (s_ + 1 < ns) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's fragments of stage s are in registers
-            wait_vm(s_ + 2 < ns, false);                        // stage s + 1 has landed (all of s + 2 may be outstanding)
+            wait_vm2(s_ + 2 < ns ? 1 : 0);                       // stage s + 1 has landed (all of s + 2 may be outstanding)
             __builtin_amdgcn_sched_barrier(0);
             if (!FC_DBG(16)) __builtin_amdgcn_s_barrier(); // stage s + 1 is complete (every wave's part of it); every wave is done reading stage s
             __builtin_amdgcn_sched_barrier(0);
             frags(s_ + 1, 0, fa0, fb0);
         }
-        mfmas(fa1, fb1, s_ + 3, 0, s_ + 3 < ns ? 4 : 0);
+        mfmas(fa1, fb1, s_ + 3, 0, s_ + 3 < ns ? 7 : 0);
     }
+    FW_STAMP(2)
     if (FC_DBG(8)) { if (acc[0][0][0] == 12345.678f) C[0] = (_Float16)1; return; }
     // epilogue: the wave's 64 (m) x 16 NF (n) block through its own LDS block, whole row segments out (k_fc_f16's epilogue)
     __builtin_amdgcn_sched_barrier(0);
@@ -392,6 +405,8 @@ __device__ __forceinline__ void fw_wave(unsigned char *lds, const _Float16 *cons
         const uint32_t v = *(const uint32_t *)(tb + row * kFwERow + dw * 4);
         if (m < Ml && n + 1 < N) *(uint32_t *)(C + (long)m * ldc + n) = v;
     }
+    FW_STAMP(3)
+#undef FW_STAMP
 }
 
 // Arguments as k_fc_f16 (W rows padded to a multiple of 128 with zeros: rows past that are never read -- clamped). grid 8 * ceil(tiles / 8).
