@@ -276,7 +276,7 @@ __device__ __forceinline__ void g5_tile(const _Float16 *__restrict__ X, const _F
         if ((int)blockIdx.x >= tiles) return;
         const long off = (long)first * 1440 * kCvC;
         X += (long)first * 1440 * cin;
-        Y += off;
+        if (!HEADS) Y += off; // (HEADS: there is no output tensor)
         if (RES) R += off;
         first_board = (long)first * 16;
     }

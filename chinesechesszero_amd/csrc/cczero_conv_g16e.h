@@ -128,7 +128,7 @@ __device__ __forceinline__ void g5e_tile(const _Float16 *__restrict__ X, const _
         groups = live;
         const long off = (long)first * 1440 * kCvC;
         X += (long)first * 1440 * cin;
-        Y += off;
+        if (!HEADS) Y += off; // (HEADS: there is no output tensor)
         if (RES) R += off;
         first_board = (long)first * 16;
     }
