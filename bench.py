@@ -61,7 +61,15 @@ def parse():
     ap.add_argument("--align-evaluator", choices=["net", "stub"], default="net", help="evaluator of the untimed alignment steps: the real "
                     "net (default) or the stub (fast; for rocprofv3 PMC passes, where every kernel of an untimed step costs profiler time)")
     ap.add_argument("--gather-plies", type=int, default=32768, help="N>1: ply capacity of the fused all-gather slot (880 B per ply record; "
-                    "one move of 4096 boards finishes ~14 k plies = ~28 k dense rows)")
+                    "one move of 4096 boards finishes ~14 k plies = ~28 k dense rows; what does not fit waits for the next exchange)")
+    ap.add_argument("--exchange", choices=["async", "sync"], default="async", help="N>1: async (default) = replay.AsyncRecordExchange: no rank "
+                    "ever waits for another one (records join a backlog at the move boundary, the all-gather is issued from a side stream once "
+                    "every rank has announced it, its result is picked up by a later step); sync = round 3/4's blocking all-gather at every move boundary")
+    ap.add_argument("--boards-rank0", default="", help="N>1 with --train-every: boards of rank 0, the rank that shares its GPU with the trainer "
+                    "(a number, or 'auto' = calibrated before the window so that rank 0's step with the trainer takes as long as a plain "
+                    "rank's step); the other ranks keep --boards. Global board ids are a prefix sum: every board keeps its RNG stream")
+    ap.add_argument("--slow-rank", default="", help="testing: RANK:SECONDS -- that rank sleeps this long at every move boundary of the timed window "
+                    "(with --exchange async its peers' step rates must not change)")
     ap.add_argument("--replay-rows", type=int, default=0, help="N>1 / trainer: rows of the dense replay ring every rank keeps in HBM "
                     "(0 = 40,000 x world size: more than one move's rows of all ranks)")
     ap.add_argument("--eval-cache-log2", type=int, default=24, help="evaluation cache of 2^n positions (528 B each; 0 = none): leaves whose "
@@ -200,6 +208,77 @@ def preroll(e, plies: int, stagger: bool):
     e.check_healthy()
 
 
+def committed_profile(path: str, head: str, workload: dict):
+    """The committed rocprofv3 summary (profiles/pmc_summary.json) IF it describes what this process runs: taken with the same
+    code (``head`` == build.code_hash() of the run that was profiled) on the same workload. Returns ``(summary | None, why not |
+    None, the profile's head)``. A profile of other code or another workload is refused, never replayed silently."""
+    if not os.path.exists(path):
+        return None, "no committed profile", None
+    try:
+        with open(path) as f:
+            pm = json.load(f)
+    except Exception as exc:
+        return None, f"unreadable profile: {exc}", None
+    ph = pm.get("head")
+    wl = dict({"boards_per_gpu": 4096, "sims_per_move": 400, "evaluator": "net", "max_plies": 200}, **pm.get("workload", {}))
+    full = {"blocks": 40, "channels": 256, "preroll_plies": 200, "align": True}   # what run_profile.sh's passes run with
+    want = dict(full, **wl)
+    diff = {k: (workload.get(k), v) for k, v in want.items() if workload.get(k) != v}
+    if diff:
+        return None, f"the committed profile is of another workload ({', '.join(f'{k}: {a} vs {b}' for k, (a, b) in sorted(diff.items()))})", ph
+    if not ph:
+        return None, "the committed profile does not say which code it was taken with (no head)", ph
+    if ph != head:
+        return None, f"the committed profile was taken with other code (head {ph}, this run {head})", ph
+    return pm, None, ph
+
+
+def calibrate_rank0_boards(pvn, train_once, boards: int, train_every: int, dev, lo: int = 64, quantum: int = 64, periods: int = 3):
+    """How many boards can rank 0 carry NEXT TO the trainer at the pace of a plain rank? Measured, not modelled: the evaluator (98 %
+    of a step) on synthetic leaf rows, alone on ``boards`` rows (= a plain rank's step), then on b rows with one trainer update
+    per ``train_every`` evaluations on the side stream (the window's cadence); b is moved by secant steps until its time meets the
+    plain one. Untimed set-up, ~3 s. The trainer may be heavier than a whole plain step: then b ends at ``lo`` and says so."""
+    g = torch.Generator(device=dev).manual_seed(3)
+    leaf_all = (torch.rand((boards, 17, 7, 10, 9), device=dev, generator=g) > 0.9).half()
+    q = lambda b: int(max(lo, min(boards, quantum * round(b / quantum))))
+
+    def probe(b, with_trainer):
+        leaf = leaf_all[:b]
+        for _ in range(2):
+            pvn.evaluate_leaves_logits(leaf)         # (first call at a new batch shape: workspace, path decision)
+        if with_trainer:
+            train_once()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(periods * train_every):
+            pvn.evaluate_leaves_logits(leaf)
+            if with_trainer and (i + 1) % train_every == 0:
+                train_once()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / (periods * train_every)
+
+    t_plain = probe(boards, False)
+    t_with = probe(boards, True)
+    pts = [(boards, t_with)]
+    b = q(boards * max(0.0, 2.0 * t_plain - t_with) / t_plain)   # first guess: the trainer adds a constant per step
+    for _ in range(4):
+        if any(p[0] == b for p in pts):
+            break
+        pts.append((b, probe(b, True)))
+        (b1, t1), (b2, t2) = pts[-2], pts[-1]
+        if abs(t2 - t_plain) <= 0.02 * t_plain or b1 == b2 or t1 == t2:
+            break
+        b = q(b2 + (t_plain - t2) * (b1 - b2) / (t1 - t2))
+    ok = [p for p in pts if p[1] <= 1.03 * t_plain]
+    best = max(ok)[0] if ok else min(pts)[0]
+    del leaf_all
+    torch.cuda.empty_cache()
+    return {"boards_rank0": best, "plain_rank_ms": 1e3 * t_plain, "trainer_bound": not ok,
+            "probes_with_trainer": [{"boards": p[0], "ms": 1e3 * p[1]} for p in pts],
+            "what": f"evaluator on synthetic rows, {periods * train_every} evaluations per probe, one trainer update (batch 2048) per {train_every} on "
+                    "the side stream; plain_rank_ms = the evaluator alone on --boards rows"}
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -230,11 +309,12 @@ def main():
         launch.init_distributed(a.backend, dev, timeout_s=a.dist_timeout)
     xdev = dev if a.backend == "nccl" else torch.device("cpu")  # where the exchange buffers live
 
+    from chinesechesszero_amd.build import code_hash
     from chinesechesszero_amd.net import PolicyValueNet, uniform_evaluator
-    from chinesechesszero_amd.replay import RecordGatherer, ReplayBuffer, exchange_finished_games
+    from chinesechesszero_amd.replay import AsyncRecordExchange, RecordGatherer, ReplayBuffer, exchange_finished_games
     from chinesechesszero_amd.selfplay import BatchedSelfPlay
 
-    B, n = a.boards, a.playout
+    n = a.playout
     if a.evaluator == "net":
         torch.manual_seed(0)
         pvn = PolicyValueNet(device=dev, num_channels=a.channels, resblocks_num=a.blocks)
@@ -242,11 +322,6 @@ def main():
         evaluator = pvn.evaluate_leaves_logits  # compact boundary: logits in, the engine gathers the legal priors
     else:
         evaluator = uniform_evaluator
-    sp = BatchedSelfPlay(evaluator, B, n_playout=n, seed=0, board_id_base=rank * B, device=local_rank,
-                         sampling="device", max_plies=a.max_plies, value_f16=a.value_f16,
-                         eval_cache_log2=a.eval_cache_log2 if a.evaluator == "net" else 0, cache_verify=a.cache_verify)
-    e = sp.engine
-    gather = RecordGatherer(max(a.gather_plies, e.max_plies), xdev) if world > 1 else None
     # the "shared replay buffer" of BASELINE configs[3]: the union of all ranks' rows as a dense ring in HBM; finished games
     # arrive as compact records and are expanded straight into the ring (ccz_expand_records) -- on the ranks that CONSUME it:
     # every rank without a trainer ("all": any rank may sample), rank 0 only when a trainer runs there (configs[4]: the other
@@ -256,7 +331,7 @@ def main():
     rb = ReplayBuffer(a.replay_rows or 40000 * world, dev) if has_ring else None
     bad_records = torch.zeros(1, dtype=torch.int32, device=dev)
 
-    trainer = None
+    trainer = train_once = None
     if a.train_every > 0 and rank == 0:
         from chinesechesszero_amd.trainer import Trainer
         torch.manual_seed(1)
@@ -274,10 +349,69 @@ def main():
         side_done.record(torch.cuda.current_stream(dev))
         train_steps = [0]
 
+        def train_once():
+            """One trainer update (batch 2048 sampled from the replay ring) on the side stream of GPU0, no host wait."""
+            side.wait_stream(torch.cuda.current_stream(dev))  # replay-buffer appends (main stream) happen before the sample
+            with torch.cuda.stream(side):
+                trainer.step(*rb.sample(2048), sync=False)
+                side_done.record(side)
+
+    # ---- boards per rank. All ranks hold --boards boards except, on request, rank 0 (the rank that shares its GPU with the trainer):
+    # with ``auto`` rank 0 measures, before anything else runs, how many rows its evaluator gets through per step NEXT TO the
+    # trainer in the time a plain rank needs for --boards rows, and takes that many boards. Global board ids are a prefix sum.
+    boards_rank0, calibration = None, None
+    if a.boards_rank0:
+        if a.boards_rank0 == "auto":
+            if a.train_every <= 0 or a.evaluator != "net":
+                raise SystemExit("--boards-rank0 auto balances rank 0 against its trainer: it needs --train-every and the real evaluator")
+            t = torch.zeros(1, dtype=torch.int64, device=xdev)
+            if rank == 0:
+                calibration = calibrate_rank0_boards(pvn, train_once, a.boards, a.train_every, dev)
+                t[0] = calibration["boards_rank0"]
+            if world > 1:
+                dist.broadcast(t, src=0)
+            boards_rank0 = int(t.item())
+        else:
+            boards_rank0 = int(a.boards_rank0)
+    counts, bases = launch.board_partition(world, a.boards, boards_rank0)
+    B = counts[rank]
+    mul = 2   # dense rows per ply record (the sample and its mirror image, collect.py:112-131)
+
+    sp = BatchedSelfPlay(evaluator, B, n_playout=n, seed=0, board_id_base=bases[rank], device=local_rank,
+                         sampling="device", max_plies=a.max_plies, value_f16=a.value_f16,
+                         eval_cache_log2=a.eval_cache_log2 if a.evaluator == "net" else 0, cache_verify=a.cache_verify)
+    e = sp.engine
+    mul = 2 if e.mirror else 1
+    gather = ex = None
+    if world > 1:
+        if a.exchange == "sync":
+            gather = RecordGatherer(max(a.gather_plies, e.max_plies), xdev)
+        else:
+            ex = AsyncRecordExchange(max(a.gather_plies, e.max_plies), xdev, timeout_s=a.dist_timeout)
+    slow_rank, slow_s = (int(a.slow_rank.split(":")[0]), float(a.slow_rank.split(":")[1])) if a.slow_rank else (-1, 0.0)
+
     ev = lambda: torch.cuda.Event(enable_timing=True)
-    boundary = {"events": [], "host_s": 0.0, "n": 0, "rows": 0, "rows_local": 0, "games": 0, "gather_s": 0.0, "collectives": 0, "expand_s": 0.0}
+    boundary = {"events": [], "host_s": 0.0, "n": 0, "rows": 0, "rows_local": 0, "games": 0, "gather_s": 0.0, "collectives": 0, "expand_s": 0.0,
+                "exchanges_completed": 0, "slept_s": 0.0}
     timing = [False]
     step_no = [0]
+
+    def consume(done_list):
+        """Completed exchanges (AsyncRecordExchange): the dense rows of ALL ranks' games rebuilt in this rank's replay ring
+        (k_expand_records on the main stream, asynchronous) -- or only counted, on a rank that consumes no rows."""
+        for x in done_list:
+            g1 = time.perf_counter()
+            if rb is not None:
+                if trainer is not None:
+                    torch.cuda.current_stream(dev).wait_event(side_done)  # the trainer's gather reads must not race the append
+                rows = rb.append_records(x.union.to(dev, non_blocking=True), e.record_flags(), e.plane_of_type, bad=bad_records)
+            else:
+                rows = mul * int(x.union.shape[0])
+            if timing[0]:
+                boundary["rows"] += rows
+                boundary["games"] += x.games
+                boundary["exchanges_completed"] += 1
+                boundary["expand_s"] += time.perf_counter() - g1
 
     def per_move():
         """The move boundary: pi + Dirichlet-mixed choice + re-root + push + game end (k_finish_move, k_flip_half), tuple
@@ -294,7 +428,17 @@ def main():
         moves = sp.finish_move()
         st = e.game_status()
         done = int(st["over"].sum())
-        if gather is None:
+        if timed and rank == slow_rank:   # testing: this rank falls behind at its move boundary (--slow-rank)
+            time.sleep(slow_s)
+            boundary["slept_s"] += slow_s
+        if ex is not None:
+            # no rank waits for another one here: the records join this rank's backlog, the rank announces the next exchange, and
+            # whatever exchange has completed meanwhile is expanded into the ring (replay.AsyncRecordExchange)
+            chunks = list(sp.harvest_record_chunks(ex.cap)) if done else []
+            loc = mul * sum(int(c.shape[0]) for c in chunks)
+            rows = 0
+            consume(ex.post(chunks, games=done))
+        elif gather is None:
             chunks = list(e.harvest_chunks(1 << 19)) if done else []
             rows = sum(int(c[2].shape[0]) for c in chunks)
             if trainer is not None and rows:
@@ -327,7 +471,7 @@ def main():
             boundary["n"] += 1
             boundary["rows"] += rows
             boundary["rows_local"] += loc
-            if gather is None:
+            if gather is None and ex is None:
                 boundary["games"] += done
         return moves
 
@@ -354,11 +498,10 @@ def main():
             if a.inject_fault and a.inject_fault == f"{rank}:{len(trace)}":
                 raise RuntimeError(f"injected fault on rank {rank} at timed step {len(trace)} (--inject-fault)")
         step_no[0] += 1
+        if ex is not None:
+            consume(ex.tick())   # a host-side check (nearly always nothing): issue the all-gather once every rank announced it, pick up a finished one
         if trainer is not None and step_no[0] % a.train_every == 0:
-            side.wait_stream(torch.cuda.current_stream(dev))  # replay-buffer appends (main stream) happen before the sample
-            with torch.cuda.stream(side):
-                trainer.step(*rb.sample(2048), sync=False)
-                side_done.record(side)
+            train_once()
             train_steps[0] += 1 if timing[0] else 0  # updates inside the timed window
 
     def run(steps, timed):
@@ -392,6 +535,11 @@ def main():
     if gather is not None:  # one untimed exchange: communicator / channel set-up of the collective is not part of a move
         gather.gather(torch.empty((0, 880), dtype=torch.uint8, device=xdev))
     run(a.warmup, False)
+    if ex is not None:      # drain what the untimed moves left (and set the communicator up): nothing is in flight at the window's barrier
+        for x in ex.flush_iter():
+            consume([x])
+        ex_stats0 = (ex.issued, ex.host_seconds, ex.plies_sent)
+        ex.max_call_s = 0.0
     torch.cuda.synchronize()
     s0 = e.stats()
     tower_probe = None
@@ -404,6 +552,18 @@ def main():
     run(a.steps, True)
     torch.cuda.synchronize()
     dt_local = time.perf_counter() - t0  # this rank's own time (the per-rank rates); the job's time is taken behind the barrier
+    drain_s = 0.0
+    if ex is not None:
+        # INSIDE the job's timed region: every record harvested in the window is delivered to every rank before the clock stops
+        # (the drain waits for the slowest rank, as the barrier behind it would anyway)
+        d0 = time.perf_counter()
+        ex_window = (ex.issued - ex_stats0[0], ex.host_seconds - ex_stats0[1], ex.plies_sent - ex_stats0[2], ex.max_call_s)
+        timing[0] = True
+        for x in ex.flush_iter():
+            consume([x])
+        timing[0] = False
+        torch.cuda.synchronize()
+        drain_s = time.perf_counter() - d0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -413,7 +573,7 @@ def main():
     s1 = e.stats()
     ranks_seen, per_rank, err_any, bad_total = 1, None, int(s1["error_flags"]), int(bad_records.item())
     if world > 1:
-        t = torch.zeros(world + 4, dtype=torch.float64, device=xdev)
+        t = torch.zeros(3 * world + 4, dtype=torch.float64, device=xdev)
         t[0] = dt
         mx = t[:1].clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -422,26 +582,18 @@ def main():
         t[world + 1] = 1.0                                      # ranks that got here
         t[world + 2] = float(bad_total)                         # records of cut games seen by the expansion, all ranks
         t[world + 3] = 1.0 if s1["error_flags"] else 0.0        # ranks whose engine raised a sticky error bit
+        t[world + 4 + rank] = 1e3 * dt_local / a.steps          # this rank's own step time (its K steps, boundary included, no waiting for peers)
+        t[2 * world + 4 + rank] = 1e3 * (ex.max_call_s if ex is not None else 0.0)   # the longest single call into the exchange (host)
         dist.all_reduce(t)
         dt = float(mx.item())
         ranks_seen = int(t[world + 1].item())
         bad_total = int(t[world + 2].item())
         err_any = int(t[world + 3].item())
         per_rank = [float(v) for v in t[1:world + 1].tolist()]
+        rank_step_ms = [float(v) for v in t[world + 4:2 * world + 4].tolist()]
+        rank_xchg_max_call_ms = [float(v) for v in t[2 * world + 4:3 * world + 4].tolist()]
     e.check_healthy()
     st_end = e.game_status()
-    # what a HIP-event pair reports around a trivial kernel on this stream: the floor included in every per-kernel event figure
-    tiny = torch.zeros(64, device=dev)
-    fl = []
-    for _ in range(64):
-        a0, a1 = ev(), ev()
-        a0.record()
-        tiny.add_(1.0)
-        a1.record()
-        fl.append((a0, a1))
-    torch.cuda.synchronize()
-    event_floor_us = float(np.median([x.elapsed_time(y) for x, y in fl])) * 1e3
-
     sims = s1["sims"] - s0["sims"]
     probes = s1["cache_probes"] - s0["cache_probes"]
     planned = sp.planned
@@ -461,10 +613,12 @@ def main():
     dbar = (s1["sum_depth"] - s0["sum_depth"]) / max(1, sims)
     out = None
     if rank == 0:
-        value = world * B * a.steps / dt
+        total_boards = sum(counts)
+        value = total_boards * a.steps / dt
         if pairs:
-            t_net = float(np.mean([p[0].elapsed_time(p[1]) for p in pairs])) * 1e-3
-            t_step = float(np.mean([p[1].elapsed_time(p[2]) for p in pairs])) * 1e-3
+            # MEDIAN of the per-step HIP-event pairs (a stray long interval -- a boundary's neighbour, a trainer burst -- must not move it)
+            t_net = float(np.median([p[0].elapsed_time(p[1]) for p in pairs])) * 1e-3
+            t_step = float(np.median([p[1].elapsed_time(p[2]) for p in pairs])) * 1e-3
         else:
             t_net = t_step = float("nan")
         # algorithmic bytes per simulation, SURVEY 8(d): the fused k_step kernel does all of it. The
@@ -474,47 +628,46 @@ def main():
         a_exp = (4 * kbar + 4) + 18 * kbar + 16 * (dbar + 1)
         a_step = a_sel + a_exp
         a_sim_survey = a_step - 3780 + 21420
-        # roofline.frac / achieved: THIS run's algorithmic bytes over THIS run's k_step duration, measured live with HIP events
-        # around every k_step launch of the timed window on the stream it is launched on, minus the event floor measured the same
-        # way around a trivial kernel (an event pair costs ~10 us on a ~30 us kernel; the floor holds the trivial kernel's own
-        # ~2 us, so the net duration is if anything too short by that much). A k_step regression moves this number.
-        t_live = (t_step - event_floor_us * 1e-6) if t_step == t_step else None
-        if t_live is not None and t_live <= 0:
-            t_live = t_step
-        ach = a_step * B / t_live if t_live else 0.0
+        # roofline.frac / achieved = THIS run's algorithmic bytes over k_step's average launch duration:
+        #  (1) the rocprofv3 --kernel-trace --stats average of profiles/<tag>_kernel_stats.csv -- when profiles/pmc_summary.json says it
+        #      was taken with the code this process runs (``head`` == build.code_hash(): kernels, C ABI, launch loop, evaluator) on
+        #      this workload: the profiler's clock has no per-launch overhead, and anyone can recompute the figure from the CSV;
+        #  (2) otherwise the RAW HIP-event figure measured live around every k_step launch of the window on its stream. An event
+        #      pair adds ~9 us to a ~33 us kernel, and nothing is subtracted (round 4 subtracted a separately measured "floor" and
+        #      over-corrected by 6 us): the raw figure is a LOWER bound of the fraction, and named as one.
+        head = code_hash()
         ach_raw = a_step * B / t_step if t_step == t_step else 0.0
-        # committed rocprofv3 profile of the same command: average k_step duration and PMC traffic, REPLAYED (never measured inside
-        # bench.py) and named as such; only when this run is the profiled workload
         traffic = traffic_source = rocprof_ns = pmc_window = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):
-            try:
-                with open(pmc) as f:
-                    pm = json.load(f)
-                wl = pm.get("workload", {"boards_per_gpu": 4096, "sims_per_move": 400, "evaluator": "net", "max_plies": 200})
-                same = (wl["boards_per_gpu"], wl["sims_per_move"], wl["evaluator"], wl["max_plies"]) == (B, n, a.evaluator, a.max_plies) \
-                    and a.blocks == 40 and a.channels == 256 and a.preroll_plies == 200 and a.align
-                if not same:
-                    raise LookupError("the committed profile is of another workload")
-                ks = pm.get("k_step", {})
-                rocprof_ns = ks.get("avg_ns")
-                pmc_window = ks.get("window")
-                traffic = (pmc_window or {}).get("hbm_bytes_per_launch", ks.get("hbm_bytes_per_launch"))
-                traffic_source = f"profiles/pmc_summary.json ({pm.get('run', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, separate runs')}), replayed, not live"
-                if net_roofline is not None:  # HBM bytes of one convolution launch (PMC passes of profiles/run_profile.sh)
-                    per_kernel = pm.get("k_conv3x3", {}).get("hbm_bytes_per_launch")
-                    # one layer over the live rows = groups x chains launches of the tower kernel(s), two per chain with the edge-pair
-                    # kernel; the committed counter is the average over ALL k_conv3x3* launches (middle and edge alike)
-                    net_roofline["traffic"] = per_kernel * net_roofline["chains"] * net_roofline["groups"] * net_roofline["kernel_launches_per_chain_and_layer"] if per_kernel else None
-                    net_roofline["traffic_source"] = traffic_source
-            except Exception:
-                traffic = None
+        wl_now = {"boards_per_gpu": B, "sims_per_move": n, "evaluator": a.evaluator, "max_plies": a.max_plies, "blocks": a.blocks,
+                  "channels": a.channels, "preroll_plies": a.preroll_plies, "align": bool(a.align)}
+        pm, profile_why, profile_head = committed_profile(os.path.join(ROOT, "profiles", "pmc_summary.json"), head, wl_now)
+        if pm is not None:
+            ks = pm.get("k_step", {})
+            rocprof_ns = ks.get("avg_ns")
+            pmc_window = ks.get("window")
+            traffic = (pmc_window or {}).get("hbm_bytes_per_launch", ks.get("hbm_bytes_per_launch"))
+            traffic_source = f"profiles/pmc_summary.json ({pm.get('run', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, separate runs')}), head {profile_head}: replayed, not live"
+            if net_roofline is not None:  # HBM bytes of one convolution launch (PMC passes of profiles/run_profile.sh)
+                per_kernel = pm.get("k_conv3x3", {}).get("hbm_bytes_per_launch")
+                # one layer over the live rows = groups x chains launches of the tower kernel(s), two per chain with the edge-pair
+                # kernel; the committed counter is the average over ALL k_conv3x3* launches (middle and edge alike)
+                net_roofline["traffic"] = per_kernel * net_roofline["chains"] * net_roofline["groups"] * net_roofline["kernel_launches_per_chain_and_layer"] if per_kernel else None
+                net_roofline["traffic_source"] = traffic_source
+        if rocprof_ns:
+            t_used, dur_src = rocprof_ns * 1e-9, (f"rocprofv3 --kernel-trace --stats average of k_step, profiles/{pm.get('tag', 'rNN')}_kernel_stats.csv, "
+                                                  f"taken with this code (head {head}) on this workload")
+        else:
+            t_used, dur_src = (t_step if t_step == t_step else None), ("RAW HIP events around every k_step launch of the timed window on its stream (median; "
+                                                                       "the ~9 us an event pair adds are NOT subtracted: a lower bound of the fraction)"
+                                                                       + (f" -- {profile_why}" if profile_why else ""))
+        ach = a_step * B / t_used if t_used else 0.0
+        live_vs_profile = (t_step / (rocprof_ns * 1e-9)) if (rocprof_ns and t_step == t_step) else None
         # the move boundary, measured: HIP events around finish_move + harvest/restart (+ exchange) and the host wall
         # around the same region (the harvest and the exchange read counts on the host)
         mb_ev = float(np.mean([x.elapsed_time(y) for x, y in boundary["events"]])) if boundary["events"] else None
         mb_host = 1e3 * boundary["host_s"] / boundary["n"] if boundary["n"] else None
         step_ms = 1e3 * (dt - boundary["host_s"]) / a.steps  # one simulation step without the boundary share
-        moves_per_sec = world * B / ((n * step_ms + (mb_host or 0.0)) * 1e-3)
+        moves_per_sec = total_boards / ((n * step_ms + (mb_host or 0.0)) * 1e-3)
         flops = 8.551e9 * (a.blocks / 40.0) * (a.channels / 256.0) ** 2
         plies0, plies1 = st_pre["plies"], st_end["plies"]
         net_desc = f"random-init {a.blocks}x{a.channels} policy-value net fp16" if a.evaluator == "net" else "stub evaluator (uniform priors, v=0)"
@@ -531,8 +684,8 @@ def main():
             # the golden traces pin); --value-f16 is its CUDA path end to end (profiles/r03_bench_value_f16.json: the same rate)
             "dtype": ("u8 rules / f16 Q (reference CUDA path) / f64 PUCT (net: fp16)" if a.value_f16 else
                       "u8 rules / f32 Q (reference CPU path) / f64 PUCT (net: fp16)"), "data": "synthetic",
-            "config": {"workload": f"{B} concurrent boards/GPU x {n} sims/move, Dirichlet root noise on (device Philox), " + net_desc + ", " + state_desc,
-                       "boards_per_gpu": B, "sims_per_move": n, "evaluator": a.evaluator,
+            "config": {"workload": f"{a.boards if world > 1 else B} concurrent boards/GPU x {n} sims/move, Dirichlet root noise on (device Philox), " + net_desc + ", " + state_desc,
+                       "boards_per_gpu": a.boards if world > 1 else B, "boards_per_rank": counts, "sims_per_move": n, "evaluator": a.evaluator,
                        "preroll_plies": a.preroll_plies, "max_plies": a.max_plies, "warm_moves": a.warm_moves if a.evaluator == "net" else 0,
                        "window": f"{a.steps} steps starting at simulation {phase + a.warmup} of a move: "
                                  f"{boundary['n']} move boundary(ies) inside the timed window"},
@@ -544,16 +697,17 @@ def main():
                               "moves_per_sec_formula": "n_gpus * boards / (sims_per_move * (ms_per_step without the boundary) + ms_host)"},
             "roofline": {"bound": "hbm", "kernel": "k_step (fused expand+backup+select+movegen+encode)",
                          "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
-                         "duration_source": "HIP events around every k_step launch of the timed window on its stream, minus event_floor_us (live)",
-                         "avg_launch_us": (t_live or 0) * 1e6,
+                         "duration_source": dur_src, "avg_launch_us": (t_used or 0) * 1e6,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": a_step * B, "k_bar": kbar, "d_bar": dbar,
-                         # the raw event figure (floor included) and the floor itself
-                         "avg_launch_us_hip_events_raw": t_step * 1e6, "event_floor_us": event_floor_us,
-                         "frac_hip_events_raw": ach_raw / HBM_PEAK,
-                         # cross-check, NOT this run: this run's bytes over the committed rocprofv3 --kernel-trace --stats average of k_step
-                         "avg_launch_us_committed_rocprofv3": (rocprof_ns * 1e-3 if rocprof_ns else None),
-                         "frac_at_committed_rocprofv3_duration": (a_step * B / (rocprof_ns * 1e-9) / HBM_PEAK if rocprof_ns else None),
+                         # always: the raw live HIP-event figure of this run (a lower bound of the fraction)
+                         "avg_launch_us_hip_events_raw": t_step * 1e6, "frac_hip_events_raw": ach_raw / HBM_PEAK,
+                         "code_hash": head, "profile_head": profile_head,
+                         # how far this run's raw event figure sits above the profile's duration (an event pair's own cost is ~1.25x here);
+                         # beyond 1.5x k_step itself has changed since the profile
+                         "live_over_profile": live_vs_profile,
+                         "warning": ("this run's k_step (HIP events) is more than 1.5x the committed profile's: re-profile"
+                                     if (live_vs_profile and live_vs_profile > 1.5) else None),
                          # counters and algorithmic bytes of ONE pass (the PMC passes' own timed window): reproducible from profiles/
                          "pmc_window": pmc_window},
             "survey_a_sim_bytes": a_sim_survey,
@@ -577,19 +731,45 @@ def main():
             "setup_seconds": setup_s,
         }
         if world > 1:
+            xg = gather if gather is not None else ex
             out["multi_gpu"] = {"world_size": world, "ranks_seen": ranks_seen, "backend": a.backend,
                                 "error_flags_any": err_any, "bad_records": bad_total,
-                                "per_rank_sims_per_sec": per_rank, "exchanges_in_window": boundary["n"],
-                                "collectives_in_window": boundary["collectives"], "rows_gathered": boundary["rows"],
-                                "gather_ms": 1e3 * boundary["gather_s"] / max(1, boundary["n"]),
+                                "boards_per_rank": counts, "board_id_base_per_rank": bases,
+                                "per_rank_sims_per_sec": per_rank,
+                                # every rank's own time per step over its K steps, boundary included, WITHOUT any wait for a peer
+                                # (with --exchange async nothing in the window waits; the job's ms_per_step is the slowest rank + the drain)
+                                "rank_step_ms": rank_step_ms,
+                                "exchange": a.exchange, "exchanges_in_window": boundary["n"],
+                                "rows_gathered": boundary["rows"],
                                 "expand_ms_host": 1e3 * boundary["expand_s"] / max(1, boundary["n"]),
                                 "wire_format": "compact ply records, 880 B per ply = 2 dense rows of 29,768 B (ccz_harvest_records -> "
                                                "all_gather_into_tensor -> ccz_expand_records into the replay ring of the ranks that consume rows)",
-                                "bytes_sent_per_rank_per_collective": gather.bytes_per_exchange(), "gather_capacity_plies": gather.cap,
-                                "payload_bytes_rank0_per_exchange": 880 * boundary["rows_local"] // (2 if e.mirror else 1) // max(1, boundary["n"]),
+                                "bytes_sent_per_rank_per_collective": xg.bytes_per_exchange(), "gather_capacity_plies": xg.cap,
+                                "payload_bytes_rank0_per_exchange": 880 * boundary["rows_local"] // mul // max(1, boundary["n"]),
                                 "ring_ranks": ring_ranks, "replay_ring_rows": rb.cap if rb is not None else 0,
                                 "replay_rows_total": rb.total if rb is not None else 0,
                                 "dist_timeout_s": a.dist_timeout}
+            if ex is not None:
+                out["multi_gpu"].update({
+                    # collectives ISSUED between the window's start and the end of its K steps, and by the drain behind them
+                    "collectives_in_window": ex_window[0], "collectives_in_drain": ex.issued - ex_stats0[0] - ex_window[0],
+                    "exchanges_completed_in_window_and_drain": boundary["exchanges_completed"],
+                    "games_gathered": boundary["games"],
+                    # what rank 0's launch loop spent inside the exchange during its K steps (host seconds: announcements, store
+                    # polls, issuing the collective, reading headers) and the longest single call of any rank
+                    "exchange_host_ms_rank0": 1e3 * ex_window[1], "exchange_max_call_ms_per_rank": rank_xchg_max_call_ms,
+                    "plies_sent_rank0": ex.plies_sent - ex_stats0[2], "backlog_peak_plies_rank0": ex.max_backlog_plies,
+                    "drain_ms_rank0": 1e3 * drain_s,
+                    "what": "replay.AsyncRecordExchange: post at the move boundary (backlog + announcement on the job's TCPStore), ONE async "
+                            "all_gather_into_tensor from a side stream once every rank has announced it, picked up by a later step's tick; "
+                            "the drain (every record of the window delivered to every rank) is inside the timed region"})
+            else:
+                out["multi_gpu"].update({"collectives_in_window": boundary["collectives"],
+                                         "gather_ms": 1e3 * boundary["gather_s"] / max(1, boundary["n"])})
+            if slow_rank >= 0:
+                out["multi_gpu"]["slow_rank"] = {"rank": slow_rank, "sleep_s_per_boundary": slow_s}
+        if calibration is not None:
+            out["rank0_calibration"] = calibration
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_seconds, a.blocks, a.channels)
         print(json.dumps(out), flush=True)

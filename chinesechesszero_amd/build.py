@@ -19,3 +19,22 @@ def build(verbose: bool = False) -> str:
     if not os.path.exists(path):
         raise RuntimeError("libcczero.so was not produced")
     return path
+
+
+# what decides the kernels a bench line times and the launches around them: a committed rocprofv3 profile describes a bench run
+# only while these files are the ones it was taken with (bench.py prints the hash, profiles/summarize.py stores it as ``head``)
+_HASHED = ("csrc/*.h", "csrc/*.hip", "csrc/Makefile", "engine.py", "selfplay.py", "net.py", "_lib.py")
+
+
+def code_hash() -> str:
+    """16 hex digits over the sources of the timed path (kernels, C ABI, launch loop, evaluator). There is no ``.git`` on a GPU
+    box (gpurun ships a snapshot without it), so "the HEAD a profile was taken at" is this content hash, not a commit id."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for pat in _HASHED:
+        for p in sorted(glob.glob(os.path.join(_HERE, pat))):
+            h.update(os.path.relpath(p, _HERE).encode() + b"\0")
+            with open(p, "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]

@@ -28,8 +28,8 @@ def _mask_len(name: str):
 def visible_gpus(sysfs_root: str = "/sys/class/kfd/kfd/topology/nodes") -> int:
     """GPUs a child process of this one could open, WITHOUT initialising HIP here: KFD topology nodes with SIMDs (CPUs are
     nodes with ``simd_count 0``), clipped by the ``HIP_VISIBLE_DEVICES`` / ``ROCR_VISIBLE_DEVICES`` / ``CUDA_VISIBLE_DEVICES``
-    masks. When the topology cannot be read (no /sys in a sandbox), ``torch.cuda.device_count()`` is asked instead -- on
-    PyTorch-ROCm that enumerates without creating a context."""
+    masks. When the topology cannot be read (no /sys in a sandbox), a short-lived CHILD process asks
+    ``torch.cuda.device_count()`` (:func:`_device_count_in_child`): this process never calls into HIP."""
     n = None
     try:
         nodes = glob.glob(os.path.join(sysfs_root, "*", "properties"))
@@ -47,16 +47,43 @@ def visible_gpus(sysfs_root: str = "/sys/class/kfd/kfd/topology/nodes") -> int:
     except Exception:
         n = None
     if n is None:
-        try:
-            import torch
-            n = int(torch.cuda.device_count())
-        except Exception:
-            n = 0
+        n = _device_count_in_child()
     for name in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         m = _mask_len(name)
         if m is not None:
             n = min(n, m)
     return n
+
+
+def _device_count_in_child(timeout_s: float = 120.0) -> int:
+    """``torch.cuda.device_count()`` as a fresh child process sees it. On ROCm that call can go through ``hipGetDeviceCount`` and
+    initialise HIP/HSA; the parent that later spawns the ranks must stay GPU-free (module docstring), so the question is asked in
+    a process that exits right after answering. 0 when the child fails or says nothing parseable."""
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print('ccz_device_count', torch.cuda.device_count())"],
+                           capture_output=True, text=True, timeout=timeout_s)
+        for line in r.stdout.splitlines():
+            if line.startswith("ccz_device_count"):
+                return int(line.split()[1])
+    except Exception:
+        pass
+    return 0
+
+
+def board_partition(world: int, boards: int, boards_rank0: int | None = None):
+    """Boards per rank and the global id of every rank's first board. All ranks hold ``boards`` boards except rank 0, which may
+    hold fewer (``boards_rank0``: the rank that shares its GPU with the trainer, BASELINE configs[4]). The ids are a prefix sum, so
+    board ``g`` of the job has the same RNG stream -- and plays the same games -- however the boards are split over ranks."""
+    counts = [int(boards)] * int(world)
+    if boards_rank0 is not None:
+        counts[0] = int(boards_rank0)
+    if min(counts) <= 0:
+        raise ValueError("every rank needs at least one board")
+    bases, acc = [], 0
+    for c in counts:
+        bases.append(acc)
+        acc += c
+    return counts, bases
 
 
 def preflight(n_ranks: int, share_gpu: bool = False, gpus: int | None = None) -> str | None:
@@ -65,13 +92,9 @@ def preflight(n_ranks: int, share_gpu: bool = False, gpus: int | None = None) ->
     have = visible_gpus() if gpus is None else int(gpus)
     need = 1 if share_gpu else int(n_ranks)
     if have < need and gpus is None:
-        # second opinion before refusing: a container may show less of the KFD topology than its processes can open. Counting
-        # devices through PyTorch-ROCm enumerates without creating a context (and a parent that only spawns children may hold one).
-        try:
-            import torch
-            have = max(have, int(torch.cuda.device_count()))
-        except Exception:
-            pass
+        # second opinion before refusing: a container may show less of the KFD topology than its processes can open. Asked in a
+        # short-lived child: counting devices can initialise HIP, and this process must not
+        have = max(have, _device_count_in_child())
     if have < need:
         return (f"bench: --gpus {n_ranks} needs {need} visible GPU(s), this node shows {have} "
                 f"(KFD topology / *_VISIBLE_DEVICES); not starting any rank")

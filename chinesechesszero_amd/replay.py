@@ -13,6 +13,7 @@ file (collect.py:146-167); parity = the union of shards equals what N collectors
 from __future__ import annotations
 
 import time
+from typing import NamedTuple
 
 import torch
 import torch.distributed as dist
@@ -191,6 +192,296 @@ def exchange_finished_games(source, gatherer: RecordGatherer, done: int):
         if not gatherer.any_more:
             return
         chunk = nxt
+
+
+class Exchanged(NamedTuple):
+    """One completed exchange of :class:`AsyncRecordExchange`."""
+    union: torch.Tensor          # uint8 [P, 880]: every rank's records, rank-major, whole games
+    games: int                   # finished games announced with them, summed over ranks
+    rows_per_rank: list          # records per source rank (the union's segments)
+    index: int                   # exchange number (the same on every rank)
+
+
+class AsyncRecordExchange(_FusedGather):
+    """The all-gather of finished games with NO rank ever waiting for another one (round 5).
+
+    The reference's collectors and its trainer are separate processes that never wait on each other (README.md:31-48,
+    collect.py:181-183: N shell commands appending to one file). :class:`RecordGatherer` met every peer once per move inside a
+    blocking collective + header read, so a job ran at the pace of its slowest rank (the one that shares its GPU with the trainer).
+    Here a rank only ever does three non-blocking things:
+
+    * :meth:`post` -- at its move boundary: the finished games (compact ply records, whole games) join a local BACKLOG in
+      device memory, and the rank announces on the job's key-value store (the rendezvous TCPStore) that it is ready for
+      exchange ``j``;
+    * :meth:`tick` -- any time (bench.py: after every simulation step): when ALL ranks have announced ``j``, the backlog goes
+      into the send slot and ONE ``all_gather_into_tensor(async_op=True)`` is issued from a side stream (it depends on the
+      harvest only, not on the simulation steps queued on the main stream); a completed exchange is handed over as an
+      :class:`Exchanged` ``(union = records uint8 [P, 880], rank-major, whole games; games; rows_per_rank; index)``;
+    * the collective itself runs on the process group's own stream while the search goes on.
+
+    Exchanges pair by their index ``j``, not by move number: a fast rank posts several moves into one exchange, a slow rank
+    delays DATA, never its peers' launch loops. The store handshake keeps the collective's kernel from spinning on a fast
+    rank's CUs while a slow rank is still a move away: it is launched only once every rank is known to be within one
+    ``tick`` of launching it too. At most ONE exchange is in flight; the receive slot is double-buffered, so a handed-over
+    union stays valid until the second-next exchange is issued (consume it, or enqueue its consumer, before that).
+
+    What stays of :class:`RecordGatherer`: the fused ``[header 64 B | payload]`` slot (counts ride in the collective), whole
+    games only, and the abort flag -- a rank that cannot take part (one game longer than the slot) joins with the flag up and
+    EVERY rank raises :class:`GatherAborted` when it completes that exchange. A peer that never announces makes :meth:`tick`
+    raise after ``timeout_s`` (naming the missing ranks) instead of leaving anyone inside a collective.
+    :meth:`flush` (blocking; end of a run, or before any other collective of the job) drains: exchanges are repeated until every
+    rank's header says "closing, nothing left" -- every rank sees the same headers, so all stop after the same exchange.
+    """
+
+    READY_POLL_S = 0.02   # a waiting rank asks the store at most this often (one ~0.1 ms round trip)
+    _instances = 0
+
+    def __init__(self, capacity_plies: int = 65536, device="cpu", group=None, always_collective: bool = False,
+                 store=None, timeout_s: float = 180.0, name: str = "ccz_xchg"):
+        self.cap = int(capacity_plies)
+        if self.cap <= 0:
+            raise ValueError("capacity_plies must be positive")
+        super().__init__(self.cap * REC_BYTES, device, group, always_collective)
+        self._recv2 = [self._recv, torch.zeros_like(self._recv)]
+        self.timeout_s = float(timeout_s)
+        self._name = name
+        self._store = store
+        if self._store is None and not self._solo() and dist.is_initialized():
+            from torch.distributed.distributed_c10d import _get_default_store
+            # (every rank builds its exchanges in the same order: the instance counter keeps their keys apart)
+            AsyncRecordExchange._instances += 1
+            self._store = dist.PrefixStore(f"{name}{AsyncRecordExchange._instances}", _get_default_store())
+        self._xs = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self._backlog: list[torch.Tensor] = []
+        self._backlog_plies = 0
+        self._games_pending = 0
+        self._work = None
+        self._inflight = None        # (index, receive buffer) of the exchange in flight
+        self._announced = -1         # highest exchange index this rank has announced
+        self._announced_at = 0.0
+        self._last_ready_check = 0.0
+        self._closing = False
+        self._all_closed = False
+        self.issued = 0              # exchanges issued / completed so far (the next one has index ``issued``)
+        self.completed = 0
+        self.moves_posted = 0
+        # statistics (bench.py reports them): host seconds spent inside post()/tick() -- what this rank's launch loop lost
+        self.host_seconds = 0.0
+        self.max_call_s = 0.0
+        self.max_backlog_plies = 0
+        self.plies_sent = 0
+        self.last_heads = None
+
+    # ---- the three non-blocking calls ------------------------------------------------------------------------------------
+    def post(self, chunks, games: int = 0):
+        """This rank's finished games of one move boundary: ``chunks`` = iterable of uint8 [P, 880] tensors, whole games each
+        (``engine.harvest_record_chunks``), possibly empty. Never waits for a peer. Returns what :meth:`tick` returns."""
+        t0 = time.perf_counter()
+        if isinstance(chunks, torch.Tensor):
+            chunks = [chunks]
+        ev = None
+        for c in chunks:
+            if int(c.shape[0]) == 0:
+                continue
+            c = c if c.device == self.device else c.to(self.device)
+            self._backlog.append(c)
+            self._backlog_plies += int(c.shape[0])
+        if self._xs is not None:   # the side stream may read the new records only after the harvest that wrote them
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._harvest_ev = ev
+        self._games_pending += int(games)
+        self.moves_posted += 1
+        self.max_backlog_plies = max(self.max_backlog_plies, self._backlog_plies)
+        self._announce()
+        self._account(t0)
+        return self.tick()
+
+    def tick(self, block: bool = False):
+        """Advance the exchange without waiting for anybody: complete the collective in flight if it has finished, issue the
+        next one if every rank has announced it. Returns the list of completed exchanges (:class:`Exchanged`; empty
+        nearly always). ``block``: wait for the collective in flight (used by :meth:`flush`)."""
+        t0 = time.perf_counter()
+        out = []
+        if self._solo():
+            if self._backlog or self._games_pending:
+                union = self._backlog[0] if len(self._backlog) == 1 else (torch.cat(self._backlog) if self._backlog else
+                                                                          torch.empty((0, REC_BYTES), dtype=torch.uint8, device=self.device))
+                out.append(Exchanged(union, self._games_pending, [int(union.shape[0])], self.issued))
+                self.rows_per_rank = [int(union.shape[0])]
+                self.plies_sent += int(union.shape[0])
+                self._backlog, self._backlog_plies, self._games_pending = [], 0, 0
+                self.issued += 1
+                self.completed += 1
+            self._all_closed = self._closing
+            self._account(t0)
+            return out
+        if self._work is not None and (block or self._work.is_completed()):
+            out.append(self._complete())
+        elif self._work is None and self._announced >= self.issued and self._everyone_ready(block):
+            self._issue()
+        self._account(t0)
+        return out
+
+    def flush(self):
+        """Blocking drain (end of a run; before any OTHER collective of the job is issued): waits for the exchange in flight and
+        repeats exchanges until every rank is closing with an empty backlog. Returns the completed exchanges, in order; their
+        unions are COPIES (the drain may run through more exchanges than the receive slots hold)."""
+        return [x._replace(union=x.union.clone()) for x in self.flush_iter()]
+
+    def flush_iter(self):
+        """:meth:`flush` as a generator: every completed exchange is yielded before the next one is issued, so the union (a view
+        of a receive slot) can be consumed in place. Iterate it to the end."""
+        self._closing = True
+        self._all_closed = False
+        try:
+            while True:
+                if self._work is None:
+                    self._announce()
+                for x in self.tick(block=True):       # completes the exchange in flight, else waits for all ranks and issues
+                    yield x
+                if self._all_closed:
+                    return
+        finally:
+            self._closing = False
+
+    # ---- internals -------------------------------------------------------------------------------------------------------
+    def _account(self, t0):
+        dt = time.perf_counter() - t0
+        self.host_seconds += dt
+        self.max_call_s = max(self.max_call_s, dt)
+
+    def _key(self, j, rank=None):
+        return f"x{j}" if rank is None else f"x{j}r{rank}"
+
+    def _announce(self):
+        j = self.issued   # the next exchange to be issued (one in flight has index issued - 1 and completes without this rank's help)
+        if self._announced >= j or self._solo():
+            return
+        self._announced = j
+        self._announced_at = time.perf_counter()
+        if self._store is not None:
+            self._store.set(self._key(j, self.rank), b"1")
+            self._store.add(self._key(j), 1)
+
+    def _everyone_ready(self, block: bool) -> bool:
+        """Have all ranks announced exchange ``issued``? One store round trip, rate-limited; ``block`` polls until they have
+        (or the timeout names the ranks that have not)."""
+        if self._store is None:
+            return True
+        j = self.issued
+        while True:
+            now = time.perf_counter()
+            if block or now - self._last_ready_check >= self.READY_POLL_S:
+                self._last_ready_check = now
+                if int(self._store.add(self._key(j), 0)) >= self.world:
+                    return True
+            if now - self._announced_at > self.timeout_s:
+                missing = []
+                for k in range(self.world):
+                    try:
+                        if not self._store.check([self._key(j, k)]):
+                            missing.append(k)
+                    except Exception:
+                        missing.append(k)
+                raise RuntimeError(f"exchange {j}: rank(s) {missing} did not announce within {self.timeout_s:.0f} s "
+                                   f"(this rank {self.rank} has {self._backlog_plies} plies waiting)")
+            if not block:
+                return False
+            time.sleep(0.002)
+
+    def _fill(self, payload) -> tuple[int, int]:
+        """Move whole games from the backlog into the send slot: (records placed, abort flag)."""
+        m = 0
+        while self._backlog and m < self.cap:
+            c = self._backlog[0]
+            n = int(c.shape[0])
+            take = n
+            if n > self.cap - m:
+                if m:          # a chunk that does not fit behind what is already placed waits for the next exchange
+                    break
+                try:
+                    take = self._whole_games(c, 0, self.cap)
+                except ValueError as e:   # one game longer than the slot: join the collective with the abort flag up
+                    self._abort_why = str(e)
+                    return m, 1
+            payload[m:m + take].copy_(c[:take], non_blocking=True)
+            if self._xs is not None:
+                c.record_stream(self._xs)
+            m += take
+            if take == n:
+                self._backlog.pop(0)
+            else:
+                self._backlog[0] = c[take:]
+            self._backlog_plies -= take
+        return m, 0
+
+    _whole_games = staticmethod(RecordGatherer._whole_games)
+
+    def _issue(self):
+        j = self.issued
+        recv = self._recv2[j & 1]
+        ctx = torch.cuda.stream(self._xs) if self._xs is not None else _NullCtx()
+        with ctx:
+            if self._xs is not None and getattr(self, "_harvest_ev", None) is not None:
+                self._xs.wait_event(self._harvest_ev)
+            m, abort = self._fill(self._payload_of(self._send))
+            hdr = torch.tensor([m, self._backlog_plies, 1 if self._closing else 0, self._games_pending, abort, j,
+                                self.moves_posted, 0], dtype=torch.int64)
+            self._send[:self.HEADER].view(torch.int64).copy_(hdr)       # (blocking on the side stream only)
+            self._work = dist.all_gather_into_tensor(recv, self._send, group=self.group, async_op=True)
+        self._inflight = (j, recv)
+        self._games_pending = 0
+        self.plies_sent += m
+        self.issued += 1
+        self.collectives += 1
+
+    def _payload_of(self, buf, k: int = 0):
+        base = k * self.slot_bytes + self.HEADER
+        return buf[base: base + self.cap * REC_BYTES].view(self.cap, REC_BYTES)
+
+    def _complete(self):
+        """The exchange in flight has finished (or: wait for it): read the headers, hand over the union."""
+        j, recv = self._inflight
+        work, self._work, self._inflight = self._work, None, None
+        # the headers are read on the SIDE stream (which waits for the collective's stream only): the host does not wait for the
+        # simulation steps queued on the main stream. gloo: a host wait.
+        with (torch.cuda.stream(self._xs) if self._xs is not None else _NullCtx()):
+            work.wait()
+            heads = recv.view(self.world, self.slot_bytes)[:, :self.HEADER].contiguous().view(torch.int64).view(self.world, 8).cpu()
+        if self._xs is not None:   # consumers of the union are enqueued on the current stream: behind the collective
+            torch.cuda.current_stream(self.device).wait_stream(self._xs)
+        self.last_heads = heads
+        self.completed += 1
+        if self._store is not None and self.rank == 0 and j >= 2:   # the announcements of exchange j - 2 are history
+            try:
+                for key in [self._key(j - 2)] + [self._key(j - 2, k) for k in range(self.world)]:
+                    self._store.delete_key(key)
+            except Exception:
+                pass
+        if any(int(heads[k, 5]) != j for k in range(self.world)):
+            raise RuntimeError(f"exchange {j}: the ranks paired different exchanges {heads[:, 5].tolist()} (a collective was issued "
+                               f"on this group outside the exchange)")
+        bad = [k for k in range(self.world) if int(heads[k, 4])]
+        if bad:
+            raise GatherAborted(f"rank(s) {bad} aborted the exchange" + (f": {self._abort_why}" if self.rank in bad and self._abort_why else ""))
+        segs = []
+        self.rows_per_rank = [int(heads[k, 0]) for k in range(self.world)]
+        for k in range(self.world):
+            if self.rows_per_rank[k]:
+                segs.append(self._payload_of(recv, k)[:self.rows_per_rank[k]])
+        union = (segs[0] if len(segs) == 1 else torch.cat(segs)) if segs else torch.empty((0, REC_BYTES), dtype=torch.uint8, device=self.device)
+        self._all_closed = bool((heads[:, 2] == 1).all()) and bool((heads[:, 1] == 0).all())
+        self.user_sum = int(heads[:, 3].sum())
+        return Exchanged(union, self.user_sum, list(self.rows_per_rank), j)
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 class TupleGatherer(_FusedGather):

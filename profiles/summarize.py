@@ -30,7 +30,7 @@ def main():
     stats = find(os.path.join(out_dir, "trace"), "*kernel_stats.csv")
     if stats:
         rows = list(csv.DictReader(open(stats)))
-        keep = rows[:48]
+        keep = rows[:48] + [r for r in rows[48:] if "ccz" in r.get("Name", "")]   # the top of the list + every kernel of this library
         with open(os.path.join(root, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
             w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
             w.writeheader()
@@ -208,6 +208,13 @@ def main():
     if tb:  # bench.py replays these figures only for the workload they were measured on
         pm["workload"] = {"boards_per_gpu": tb["config"]["boards_per_gpu"], "sims_per_move": tb["config"]["sims_per_move"],
                           "evaluator": tb["config"]["evaluator"], "max_plies": tb["config"]["max_plies"]}
+        # the code the profile was taken with (chinesechesszero_amd.build.code_hash(): kernels, C ABI, launch loop, evaluator): bench.py uses
+        # the profile's k_step duration and counters only while it runs the same code
+        pm["head"] = tb.get("roofline", {}).get("code_hash")
+        heads = {name: b.get("roofline", {}).get("code_hash") for name, b in summary.get("_bench", {}).items()}
+        if len(set(heads.values())) > 1:
+            pm["head_warning"] = f"the passes were taken with different code: {heads}"
+    pm["tag"] = tag
     pm["run"] = (f"profiles/run_profile.sh {tag}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes of bench.py --steps 24, "
                  "counter collection filtered per kernel (k_step: the bench's full command shape; k_conv3x3: short passes)")
     with open(os.path.join(root, "pmc_summary.json"), "w") as f:

@@ -32,6 +32,8 @@ sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+from _ref_guard import assert_reference_untouched, silence_reference_log  # noqa: E402
 
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle as _oracle  # noqa: E402
@@ -63,6 +65,7 @@ def load_reference():
     import tools as ref_tools  # noqa
     import mcts as ref_mcts  # noqa
     os.chdir(cwd)
+    silence_reference_log(ref_tools, ref_mcts)   # tools.log writes next to tools.py whatever the working directory is (tools.py:46-51)
     return ref_tools, ref_mcts
 
 
@@ -336,3 +339,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+    assert_reference_untouched()

@@ -24,6 +24,8 @@ sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+from _ref_guard import assert_reference_untouched, silence_reference_log  # noqa: E402
 
 from oracle import OracleBoard  # noqa: E402
 from oracle.evaluators import hash_eval  # noqa: E402
@@ -63,6 +65,7 @@ def load_reference():
     import game as ref_game  # noqa
     import mcts as ref_mcts  # noqa
     os.chdir(cwd)
+    silence_reference_log(ref_collect, ref_game, ref_mcts)   # tools.log writes next to tools.py whatever the working directory is (tools.py:46-51)
     return ref_game, ref_mcts, ref_collect
 
 
@@ -159,3 +162,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+    assert_reference_untouched()

@@ -23,6 +23,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
+from _ref_guard import assert_reference_untouched, silence_reference_log  # noqa: E402
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import net_recipe  # noqa: E402
@@ -51,6 +52,7 @@ def load_reference():
     os.chdir("/tmp")
     import net as ref_net  # noqa
     os.chdir(cwd)
+    silence_reference_log(ref_net)   # tools.log writes next to tools.py whatever the working directory is (tools.py:46-51)
     return ref_net
 
 
@@ -110,3 +112,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+    assert_reference_untouched()

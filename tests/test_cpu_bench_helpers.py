@@ -1,0 +1,64 @@
+"""CPU: the parts of bench.py that need no GPU -- which committed profile a bench line may quote (round 5: a profile is tied to
+the code it was taken with), and that the code hash moves when a kernel source does."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+WL = {"boards_per_gpu": 4096, "sims_per_move": 400, "evaluator": "net", "max_plies": 200, "blocks": 40, "channels": 256,
+      "preroll_plies": 200, "align": True}
+
+
+def _profile(tmp_path, **kw):
+    pm = {"k_step": {"avg_ns": 33000.0, "window": {"hbm_bytes_per_launch": 4.0e7}},
+          "workload": {"boards_per_gpu": 4096, "sims_per_move": 400, "evaluator": "net", "max_plies": 200}, "head": "aaaabbbbccccdddd", "tag": "r05"}
+    pm.update(kw)
+    p = tmp_path / "pmc_summary.json"
+    p.write_text(json.dumps(pm))
+    return str(p)
+
+
+def test_a_profile_of_other_code_or_another_workload_is_refused(tmp_path):
+    import bench
+    pm, why, head = bench.committed_profile(_profile(tmp_path), "aaaabbbbccccdddd", WL)
+    assert pm is not None and why is None and head == "aaaabbbbccccdddd" and pm["k_step"]["avg_ns"] == 33000.0
+    pm, why, head = bench.committed_profile(_profile(tmp_path), "0000111122223333", WL)           # the code changed since the profile
+    assert pm is None and "other code" in why and head == "aaaabbbbccccdddd"
+    pm, why, _ = bench.committed_profile(_profile(tmp_path, head=None), "aaaabbbbccccdddd", WL)   # a profile that does not say
+    assert pm is None and "no head" in why
+    for key, val in (("boards_per_gpu", 1024), ("sims_per_move", 800), ("evaluator", "stub"), ("blocks", 2), ("align", False)):
+        pm, why, _ = bench.committed_profile(_profile(tmp_path), "aaaabbbbccccdddd", dict(WL, **{key: val}))
+        assert pm is None and "another workload" in why and key in why
+    pm, why, _ = bench.committed_profile(str(tmp_path / "missing.json"), "x", WL)
+    assert pm is None and "no committed profile" in why
+
+
+def test_the_committed_profile_names_its_head_and_holds_no_kernel_that_no_longer_runs():
+    """profiles/pmc_summary.json as committed: it says which code it was taken with, and every kernel block in it belongs to a kernel
+    the profiled run launched (round 4 shipped a k_head_conv1x1 block of a kernel that had left the timed path)."""
+    with open(os.path.join(ROOT, "profiles", "pmc_summary.json")) as f:
+        pm = json.load(f)
+    assert isinstance(pm.get("head"), str) and len(pm["head"]) == 16 and pm.get("tag")
+    stats = os.path.join(ROOT, "profiles", f"{pm['tag']}_kernel_stats.csv")
+    assert os.path.exists(stats)
+    names = open(stats).read()
+    for k, v in pm.items():
+        if isinstance(v, dict) and k.startswith("k_"):
+            assert k in names, f"{k}: in the PMC summary, not in {pm['tag']}_kernel_stats.csv"
+
+
+def test_code_hash_follows_the_kernel_sources(tmp_path, monkeypatch):
+    from chinesechesszero_amd import build
+    h0 = build.code_hash()
+    assert len(h0) == 16 and h0 == build.code_hash()
+    # a copy of the package tree with one byte more in one kernel header hashes differently
+    import shutil
+    dst = tmp_path / "pkg"
+    shutil.copytree(os.path.join(ROOT, "chinesechesszero_amd"), dst, ignore=shutil.ignore_patterns("*.so", "__pycache__", ".pytest_cache"))
+    monkeypatch.setattr(build, "_HERE", str(dst))
+    assert build.code_hash() == h0
+    with open(dst / "csrc" / "cczero_kernels.h", "a") as f:
+        f.write("\n")
+    assert build.code_hash() != h0

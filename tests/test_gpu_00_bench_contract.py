@@ -40,11 +40,14 @@ def _env():
     return env
 
 
-def test_bench_starts_its_own_ranks_and_exchanges_inside_the_timed_window():
+@pytest.mark.parametrize("exchange", ["async", "sync"])
+def test_bench_starts_its_own_ranks_and_exchanges_inside_the_timed_window(exchange):
     """`python bench.py --gpus 2 ...` with NO launcher (the driver's N = 1 command shape with another N): bench.py starts its
-    own two ranks as a child `torch.distributed.run` before touching the GPU and relays rank 0's line and the exit code."""
+    own two ranks as a child `torch.distributed.run` before touching the GPU and relays rank 0's line and the exit code.
+    async (the default): replay.AsyncRecordExchange -- post at the boundary, the collective issued by a later step, the drain inside
+    the timed region; sync: round 4's blocking all-gather at the boundary."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2",
-           "--backend", "gloo", "--share-gpu", "--gather-plies", "1024", "--playout", "16"] + SMALL
+           "--backend", "gloo", "--share-gpu", "--gather-plies", "1024", "--playout", "16", "--exchange", exchange] + SMALL
     env = _env()
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -53,13 +56,23 @@ def test_bench_starts_its_own_ranks_and_exchanges_inside_the_timed_window():
     j = _json_line(r.stdout)
     assert j["n_gpus"] == 2 and j["steps"] == 12 and j["warmup"] == 2 and j["scaling"] == "weak" and j["unit"] == "sims/s"
     m = j["multi_gpu"]
-    assert m["world_size"] == 2 and m["ranks_seen"] == 2 and m["backend"] == "gloo"
-    # a 12-step window of a 16-simulation move still holds one real move boundary with its exchange: ONE collective
-    assert m["exchanges_in_window"] == 1 and m["collectives_in_window"] == 1
+    assert m["world_size"] == 2 and m["ranks_seen"] == 2 and m["backend"] == "gloo" and m["exchange"] == exchange
+    assert m["boards_per_rank"] == [256, 256] and m["board_id_base_per_rank"] == [0, 256]
+    assert len(m["rank_step_ms"]) == 2 and all(0 < v <= j["ms_per_step"] * 1.001 for v in m["rank_step_ms"])
+    # a 12-step window of a 16-simulation move still holds one real move boundary with its exchange
+    assert m["exchanges_in_window"] == 1
+    if exchange == "sync":
+        assert m["collectives_in_window"] == 1 and m["gather_ms"] > 0      # ONE blocking collective at the boundary
+    else:
+        # the boundary's records travel in a collective issued by a later step (or by the drain); the drain adds the closing one(s)
+        assert m["collectives_in_window"] + m["collectives_in_drain"] >= 2 and m["collectives_in_window"] <= 2
+        assert m["exchanges_completed_in_window_and_drain"] == m["collectives_in_window"] + m["collectives_in_drain"]
+        assert m["exchange_host_ms_rank0"] >= 0 and len(m["exchange_max_call_ms_per_rank"]) == 2
+        assert m["plies_sent_rank0"] == j["move_boundary"]["rows_harvested_rank0"] // 2
     # boards 0, 12, 24, ... of each rank stand at the 12-ply cap: 22 games x 12 plies x 2 (mirror images) per rank at least
     assert m["rows_gathered"] >= 2 * 22 * 12 * 2 and j["move_boundary"]["games_finished"] >= 44
     # the wire carries compact ply records: 880 B per ply (= two dense rows of 29,768 B), one fixed-size slot per rank
-    assert m["gather_ms"] > 0 and m["bytes_sent_per_rank_per_collective"] == 64 + 1024 * 880 and m["gather_capacity_plies"] == 1024
+    assert m["bytes_sent_per_rank_per_collective"] == 64 + 1024 * 880 and m["gather_capacity_plies"] == 1024
     assert m["payload_bytes_rank0_per_exchange"] == 880 * j["move_boundary"]["rows_harvested_rank0"] // 2
     # every rank's ring received the union: the window's exchange and those of the two untimed warm-up moves before it
     assert m["bad_records"] == 0 and m["replay_rows_total"] >= m["rows_gathered"] and j["config"]["warm_moves"] == 2
@@ -69,6 +82,56 @@ def test_bench_starts_its_own_ranks_and_exchanges_inside_the_timed_window():
     assert 0 < j["value"] <= sum(m["per_rank_sims_per_sec"]) * 1.001
     assert j["move_boundary"]["in_window"] == 1 and j["move_boundary"]["ms_host"] > 0
     assert abs(j["ms_per_step"] * 12 * 1e-3 * j["value"] - 2 * 256 * 12) < 1e-3 * 2 * 256 * 12
+
+
+def _two_ranks(extra, steps="12"):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", steps, "--warmup", "2",
+           "--backend", "gloo", "--share-gpu", "--gather-plies", "1024", "--playout", "16"] + extra + SMALL
+    env = _env()
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    return _json_line(r.stdout)
+
+
+def test_bench_a_slow_rank_delays_data_not_its_peer():
+    """Rank 1 sleeps 3 s at the window's move boundary (--slow-rank 1:3). With the asynchronous exchange rank 0's own K steps
+    take what they take without it (the reference's collectors never wait for each other, collect.py:181-183); with round 4's
+    blocking all-gather rank 0 sat in the collective until rank 1 woke up. The job's time (slowest rank) holds the sleep either way."""
+    a = _two_ranks(["--slow-rank", "1:3"])
+    m = a["multi_gpu"]
+    own = [v * 12 * 1e-3 for v in m["rank_step_ms"]]       # each rank's own time over its 12 steps, seconds
+    assert own[1] >= 3.0 and own[0] < own[1] - 2.5, own   # rank 0 did not wait for the sleeper
+    assert a["ms_per_step"] * 12 * 1e-3 >= 3.0            # the job did (max over ranks + drain)
+    assert m["slow_rank"] == {"rank": 1, "sleep_s_per_boundary": 3.0}
+    assert m["rows_gathered"] >= 2 * 22 * 12 * 2 and m["bad_records"] == 0     # and nothing was lost: the drain delivered rank 1's games
+    s = _two_ranks(["--slow-rank", "1:3", "--exchange", "sync"])
+    own = [v * 12 * 1e-3 for v in s["multi_gpu"]["rank_step_ms"]]
+    assert own[0] >= 2.5, own                             # the control: the blocking exchange couples the ranks
+
+
+def test_bench_six_ranks_rehearsal_one_gpu():
+    """Six ranks over gloo on the one GPU (a GPU box allows six processes on its card; the world-8 control flow of the exchange is
+    tests/test_cpu_async_exchange.py): every rank seen, rows of all six ranks in every ring, one collective per exchange, no error flag."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "6", "--steps", "40", "--warmup", "2", "--backend", "gloo", "--share-gpu",
+           "--gather-plies", "1024", "--playout", "16", "--boards", "128", "--blocks", "2", "--channels", "256", "--preroll-plies", "12", "--max-plies", "12"]
+    env = _env()
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    j = _json_line(r.stdout)
+    m = j["multi_gpu"]
+    assert j["n_gpus"] == 6 and m["ranks_seen"] == 6 and m["error_flags_any"] == 0 and m["bad_records"] == 0
+    assert m["boards_per_rank"] == [128] * 6 and m["board_id_base_per_rank"] == [128 * r for r in range(6)]
+    # 40 steps of 16-simulation moves: 2-3 move boundaries; every one of them posts, every exchange is ONE collective
+    assert m["exchanges_in_window"] in (2, 3)
+    assert m["exchanges_completed_in_window_and_drain"] == m["collectives_in_window"] + m["collectives_in_drain"] >= 2
+    # per boundary every rank finishes >= 11 games of 12 plies (boards 0, 12, ... at the cap): the ring holds all six ranks' rows
+    assert m["rows_gathered"] >= m["exchanges_in_window"] * 6 * 10 * 12 * 2 and m["replay_rows_total"] >= m["rows_gathered"]
+    assert m["games_gathered"] >= m["exchanges_in_window"] * 6 * 10
+    assert len(m["rank_step_ms"]) == 6 and max(m["exchange_max_call_ms_per_rank"]) < 2000
 
 
 def test_bench_a_rank_that_fails_inside_the_timed_window_ends_the_job_fast():
@@ -131,11 +194,17 @@ def test_bench_two_ranks_with_concurrent_trainer_on_rank0():
     port = _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "16", "--warmup", "2",
-           "--backend", "gloo", "--share-gpu", "--gather-plies", "1024", "--playout", "16", "--train-every", "4"] + SMALL
+           "--backend", "gloo", "--share-gpu", "--gather-plies", "1024", "--playout", "16", "--train-every", "4", "--boards-rank0", "auto"] + SMALL
     r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     j = _json_line(r.stdout)
     assert j["multi_gpu"]["ranks_seen"] == 2 and j["multi_gpu"]["exchanges_in_window"] == 1
+    # rank 0 shares its GPU with the trainer: it calibrated itself a lighter load, the global board ids stay a prefix sum
+    bpr = j["multi_gpu"]["boards_per_rank"]
+    cal = j["rank0_calibration"]
+    assert bpr[0] < bpr[1] == 256 and bpr[0] == cal["boards_rank0"] and bpr[0] % 64 == 0 and j["multi_gpu"]["board_id_base_per_rank"] == [0, bpr[0]]
+    assert cal["plain_rank_ms"] > 0 and len(cal["probes_with_trainer"]) >= 2 and cal["probes_with_trainer"][0]["boards"] == 256
+    assert abs(j["ms_per_step"] * 16 * 1e-3 * j["value"] - sum(bpr) * 16) < 1e-3 * sum(bpr) * 16
     assert j["multi_gpu"]["rows_gathered"] >= 2 * 22 * 12 * 2     # both ranks' finished games reached rank 0's buffer
     assert j["trainer_updates"] == 4                               # one 2048-row update per 4 steps, inside the window
     assert j["multi_gpu"]["ring_ranks"] == "0"                     # with a trainer only its rank expands the records into a dense ring
@@ -159,9 +228,11 @@ def test_bench_single_gpu_line_contract():
     mb = j["move_boundary"]
     assert mb["in_window"] == 1 and mb["games_finished"] >= 22 and mb["rows_harvested_rank0"] >= 22 * 12 * 2
     assert mb["ms_events"] > 0 and mb["ms_host"] > 0 and j["moves_per_sec"] > 0
-    # the headline fraction is THIS run's measurement (HIP events minus the floor); the committed rocprofv3 figure has its own name
-    assert "live" in rf["duration_source"] and rf["avg_launch_us"] > 0 and rf["avg_launch_us_hip_events_raw"] >= rf["avg_launch_us"]
-    assert "frac_at_committed_rocprofv3_duration" in rf and rf["frac_hip_events_raw"] <= rf["frac"]
+    # this small workload is not the profiled one: the fraction is THIS run's raw HIP-event figure (nothing subtracted: a lower bound),
+    # and the line says which code it ran and why the committed profile does not apply
+    assert "RAW HIP events" in rf["duration_source"] and "another workload" in rf["duration_source"]
+    assert rf["avg_launch_us"] == rf["avg_launch_us_hip_events_raw"] > 0 and rf["frac"] == rf["frac_hip_events_raw"]
+    assert len(rf["code_hash"]) == 16 and "profile_head" in rf and rf["live_over_profile"] is None and rf["warning"] is None
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     # the split net / rules / tree of a CPU playout, and the same loop with a constant-time stub evaluator
