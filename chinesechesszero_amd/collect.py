@@ -437,22 +437,18 @@ class CollectPipeline:
                     for chunk in self.selfplay.harvest_chunks(1 << 19):
                         self.sink.append(*chunk, games=done if first else 0)
                         first = False
+            elif hasattr(gatherer, "post"):
+                # asynchronous exchange (replay.AsyncRecordExchange): this rank never waits for its peers -- the finished games join
+                # its backlog, whatever exchange has completed meanwhile is stored; :meth:`drain_exchange` delivers the rest at the end
+                chunks = list(self.selfplay.harvest_record_chunks(gatherer.cap)) if done else []
+                for x in gatherer.post(chunks, games=done):
+                    self._store_union(x.union, x.games, gatherer)
             elif hasattr(gatherer, "_payload"):
                 # compact exchange (replay.RecordGatherer): finished games travel as 880-byte ply records, ONE collective per
                 # move at the benchmark workload; rank 0 rebuilds the dense rows (ccz_expand_records) and stores the union
-                from .engine import expand_records, game_aligned_chunks
                 from .replay import exchange_finished_games
-                e = self.selfplay.engine
                 for union, games in exchange_finished_games(self.selfplay, gatherer, done):
-                    if gatherer.rank == 0:  # the union of the shards goes to ONE store, as N collectors -> one data file
-                        first = True
-                        for part in game_aligned_chunks(union.to(e.device), 1 << 14):  # bounds the dense temporary (2^15 rows = 1 GB)
-                            self.sink.append(*expand_records(part.contiguous(), e.record_flags(), e.plane_of_type), games=games if first else 0)
-                            first = False
-                        if first:
-                            self.sink.append(e.leaf_input[:0], torch.empty((0, 2086)), torch.empty((0,)), games=games)
-                    else:
-                        self.sink.games += games
+                    self._store_union(union, games, gatherer)
             else:
                 # Dense exchange (replay.TupleGatherer, round 2's wire format). Every rank calls gather() the same number of
                 # times: once per move at least (possibly with zero rows), and again while ANY rank still holds harvest chunks.
@@ -478,13 +474,41 @@ class CollectPipeline:
         self.selfplay.engine.check_healthy()
         return self.iters
 
-    def run(self, is_shown=False, max_calls: int = 0):
+    def _store_union(self, union, games: int, gatherer):
+        """Records of ALL ranks' finished games (one exchange): rank 0 rebuilds the dense rows (ccz_expand_records) and appends them
+        to ONE store, as N reference collectors appending to one data file would (collect.py:146-167); the other ranks count the games."""
+        from .engine import expand_records, game_aligned_chunks
+        e = self.selfplay.engine
+        if gatherer.rank == 0:
+            first = True
+            for part in game_aligned_chunks(union.to(e.device), 1 << 14):  # bounds the dense temporary (2^15 rows = 1 GB)
+                self.sink.append(*expand_records(part.contiguous(), e.record_flags(), e.plane_of_type), games=games if first else 0)
+                first = False
+            if first:
+                self.sink.append(e.leaf_input[:0], torch.empty((0, 2086)), torch.empty((0,)), games=games)
+        else:
+            self.sink.games += games
+        self.iters = self.sink.games
+
+    def drain_exchange(self, gatherer):
+        """End of a multi-rank collection with an asynchronous exchange: blocking, every rank calls it; afterwards every record of
+        every rank has reached rank 0's store."""
+        for x in gatherer.flush_iter():
+            self._store_union(x.union, x.games, gatherer)
+        self._maybe_finalize()
+        return self.iters
+
+    def run(self, is_shown=False, max_calls: int = 0, viewer=None):
         """collect.py:178-186: collect until interrupted (``max_calls`` > 0 stops after that many ``collect_data`` calls:
-        games on the single-board path, lockstep moves on the batched one). ``is_shown`` opens the viewer window
-        (reference ``--show``): the single game, or board 0 of the batch."""
+        games on the single-board path, lockstep moves on the batched one). ``is_shown`` (reference ``--show``) pushes the single
+        game, or board 0 of the batch, to ``viewer`` -- anything with ``update_board(svg, status)``; the HTTP window itself is not
+        part of the package (``examples/viewer.py``)."""
         if is_shown and self.n_boards > 1:
-            from .frontend import get_chess_window
-            self._viewer = get_chess_window()
+            if viewer is None:
+                log("--show without a viewer: pass viewer=... (e.g. examples/viewer.py get_chess_window()); nothing is displayed", "WARNING")
+            self._viewer = viewer
+        elif is_shown and viewer is not None and getattr(self, "game", None) is not None:
+            self.game.viewer = viewer   # the one-game-at-a-time loop: Game.graphic pushes every position (game.py:47-75)
         calls = 0
         try:
             while max_calls <= 0 or calls < max_calls:
@@ -512,6 +536,15 @@ if __name__ == "__main__":
     parser.add_argument("--blocks", type=int, default=40)
     parser.add_argument("--seed", type=int, default=0)
     args = parser.parse_args()
+    viewer = None
+    if args.show:   # the window is an example, not part of the package: found when run from a checkout of the repository
+        try:
+            import sys
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            from examples.viewer import get_chess_window
+            viewer = get_chess_window()
+        except Exception as exc:
+            log(f"--show: examples/viewer.py is not importable here ({exc}); running without a window", "WARNING")
     CollectPipeline(init_model=args.model, n_boards=args.boards, n_playout=args.playout, data_dir=args.data_dir, seed=args.seed,
                     num_channels=args.channels, resblocks_num=args.blocks, max_plies=args.max_plies,
-                    eval_cache_log2=args.eval_cache_log2).run(is_shown=args.show, max_calls=args.moves)
+                    eval_cache_log2=args.eval_cache_log2).run(is_shown=args.show, max_calls=args.moves, viewer=viewer)

@@ -743,7 +743,9 @@ __global__ __launch_bounds__(1024) void k_cache_plan(Dev D, int32_t *miss_rows, 
         for (int i = 0; i < 4; ++i) {
             const int b = b0 + i * 1024 + tid;
             rep[i] = b;
-            if (st[i] == 0 && w[i] >= 0 && w[i] < D.B && w[i] != b) {
+            // (w < b: a bidder's claim winner is never above it; a CACHE_VERIFY board did not bid, and must not take the row of a
+            // higher board -- possibly of a later pass, not assigned yet -- on a full 64-bit key collision)
+            if (st[i] == 0 && w[i] >= 0 && w[i] < b) {
                 const bool same = D.cstate[w[i]] == 0 && D.leaf_key[w[i]] == key[i];
                 rep[i] = same ? w[i] : b;
             }

@@ -247,7 +247,7 @@ class Game:
     def __init__(self, board=None, reference_quirks: bool = False, progress=None, viewer=None):
         """``progress(game_index, step, advanced, total, avg_step_seconds)``: the sink the reference feeds its rich progress
         bar from (game.py:162-185), called through ``get_action``'s ``on_playout``. ``viewer``: anything with
-        ``update_board(board_text_or_svg, status_text)`` -- the hook ``graphic`` drives (frontend.py ``ChessWindow``,
+        ``update_board(board_text_or_svg, status_text)`` -- the hook ``graphic`` drives (reference frontend.py ``ChessWindow``; here e.g. ``examples/viewer.py``,
         game.py:47-75); without one ``graphic`` logs the text board."""
         self.board = board if board is not None else Board()
         self.reference_quirks = reference_quirks
@@ -273,12 +273,12 @@ class Game:
 
     def graphic(self, board):
         """game.py:47-75: push the position to the viewer window (status line as the reference formats it); the SVG
-        rendering of ``cchess.svg`` is not part of this build: :func:`frontend.board_svg` draws the position."""
+        rendering of ``cchess.svg`` is not part of this build: :func:`boardsvg.board_svg` draws the position."""
         current_player = "red" if board.turn == RED else "black"
         status_text = f"to move: {current_player} - ply: {len(board.move_stack)}"
         if self.viewer is not None:
             try:
-                from .frontend import board_svg
+                from .boardsvg import board_svg
                 last = board.peek()
                 lm = (int(MOVE_FROM[last.id]), int(MOVE_TO[last.id])) if last is not None else None
                 self.viewer.update_board(board_svg(board.squares(), lm), status_text)

@@ -252,15 +252,31 @@ class InferenceNet(nn.Module):
         """Concurrent launch chains per group (one HIP stream each)."""
         return max(1, min(self.opt.chains or (self.TOWER_CHAINS_EDGE if edge else self.TOWER_CHAINS), 8, -(-B // groups) // 256))
 
+    def derived_parameter_names(self) -> set:
+        """Names (as in ``named_parameters()``) of the parameters that are pure functions of OTHER parameters of this module -- the
+        weights packed for k_conv3x3_g16. ``replay.broadcast_model(what="inference")`` does not send them and :meth:`repack_derived`
+        rebuilds exactly this set: one list for both, so a future packed tensor cannot be skipped by one and forgotten by the other."""
+        names = set()
+        if hasattr(self, "ws_g16"):
+            names |= {f"ws_g16.{i}" for i in range(len(self.ws_g16))}
+        if hasattr(self, "stem_w64_g16"):
+            names.add("stem_w64_g16")
+        return names
+
     @torch.no_grad()
     def repack_derived(self):
         """The tensors derived from others (the weights packed for k_conv3x3_g16) re-derived IN PLACE after the primary ones were
         overwritten (``replay.broadcast_model(what="inference")``): addresses stay what captured graphs hold."""
+        done = set()
         if hasattr(self, "ws_g16"):
-            for dst, w in zip(self.ws_g16, self.ws):
+            for i, (dst, w) in enumerate(zip(self.ws_g16, self.ws)):
                 dst.copy_(pack_conv_weights_g16(w.permute(0, 2, 3, 1)))
+                done.add(f"ws_g16.{i}")
         if hasattr(self, "stem_w64_g16"):
             self.stem_w64_g16.copy_(pack_conv_weights_g16(self.stem_w64))
+            done.add("stem_w64_g16")
+        if done != self.derived_parameter_names():
+            raise RuntimeError(f"repack_derived rebuilt {sorted(done)} but derived_parameter_names() lists {sorted(self.derived_parameter_names())}")
         self.__dict__.pop("_b2", None)
 
     def _epilogue(self, y, bias, residual=None):
@@ -677,11 +693,21 @@ class PolicyValueNet:
         # MIOpen "find" mode: PyTorch's default immediate mode picks the asm implicit-GEMM kernel for the
         # [B,256,10,9] 3x3 convolutions (0.87 ms at B=4096); the find step measures all applicable solvers once
         # per shape and selects the composable-kernel XDL grouped-conv kernel (0.60 ms) -- profiles/miopen_find_r01.txt
+        self._require_current_fp32("refresh_inference_copy")
         self.policy_value_net.eval()
         self._infer = InferenceNet(self.policy_value_net).to(self.device).eval()
         self._graph = None
         self.weights_version += 1
         return self._infer
+
+    def _require_current_fp32(self, what: str):
+        """After ``replay.broadcast_model(what="inference")`` a receiving rank's fp32 ``Net`` still holds its OLD weights (only the
+        fp16 inference copy was overwritten): rebuilding the inference copy from it, saving it or training it would silently revert
+        the reload. Such a rank only evaluates; anything else needs ``broadcast_model(what="state")`` first."""
+        if getattr(self, "_fp32_stale", False):
+            raise RuntimeError(f"{what}: this rank's fp32 net does not hold the weights of the last broadcast_model(what='inference') "
+                               "(only the inference copy was sent): call broadcast_model(what='state') before training, saving or "
+                               "rebuilding the inference copy here")
 
     @torch.no_grad()
     def evaluate_leaves(self, leaf_input: torch.Tensor):
@@ -748,6 +774,7 @@ class PolicyValueNet:
         return zip(legal_positions, act_probs[legal_positions]), value.float().cpu().numpy()
 
     def save_model(self, model_file):
+        self._require_current_fp32("save_model")
         torch.save(self.policy_value_net.state_dict(), model_file)
 
     def train_step(self, state_batch, mcts_probs, winner_batch, lr=0.002):

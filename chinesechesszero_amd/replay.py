@@ -653,8 +653,11 @@ def broadcast_model(policy_value_net, src: int = 0, group=None, what: str = "sta
         if getattr(policy_value_net, "_infer", None) is None:
             policy_value_net.refresh_inference_copy()
         inf = policy_value_net._infer
-        derived = {n for n, _ in inf.named_parameters() if "g16" in n}   # packed copies: re-derived locally, not sent
-        tensors = [p.data for n, p in inf.named_parameters() if n not in derived]
+        derived = inf.derived_parameter_names()   # packed copies: re-derived locally (InferenceNet.repack_derived rebuilds this very set), not sent
+        named = dict(inf.named_parameters())
+        if not derived <= set(named):
+            raise RuntimeError(f"InferenceNet.derived_parameter_names() lists unknown parameters: {sorted(derived - set(named))}")
+        tensors = [p.data for n, p in named.items() if n not in derived]
     if multi and tensors:
         dev = tensors[0].device
         if dist.get_backend(group) == "gloo":
@@ -669,12 +672,15 @@ def broadcast_model(policy_value_net, src: int = 0, group=None, what: str = "sta
                 for t, (o, nb) in zip(tensors, spans):
                     t.copy_(flat[o:o + nb].view(t.dtype).view(t.shape))
     if what == "state":
+        policy_value_net._fp32_stale = False
         if hasattr(policy_value_net, "refresh_inference_copy"):
             policy_value_net.refresh_inference_copy()
     else:
         inf = policy_value_net._infer
         if multi and rank != src:
             inf.repack_derived()
+            # the receiver's fp32 net was NOT sent: refresh_inference_copy / save_model / training from it would revert the reload
+            policy_value_net._fp32_stale = True
         policy_value_net._graph = None
         policy_value_net.weights_version += 1
     return policy_value_net

@@ -209,14 +209,14 @@ class BatchedSelfPlay:
         return self.advance(self.n_playout - self._sim, on_playout=on_playout)
 
     def watch(self, board_index: int, viewer):
-        """Show ONE selected board of the batch in a viewer window (``frontend.ChessWindow`` or anything with
+        """Show ONE selected board of the batch in a viewer (``examples/viewer.py``'s ``ChessWindow`` or anything with
         ``update_board(svg, status)``): its position is pushed after every move (one small device read per move; nothing is
         read when no board is watched). The batched counterpart of ``Game.graphic`` (reference game.py:47-75)."""
         self._watch = (int(board_index), viewer)
 
     def _show(self, moves):
         b, viewer = self._watch
-        from .frontend import board_svg
+        from .boardsvg import board_svg
         from .tools import MOVE_FROM, MOVE_TO
         sq = self.engine.root_positions()[b]
         st = self.engine.game_status()

@@ -85,27 +85,33 @@ def rule_presets() -> dict:
     }
 
 
-def load_preset_file(path: str) -> dict:
+def load_preset_file(path: str, allow_unsupported: bool = False) -> dict:
     """A ``preset.json`` written by ``tools/probe_cchess.py`` (the rule choices of a REAL ``cchess`` module, probed where the
-    reference runs) as the entries :func:`set_rules` takes. Refuses a file whose probe found behaviours this build cannot express
-    unless they are acknowledged by editing the file (``"unsupported_differences": []``): parity would be claimed falsely."""
+    reference runs) as the entries :func:`set_rules` takes. REFUSES (``ValueError``) a file whose probe found behaviours this
+    build cannot express -- installing it would claim a parity that does not hold -- unless the caller says
+    ``allow_unsupported=True`` (the differences are then logged as a WARNING)."""
     import json
     with open(path) as f:
         p = json.load(f)
     if p.get("schema") != 1:
         raise ValueError(f"{path}: not a schema-1 rule preset")
     if p.get("unsupported_differences"):
-        log(f"rule preset {path}: the probed cchess differs from this build in ways no table expresses: {p['unsupported_differences']}", "WARNING")
+        msg = f"rule preset {path}: the probed cchess differs from this build in ways no table expresses: {p['unsupported_differences']}"
+        if not allow_unsupported:
+            raise ValueError(msg + " -- pass allow_unsupported=True to install the expressible part anyway")
+        log(msg, "WARNING")
     mr = p.get("move_rank")
     return dict(move_rank=None if mr is None else np.asarray(mr, np.uint16), plane_of_type=tuple(p["plane_of_type"]),
                 type_rank=None if p.get("type_rank") is None else tuple(p["type_rank"]),
                 pawn_move_resets_clock=bool(p.get("pawn_move_resets_clock")), perpetual_check=bool(p.get("perpetual_check")))
 
 
-def set_rules(move_rank=None, plane_of_type=None, type_rank=None, pawn_move_resets_clock=False, perpetual_check=False, preset=None):
+def set_rules(move_rank=None, plane_of_type=None, type_rank=None, pawn_move_resets_clock=False, perpetual_check=False, preset=None,
+              allow_unsupported: bool = False):
     """Install the rule profile of the process. Every call sets ALL choices: what is omitted returns to this build's
-    default (``set_rules()`` restores them all). ``preset``: a name from :func:`rule_presets` (explicit arguments override its
-    entries). Boards cache their legal-move list: change the profile between games."""
+    default (``set_rules()`` restores them all). ``preset``: a name from :func:`rule_presets`, or the path of a ``preset.json``
+    written by ``tools/probe_cchess.py`` (refused if the probe found behaviours no table expresses, unless ``allow_unsupported``);
+    explicit arguments override its entries. Boards cache their legal-move list: change the profile between games."""
     global MOVE_RANK, PLANE_OF_TYPE, TYPE_RANK, PAWN_MOVE_RESETS_CLOCK, PERPETUAL_CHECK, PRESET
     explicit = any(x is not None for x in (move_rank, plane_of_type, type_rank)) or pawn_move_resets_clock or perpetual_check
     if preset is not None:
@@ -113,7 +119,7 @@ def set_rules(move_rank=None, plane_of_type=None, type_rank=None, pawn_move_rese
         if preset in table:
             p = table[preset]
         elif isinstance(preset, str) and preset.endswith(".json"):
-            p = load_preset_file(preset)   # what tools/probe_cchess.py wrote after asking a real cchess module
+            p = load_preset_file(preset, allow_unsupported)   # what tools/probe_cchess.py wrote after asking a real cchess module
         else:
             raise ValueError(f"unknown rule preset {preset!r}: one of {sorted(table)} or the path of a preset.json written by tools/probe_cchess.py")
         move_rank = p.get("move_rank") if move_rank is None else move_rank

@@ -19,6 +19,21 @@ def _ensure_built():
         __graft_entry__.build()
 
 
+def pytest_addoption(parser):
+    parser.addoption("--rules-probe", default=None, metavar="DIR",
+                     help="directory written by tools/probe_cchess.py where a real `cchess` is installed (preset.json + cchess_golden.npz): "
+                          "tests/test_gpu_rules_probe.py then answers 'does the engine match MY cchess' on the GPU "
+                          "(default: the probe is run against the CPU oracle posing as cchess)")
+
+
+@pytest.fixture(scope="session")
+def rules_probe_dir(request):
+    d = request.config.getoption("--rules-probe")
+    if d is not None and not (os.path.exists(os.path.join(d, "preset.json")) and os.path.exists(os.path.join(d, "cchess_golden.npz"))):
+        raise pytest.UsageError(f"--rules-probe {d}: preset.json / cchess_golden.npz not found (run tools/probe_cchess.py --out {d})")
+    return d
+
+
 def pytest_configure(config):
     _ensure_built()
     if os.environ.get("CCZ_LIB"):  # run the suite against a diagnostic build (build/diag/libcczero_bounds.so: `make bounds`)

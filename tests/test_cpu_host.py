@@ -212,10 +212,11 @@ def test_no_diagnostic_library_travels_with_the_product():
 
 
 def test_viewer_window_serves_the_selected_board():
-    """frontend.ChessWindow: update_board(svg, status) then GET /board returns the reference's JSON keys (frontend.py:120-136)."""
+    """examples/viewer.py ChessWindow behind the hook (boardsvg.board_svg renders): update_board(svg, status) then GET /board returns the reference's JSON keys (frontend.py:120-136)."""
     import json
     import urllib.request
-    from chinesechesszero_amd.frontend import ChessWindow, board_svg
+    from chinesechesszero_amd.boardsvg import board_svg
+    from examples.viewer import ChessWindow
     sq = np.zeros(90, np.uint8)
     sq[4], sq[85], sq[0] = 7, 15, 3
     svg = board_svg(sq, last_move=(0, 9))

@@ -164,7 +164,21 @@ def _bcast_worker(rank, world, port, what, q):
         dig = float(sum(p.double().abs().sum() for p in inf.parameters()))
         g16 = float(sum(p.double().abs().sum() for n, p in inf.named_parameters() if "g16" in n))
         same_addr = addr == [p.data_ptr() for p in inf.parameters()]
-        q.put((rank, True, len(calls), dig, g16, same_addr, pvn.weights_version > v0))
+        # the packed copies are exactly what InferenceNet says it derives (one list for the sender's skip and the receiver's rebuild)
+        assert {n for n, _ in inf.named_parameters() if "g16" in n} == inf.derived_parameter_names()
+        # after an inference-only reload a RECEIVER's fp32 net is stale: rebuilding the copy from it or saving it is refused
+        guarded = None
+        if what == "inference":
+            guarded = []
+            for call in (pvn.refresh_inference_copy, lambda: pvn.save_model(os.devnull)):
+                try:
+                    call()
+                    guarded.append(False)
+                except RuntimeError as e:
+                    guarded.append("broadcast_model(what='state')" in str(e))
+            replay.broadcast_model(pvn, src=0, what="state")     # ... until the state itself is sent
+            pvn.save_model(os.devnull)
+        q.put((rank, True, len(calls), dig, g16, same_addr, pvn.weights_version > v0, guarded))
         dist.barrier()
         dist.destroy_process_group()
     except Exception:
@@ -192,3 +206,4 @@ def test_weight_broadcast_is_one_collective_of_one_flat_buffer(what):
     assert all(r[6] for r in res)                              # weights_version moved: evaluation caches keyed to it are emptied
     if what == "inference":
         assert res[1][5]                                       # in place: what captured hipGraphs point at is still valid
+        assert res[1][7] == [True, True] and res[0][7] == [False, False]   # the receiver is guarded, the source (whose fp32 IS the truth) is not

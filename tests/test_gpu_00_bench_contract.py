@@ -64,8 +64,9 @@ def test_bench_starts_its_own_ranks_and_exchanges_inside_the_timed_window(exchan
     if exchange == "sync":
         assert m["collectives_in_window"] == 1 and m["gather_ms"] > 0      # ONE blocking collective at the boundary
     else:
-        # the boundary's records travel in a collective issued by a later step (or by the drain); the drain adds the closing one(s)
-        assert m["collectives_in_window"] + m["collectives_in_drain"] >= 2 and m["collectives_in_window"] <= 2
+        # the boundary's records travel in ONE collective issued by a later step -- or, when the K steps end first, by the drain (whose
+        # first exchange then carries them with the closing flag up); the drain never needs more than two
+        assert 1 <= m["collectives_in_window"] + m["collectives_in_drain"] <= 3 and m["collectives_in_window"] <= 1
         assert m["exchanges_completed_in_window_and_drain"] == m["collectives_in_window"] + m["collectives_in_drain"]
         assert m["exchange_host_ms_rank0"] >= 0 and len(m["exchange_max_call_ms_per_rank"]) == 2
         assert m["plies_sent_rank0"] == j["move_boundary"]["rows_harvested_rank0"] // 2
@@ -111,10 +112,13 @@ def test_bench_a_slow_rank_delays_data_not_its_peer():
     assert own[0] >= 2.5, own                             # the control: the blocking exchange couples the ranks
 
 
-def test_bench_six_ranks_rehearsal_one_gpu():
-    """Six ranks over gloo on the one GPU (a GPU box allows six processes on its card; the world-8 control flow of the exchange is
-    tests/test_cpu_async_exchange.py): every rank seen, rows of all six ranks in every ring, one collective per exchange, no error flag."""
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "6", "--steps", "40", "--warmup", "2", "--backend", "gloo", "--share-gpu",
+def test_bench_four_ranks_rehearsal_one_gpu():
+    """Four ranks over gloo on the one GPU. (Eight cannot be rehearsed on a GPU box: its process guard allows six processes on the
+    card, and a first attempt with six ranks was killed at seven -- the ranks plus one launcher-side process. The world-8 control flow
+    of the exchange -- uneven loads, an empty rank, an aborting rank -- is tests/test_cpu_async_exchange.py.) Every rank seen, rows of
+    all four ranks in every ring, one collective per exchange, no error flag."""
+    R = 4
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(R), "--steps", "40", "--warmup", "2", "--backend", "gloo", "--share-gpu",
            "--gather-plies", "1024", "--playout", "16", "--boards", "128", "--blocks", "2", "--channels", "256", "--preroll-plies", "12", "--max-plies", "12"]
     env = _env()
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
@@ -123,15 +127,15 @@ def test_bench_six_ranks_rehearsal_one_gpu():
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     j = _json_line(r.stdout)
     m = j["multi_gpu"]
-    assert j["n_gpus"] == 6 and m["ranks_seen"] == 6 and m["error_flags_any"] == 0 and m["bad_records"] == 0
-    assert m["boards_per_rank"] == [128] * 6 and m["board_id_base_per_rank"] == [128 * r for r in range(6)]
+    assert j["n_gpus"] == R and m["ranks_seen"] == R and m["error_flags_any"] == 0 and m["bad_records"] == 0
+    assert m["boards_per_rank"] == [128] * R and m["board_id_base_per_rank"] == [128 * r for r in range(R)]
     # 40 steps of 16-simulation moves: 2-3 move boundaries; every one of them posts, every exchange is ONE collective
     assert m["exchanges_in_window"] in (2, 3)
-    assert m["exchanges_completed_in_window_and_drain"] == m["collectives_in_window"] + m["collectives_in_drain"] >= 2
-    # per boundary every rank finishes >= 11 games of 12 plies (boards 0, 12, ... at the cap): the ring holds all six ranks' rows
-    assert m["rows_gathered"] >= m["exchanges_in_window"] * 6 * 10 * 12 * 2 and m["replay_rows_total"] >= m["rows_gathered"]
-    assert m["games_gathered"] >= m["exchanges_in_window"] * 6 * 10
-    assert len(m["rank_step_ms"]) == 6 and max(m["exchange_max_call_ms_per_rank"]) < 2000
+    assert m["exchanges_completed_in_window_and_drain"] == m["collectives_in_window"] + m["collectives_in_drain"] >= 1
+    # per boundary every rank finishes >= 10 games of 12 plies (boards 0, 12, ... at the cap): the ring holds all ranks' rows
+    assert m["rows_gathered"] >= m["exchanges_in_window"] * R * 10 * 12 * 2 and m["replay_rows_total"] >= m["rows_gathered"]
+    assert m["games_gathered"] >= m["exchanges_in_window"] * R * 10
+    assert len(m["rank_step_ms"]) == R and max(m["exchange_max_call_ms_per_rank"]) < 2000
 
 
 def test_bench_a_rank_that_fails_inside_the_timed_window_ends_the_job_fast():

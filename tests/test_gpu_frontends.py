@@ -93,8 +93,8 @@ def test_inference_net_fp16_fused_epilogue_matches_fp32_reference_architecture()
 
 
 def test_viewer_hook_shows_one_selected_board_of_the_batch_and_the_single_board_game():
-    """SURVEY 8f row 3, second half: Game.graphic / frontend viewer hook-up (reference game.py:47-75, frontend.py:328)."""
-    from chinesechesszero_amd.frontend import ChessWindow
+    """SURVEY 8f row 3, second half: Game.graphic / BatchedSelfPlay.watch viewer hook-up (reference game.py:47-75, frontend.py:328)."""
+    from examples.viewer import ChessWindow
     from chinesechesszero_amd.game import Board, Game
     from chinesechesszero_amd.mcts import MCTS_AI
     from chinesechesszero_amd.net import uniform_evaluator

@@ -1,5 +1,6 @@
 """GPU: the host mirror of the reference call surface (tools / mcts / game / collect) on the HIP engine."""
 import numpy as np
+import torch
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -131,6 +132,29 @@ def test_collect_pipeline_batched_writes_trainer_format(tmp_path):
     assert states.shape[0] == 16 * 5 * 2  # every board was adjudicated at 5 plies once, mirrored
     assert np.allclose(pi.sum(1), 1.0, atol=1e-4)
     assert cp.iters == 16
+
+
+def test_collect_pipeline_batched_through_the_async_exchange_stores_the_same_rows(tmp_path):
+    """collect_batched with replay.AsyncRecordExchange (a group of one here: the backlog is handed straight over): finished games
+    leave as compact records, are expanded and stored -- the same files, byte for byte, as the direct dense harvest."""
+    from chinesechesszero_amd.collect import CollectPipeline
+    from chinesechesszero_amd.replay import AsyncRecordExchange
+    from chinesechesszero_amd.selfplay import BatchedSelfPlay
+    out = {}
+    for name in ("direct", "exchange"):
+        d = tmp_path / name
+        cp = CollectPipeline(init_model=None, n_boards=16, n_playout=4, data_dir=str(d), num_channels=16, resblocks_num=1)
+        torch.manual_seed(4)
+        cp.load_model()
+        cp.selfplay = BatchedSelfPlay(cp.policy_value_net.evaluate_leaves, 16, n_playout=4, max_plies=5, seed=2)
+        ex = AsyncRecordExchange(64, "cuda:0") if name == "exchange" else None
+        cp.collect_batched(13, gatherer=ex)
+        if ex is not None:
+            assert cp.drain_exchange(ex) == 32 and ex.issued == ex.completed >= 2
+        assert cp.sink.finalize() == 16 * 5 * 2 * 2 and cp.iters == 32           # two adjudicated games per board
+        out[name] = [np.load(d / f) for f in ("states.npy", "mcts.npy", "winners.npy")]
+    for a, b in zip(out["direct"], out["exchange"]):
+        assert a.dtype == b.dtype and np.array_equal(a, b)
 
 
 def test_start_play_two_players_two_engines():

@@ -261,6 +261,29 @@ def test_probe_reports_what_no_table_can_express():
     assert "no legal move without check" in text and "is_fourfold_repetition()" in text
 
 
+def test_a_preset_with_unsupported_differences_is_refused_unless_acknowledged(tmp_path):
+    """installing a preset whose probe found behaviours no table expresses would claim a parity that does not hold.
+    The checker's loader refuses it; ``allow_unsupported=True`` installs the expressible part. (The product's twin,
+    tools.set_rules(preset=...), shares the rule: tests/test_gpu_rules_probe.py.)"""
+    p = {"schema": 1, "plane_of_type": [0, 0, 1, 2, 3, 4, 5, 6], "type_rank": None, "move_rank": None, "pawn_move_resets_clock": False,
+         "perpetual_check": True, "unsupported_differences": ["no legal move without check is a draw in cchess"]}
+    path = tmp_path / "preset.json"
+    path.write_text(json.dumps(p))
+    with pytest.raises(ValueError, match="no table expresses"):
+        oracle.set_rules_from_file(str(path))
+    try:
+        got = oracle.set_rules_from_file(str(path), allow_unsupported=True)
+        assert got["perpetual_check"] is True
+    finally:
+        oracle.set_rules()
+    p["unsupported_differences"] = []
+    path.write_text(json.dumps(p))
+    try:
+        oracle.set_rules_from_file(str(path))
+    finally:
+        oracle.set_rules()
+
+
 def test_perpetual_check_yields_to_the_sixty_move_draw_at_the_same_ply():
     """Order of the reference's checks (game.py:208-214): insufficient material, sixty moves, then repetition. A perpetual-check
     repetition that completes at the ply the clock reaches 120 is a draw; eight plies of clock earlier the checker loses."""
