@@ -233,52 +233,6 @@ def committed_profile(path: str, head: str, workload: dict):
     return pm, None, ph
 
 
-def calibrate_rank0_boards(pvn, train_once, boards: int, train_every: int, dev, lo: int = 64, quantum: int = 64, periods: int = 3):
-    """How many boards can rank 0 carry NEXT TO the trainer at the pace of a plain rank? Measured, not modelled: the evaluator (98 %
-    of a step) on synthetic leaf rows, alone on ``boards`` rows (= a plain rank's step), then on b rows with one trainer update
-    per ``train_every`` evaluations on the side stream (the window's cadence); b is moved by secant steps until its time meets the
-    plain one. Untimed set-up, ~3 s. The trainer may be heavier than a whole plain step: then b ends at ``lo`` and says so."""
-    g = torch.Generator(device=dev).manual_seed(3)
-    leaf_all = (torch.rand((boards, 17, 7, 10, 9), device=dev, generator=g) > 0.9).half()
-    q = lambda b: int(max(lo, min(boards, quantum * round(b / quantum))))
-
-    def probe(b, with_trainer):
-        leaf = leaf_all[:b]
-        for _ in range(2):
-            pvn.evaluate_leaves_logits(leaf)         # (first call at a new batch shape: workspace, path decision)
-        if with_trainer:
-            train_once()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(periods * train_every):
-            pvn.evaluate_leaves_logits(leaf)
-            if with_trainer and (i + 1) % train_every == 0:
-                train_once()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / (periods * train_every)
-
-    t_plain = probe(boards, False)
-    t_with = probe(boards, True)
-    pts = [(boards, t_with)]
-    b = q(boards * max(0.0, 2.0 * t_plain - t_with) / t_plain)   # first guess: the trainer adds a constant per step
-    for _ in range(4):
-        if any(p[0] == b for p in pts):
-            break
-        pts.append((b, probe(b, True)))
-        (b1, t1), (b2, t2) = pts[-2], pts[-1]
-        if abs(t2 - t_plain) <= 0.02 * t_plain or b1 == b2 or t1 == t2:
-            break
-        b = q(b2 + (t_plain - t2) * (b1 - b2) / (t1 - t2))
-    ok = [p for p in pts if p[1] <= 1.03 * t_plain]
-    best = max(ok)[0] if ok else min(pts)[0]
-    del leaf_all
-    torch.cuda.empty_cache()
-    return {"boards_rank0": best, "plain_rank_ms": 1e3 * t_plain, "trainer_bound": not ok,
-            "probes_with_trainer": [{"boards": p[0], "ms": 1e3 * p[1]} for p in pts],
-            "what": f"evaluator on synthetic rows, {periods * train_every} evaluations per probe, one trainer update (batch 2048) per {train_every} on "
-                    "the side stream; plain_rank_ms = the evaluator alone on --boards rows"}
-
-
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -356,39 +310,23 @@ def main():
                 trainer.step(*rb.sample(2048), sync=False)
                 side_done.record(side)
 
-    # ---- boards per rank. All ranks hold --boards boards except, on request, rank 0 (the rank that shares its GPU with the trainer):
-    # with ``auto`` rank 0 measures, before anything else runs, how many rows its evaluator gets through per step NEXT TO the
-    # trainer in the time a plain rank needs for --boards rows, and takes that many boards. Global board ids are a prefix sum.
-    boards_rank0, calibration = None, None
-    if a.boards_rank0:
-        if a.boards_rank0 == "auto":
-            if a.train_every <= 0 or a.evaluator != "net":
-                raise SystemExit("--boards-rank0 auto balances rank 0 against its trainer: it needs --train-every and the real evaluator")
-            t = torch.zeros(1, dtype=torch.int64, device=xdev)
-            if rank == 0:
-                calibration = calibrate_rank0_boards(pvn, train_once, a.boards, a.train_every, dev)
-                t[0] = calibration["boards_rank0"]
-            if world > 1:
-                dist.broadcast(t, src=0)
-            boards_rank0 = int(t.item())
-        else:
-            boards_rank0 = int(a.boards_rank0)
-    counts, bases = launch.board_partition(world, a.boards, boards_rank0)
-    B = counts[rank]
     mul = 2   # dense rows per ply record (the sample and its mirror image, collect.py:112-131)
-
-    sp = BatchedSelfPlay(evaluator, B, n_playout=n, seed=0, board_id_base=bases[rank], device=local_rank,
-                         sampling="device", max_plies=a.max_plies, value_f16=a.value_f16,
-                         eval_cache_log2=a.eval_cache_log2 if a.evaluator == "net" else 0, cache_verify=a.cache_verify)
-    e = sp.engine
-    mul = 2 if e.mirror else 1
+    max_plies_eff = a.max_plies if a.max_plies > 0 else 2048
     gather = ex = None
     if world > 1:
         if a.exchange == "sync":
-            gather = RecordGatherer(max(a.gather_plies, e.max_plies), xdev)
+            gather = RecordGatherer(max(a.gather_plies, max_plies_eff), xdev)
         else:
-            ex = AsyncRecordExchange(max(a.gather_plies, e.max_plies), xdev, timeout_s=a.dist_timeout)
+            ex = AsyncRecordExchange(max(a.gather_plies, max_plies_eff), xdev, timeout_s=a.dist_timeout)
     slow_rank, slow_s = (int(a.slow_rank.split(":")[0]), float(a.slow_rank.split(":")[1])) if a.slow_rank else (-1, 0.0)
+    sp = e = None              # this rank's engine: made by make_engine() below, once the rank's board count is known
+    calibrating = [False]      # rank 0 measuring itself for --boards-rank0 auto: finished games are dropped, not exchanged
+    trainer_on = [True]
+
+    def make_engine(boards, base):
+        return BatchedSelfPlay(evaluator, boards, n_playout=n, seed=0, board_id_base=base, device=local_rank,
+                               sampling="device", max_plies=a.max_plies, value_f16=a.value_f16,
+                               eval_cache_log2=a.eval_cache_log2 if a.evaluator == "net" else 0, cache_verify=a.cache_verify)
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     boundary = {"events": [], "host_s": 0.0, "n": 0, "rows": 0, "rows_local": 0, "games": 0, "gather_s": 0.0, "collectives": 0, "expand_s": 0.0,
@@ -431,7 +369,11 @@ def main():
         if timed and rank == slow_rank:   # testing: this rank falls behind at its move boundary (--slow-rank)
             time.sleep(slow_s)
             boundary["slept_s"] += slow_s
-        if ex is not None:
+        if calibrating[0]:
+            rows = loc = 0
+            for _ in (e.harvest_record_chunks(1 << 16) if done else ()):
+                pass               # (a calibration run's games belong to no job: harvested so that the boards restart, then dropped)
+        elif ex is not None:
             # no rank waits for another one here: the records join this rank's backlog, the rank announces the next exchange, and
             # whatever exchange has completed meanwhile is expanded into the ring (replay.AsyncRecordExchange)
             chunks = list(sp.harvest_record_chunks(ex.cap)) if done else []
@@ -456,13 +398,13 @@ def main():
                     # the dense rows of ALL ranks' games rebuilt in this rank's replay ring (k_expand_records, asynchronous)
                     rows += rb.append_records(union.to(dev, non_blocking=True), e.record_flags(), e.plane_of_type, bad=bad_records)
                 else:
-                    rows += (2 if e.mirror else 1) * int(union.shape[0])   # received, not expanded: this rank consumes no rows
+                    rows += mul * int(union.shape[0])   # received, not expanded: this rank consumes no rows
                 if timed:
                     boundary["gather_s"] += gather.seconds
                     boundary["collectives"] += gather.collectives
                     boundary["games"] += games
                     boundary["expand_s"] += time.perf_counter() - g1
-                loc += (2 if e.mirror else 1) * gather.rows_per_rank[gather.rank]
+                loc += mul * gather.rows_per_rank[gather.rank]
         if timed:
             m1.record()
             torch.cuda.synchronize()
@@ -498,9 +440,9 @@ def main():
             if a.inject_fault and a.inject_fault == f"{rank}:{len(trace)}":
                 raise RuntimeError(f"injected fault on rank {rank} at timed step {len(trace)} (--inject-fault)")
         step_no[0] += 1
-        if ex is not None:
+        if ex is not None and not calibrating[0]:
             consume(ex.tick())   # a host-side check (nearly always nothing): issue the all-gather once every rank announced it, pick up a finished one
-        if trainer is not None and step_no[0] % a.train_every == 0:
+        if trainer is not None and trainer_on[0] and step_no[0] % a.train_every == 0:
             train_once()
             train_steps[0] += 1 if timing[0] else 0  # updates inside the timed window
 
@@ -511,24 +453,86 @@ def main():
         sp.advance(steps, hooks=hooks, boundary=per_move)
         timing[0] = False
 
+    def timed_steps(k):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(k, False)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / k
+
+    def board_states_and_trees():
+        """Steady-state board states (preroll) and, with the real evaluator, whole searched moves (trees, games, evaluation cache)."""
+        if a.preroll_plies > 0:
+            preroll(e, a.preroll_plies, stagger=True)
+        if a.evaluator == "net":
+            run(a.warm_moves * n, False)   # whole moves, boundaries included: trees, games and the evaluation cache in steady state
+
+    # ---- boards per rank. All ranks hold --boards boards except, on request, rank 0 (the rank that shares its GPU with the trainer).
+    # ``auto``: rank 0 measures ITSELF on the real workload -- a full engine of --boards boards brought to the steady state, then a
+    # few trainer periods of real steps without and with the trainer -- and takes the board count at which its step NEXT TO the
+    # trainer costs what a plain rank's step costs (the trainer adds a constant per step: measured, profiles/r05_*). The full engine
+    # is then dropped and rank 0 builds the one it runs with. Global board ids are a prefix sum over the final counts.
+    t_setup = time.perf_counter()
+    boards_rank0, calibration = None, None
+    if a.boards_rank0 == "auto":
+        if a.train_every <= 0 or a.evaluator != "net":
+            raise SystemExit("--boards-rank0 auto balances rank 0 against its trainer: it needs --train-every and the real evaluator")
+        t = torch.zeros(1, dtype=torch.int64, device=xdev)
+        if rank == 0:
+            sp = make_engine(a.boards, 0)
+            e = sp.engine
+            calibrating[0] = True
+            board_states_and_trees()
+            periods = 3
+            trainer_on[0] = False
+            t_plain = timed_steps(periods * a.train_every)
+            trainer_on[0] = True
+            train_once()
+            t_with = timed_steps(periods * a.train_every)
+            calibrating[0] = False
+            c = max(0.0, t_with - t_plain)                       # what the trainer adds to a step, whatever the board count
+            b0 = a.boards * max(0.0, t_plain - c) / t_plain
+            q = 64
+            b0q = int(max(q, min(a.boards, q * int(b0 // q))))
+            calibration = {"boards_rank0": b0q, "plain_step_ms": 1e3 * t_plain, "step_ms_with_trainer_at_full_boards": 1e3 * t_with,
+                           "trainer_ms_per_step": 1e3 * c, "trainer_bound": b0 < q,
+                           "what": f"rank 0, real workload ({a.boards} boards in steady state, {a.warm_moves} searched moves): {periods * a.train_every} steps without "
+                                   f"and {periods * a.train_every} with the trainer (one update of batch 2048 per {a.train_every} steps, side stream); boards_rank0 = "
+                                   "boards x (plain - trainer) / plain, rounded down to 64 (at least 64: trainer_bound says when even that is too many)"}
+            t[0] = b0q
+            if b0q != a.boards:
+                e.close()
+                sp = e = None
+                torch.cuda.empty_cache()
+        if world > 1:
+            dist.broadcast(t, src=0)
+        boards_rank0 = int(t.item())
+    elif a.boards_rank0:
+        boards_rank0 = int(a.boards_rank0)
+    counts, bases = launch.board_partition(world, a.boards, boards_rank0)
+    B = counts[rank]
+
     # ---- untimed setup: steady-state board states, trees warmed with the REAL evaluator up to the point where the
     # timed window starts, so that the K timed steps straddle a real move boundary of every board (the end of one
     # move's search, k_finish_move + harvest + restart [+ all-gather], the start of the next move on the kept subtree)
-    t_setup = time.perf_counter()
-    if a.preroll_plies > 0:
-        preroll(e, a.preroll_plies, stagger=True)
-    if a.evaluator == "net":
-        run(a.warm_moves * n, False)   # whole moves, boundaries included: trees, games and the evaluation cache in steady state
+    if sp is None:
+        sp = make_engine(B, bases[rank])
+        e = sp.engine
+        board_states_and_trees()
     st_pre = e.game_status()
     half = min(a.steps, n) // 2
     phase = (n - half - a.warmup) % n if a.align else 0
+    to_go = (phase - sp._sim) % n             # (a calibration engine that was kept stands a few steps into its move)
     if a.align_evaluator == "stub" and a.evaluator == "net":
         real = (sp.evaluator, sp.planned)     # (the pending leaf does not care which evaluator answers it)
         sp.evaluator, sp.planned = uniform_evaluator, False
-        run(phase, False)
+        run(to_go, False)
         sp.evaluator, sp.planned = real
     else:
-        run(phase, False)
+        if calibration is not None and to_go >= 2 * a.train_every:
+            calibration["step_ms_with_trainer_at_boards_rank0"] = 1e3 * timed_steps(to_go)   # the balance reached, on the engine that runs
+        else:
+            run(to_go, False)
     assert sp._sim == phase % n
     setup_s = time.perf_counter() - t_setup
 

@@ -86,7 +86,7 @@ def test_engine_kernels_replay_the_probe(probe_files):
     ``legal_moves`` order. over = is_game_over() or is_tie() (game.py:208); winner as game.py:210-219."""
     import oracle
     from fake_cchess import parse_fen
-    from chinesechesszero_amd import tools
+    from chinesechesszero_amd import _lib, tools
     from chinesechesszero_amd.engine import SelfPlayEngine
     preset, golden, real = probe_files
     tools.set_rules(preset=preset)
@@ -111,6 +111,9 @@ def test_engine_kernels_replay_the_probe(probe_files):
                 e.finish_move(forced_moves=forced, keep_tree=False)
             st = e.game_status()
             pos = e.root_positions()
+            # after k_finish_move the game status says whether the game is over; a position that was SET (no move played yet) is
+            # judged where the search meets it: the root is its own leaf, terminal by the same predicates (mcts.py:116-126)
+            judged_by_search = n_moves == 0
             live = [b for b in range(len(js)) if not st["over"][b]]
             if live:
                 e.select_leaves()      # a fresh root is its own leaf: the selection kernel's movegen lists its legal moves in order
@@ -119,14 +122,22 @@ def test_engine_kernels_replay_the_probe(probe_files):
                 label = meta[j]["label"]
                 fl = g["flags"][j].tolist()
                 want_over = any(x > 0 for x in fl)
-                assert bool(st["over"][b]) == want_over, (label, fl, meta[j]["moves"][-3:])
+                gw = int(g["winner"][j])
                 assert np.array_equal(pos[b][:90], g["squares"][j]), label
-                if want_over:
-                    ended += 1
-                    gw = int(g["winner"][j])
-                    want_w = gw if (fl[0] > 0 and gw != -2) else -1          # a tie that is not game-over is a draw (game.py:208-219)
-                    assert int(st["winner"][b]) == want_w, (label, fl, gw)
+                if judged_by_search:
+                    if want_over:      # LEAF_LOSS: the side to move has lost (mate and stalemate alike); LEAF_DRAW: a tie
+                        lost = fl[0] > 0 and gw in (0, 1) and gw != int(g["turn"][j])
+                        assert int(info["status"][b]) == (_lib.LEAF_LOSS if lost else _lib.LEAF_DRAW), (label, fl, gw)
+                        ended += 1
+                    else:
+                        assert int(info["status"][b]) == _lib.LEAF_EXPAND, (label, fl)
                 else:
+                    assert bool(st["over"][b]) == want_over, (label, fl, meta[j]["moves"][-3:])
+                    if want_over:
+                        ended += 1
+                        want_w = gw if (fl[0] > 0 and gw != -2) else -1          # a tie that is not game-over is a draw (game.py:208-219)
+                        assert int(st["winner"][b]) == want_w, (label, fl, gw)
+                if not want_over:
                     assert int(st["turn"][b]) == int(g["turn"][j]), label
                     k = int(g["k"][j])
                     assert int(info["k"][b]) == k and info["ids"][b][:k].tolist() == g["ids"][j][:k].tolist(), label
