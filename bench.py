@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--boards-rank0", default="", help="N>1 with --train-every: boards of rank 0, the rank that shares its GPU with the trainer "
                     "(a number, or 'auto' = calibrated before the window so that rank 0's step with the trainer takes as long as a plain "
                     "rank's step); the other ranks keep --boards. Global board ids are a prefix sum: every board keeps its RNG stream")
+    ap.add_argument("--graph", action="store_true", help="simulator-only runs (--evaluator stub, one GPU): replay evaluator + k_step as ONE captured hipGraph "
+                    "per simulation (BatchedSelfPlay(use_graph=True)) without per-step HIP events -- the Python launch loop with its events costs "
+                    "~75 us per step, k_step ~30: this is the device-bound figure")
     ap.add_argument("--slow-rank", default="", help="testing: RANK:SECONDS -- that rank sleeps this long at every move boundary of the timed window "
                     "(with --exchange async its peers' step rates must not change)")
     ap.add_argument("--replay-rows", type=int, default=0, help="N>1 / trainer: rows of the dense replay ring every rank keeps in HBM "
@@ -245,6 +248,8 @@ def main():
         raise SystemExit(launch.self_launch(__file__, a.gpus, sys.argv[1:], share_gpu=a.share_gpu, cores=host_cores()))
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.graph and (a.evaluator != "stub" or world > 1 or a.train_every > 0):
+        raise SystemExit("--graph is for the simulator-only line: --evaluator stub on one GPU without a trainer")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     if a.share_gpu:
@@ -324,7 +329,7 @@ def main():
     trainer_on = [True]
 
     def make_engine(boards, base):
-        return BatchedSelfPlay(evaluator, boards, n_playout=n, seed=0, board_id_base=base, device=local_rank,
+        return BatchedSelfPlay(evaluator, boards, n_playout=n, seed=0, board_id_base=base, device=local_rank, use_graph=a.graph,
                                sampling="device", max_plies=a.max_plies, value_f16=a.value_f16,
                                eval_cache_log2=a.eval_cache_log2 if a.evaluator == "net" else 0, cache_verify=a.cache_verify)
 
@@ -355,6 +360,13 @@ def main():
         """The move boundary: pi + Dirichlet-mixed choice + re-root + push + game end (k_finish_move, k_flip_half), tuple
         harvest of the games that ended (k_harvest) with restart, and for N > 1 the all-gather of those rows."""
         timed = timing[0]
+        if ex is not None and not calibrating[0]:
+            # the launch loop runs ahead of the GPU and the boundary starts with a read-back that waits for everything queued: wait
+            # HERE, ticking, so that an exchange the peers have announced is issued now and not when this host returns from its sync
+            caught_up = torch.cuda.Event()
+            caught_up.record(torch.cuda.current_stream(dev))
+            while not caught_up.query():
+                consume(ex.tick_until(caught_up))
         if timed:
             # the launch loop runs ahead of the GPU; the boundary's first host read would wait for the queued steps anyway:
             # drain them here so that the boundary's own wall time is what gets measured (no extra wait in total)
@@ -450,7 +462,7 @@ def main():
         """``steps`` lockstep simulations through the PRODUCT's loop (BatchedSelfPlay.advance: evaluator -> fused k_step; a move
         boundary flushes with expand_backup, plays the move, harvests and re-selects)."""
         timing[0] = timed
-        sp.advance(steps, hooks=hooks, boundary=per_move)
+        sp.advance(steps, hooks=None if a.graph else hooks, boundary=per_move)   # (--graph: the captured graph is replayed only without hooks)
         timing[0] = False
 
     def timed_steps(k):
@@ -554,6 +566,13 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(a.steps, True)
+    if ex is not None:   # (waiting for the queued steps: keep the exchange moving meanwhile)
+        caught_up = torch.cuda.Event()
+        caught_up.record(torch.cuda.current_stream(dev))
+        timing[0] = True
+        while not caught_up.query():
+            consume(ex.tick_until(caught_up))
+        timing[0] = False
     torch.cuda.synchronize()
     dt_local = time.perf_counter() - t0  # this rank's own time (the per-rank rates); the job's time is taken behind the barrier
     drain_s = 0.0
@@ -625,6 +644,9 @@ def main():
             t_step = float(np.median([p[1].elapsed_time(p[2]) for p in pairs])) * 1e-3
         else:
             t_net = t_step = float("nan")
+        graph_step = None
+        if a.graph:   # no per-step events: the whole step by the host clock, boundary share removed (graph launch + k_step: an upper bound of k_step)
+            graph_step = t_step = (dt - boundary["host_s"]) / a.steps
         # algorithmic bytes per simulation, SURVEY 8(d): the fused k_step kernel does all of it. The
         # 21,420-B evaluator input is counted at the 3,780 B that can be non-zero (groups 7/15/16);
         # the 14 static-zero groups are written once at create, not per simulation.
@@ -661,7 +683,9 @@ def main():
             t_used, dur_src = rocprof_ns * 1e-9, (f"rocprofv3 --kernel-trace --stats average of k_step, profiles/{pm.get('tag', 'rNN')}_kernel_stats.csv, "
                                                   f"taken with this code (head {head}) on this workload")
         else:
-            t_used, dur_src = (t_step if t_step == t_step else None), ("RAW HIP events around every k_step launch of the timed window on its stream (median; "
+            t_used, dur_src = (t_step if t_step == t_step else None), ("the whole step by the host clock under hipGraph replay, move boundaries removed (graph launch + k_step: an upper "
+                                                                       "bound of k_step's duration, a lower bound of the fraction)" if graph_step is not None else
+                                                                       "RAW HIP events around every k_step launch of the timed window on its stream (median; "
                                                                        "the ~9 us an event pair adds are NOT subtracted: a lower bound of the fraction)"
                                                                        + (f" -- {profile_why}" if profile_why else ""))
         ach = a_step * B / t_used if t_used else 0.0
@@ -705,7 +729,8 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": a_step * B, "k_bar": kbar, "d_bar": dbar,
                          # always: the raw live HIP-event figure of this run (a lower bound of the fraction)
-                         "avg_launch_us_hip_events_raw": t_step * 1e6, "frac_hip_events_raw": ach_raw / HBM_PEAK,
+                         "avg_launch_us_hip_events_raw": (t_step * 1e6 if (t_step == t_step and graph_step is None) else None),
+                         "frac_hip_events_raw": (ach_raw / HBM_PEAK if graph_step is None else None),
                          "code_hash": head, "profile_head": profile_head,
                          # how far this run's raw event figure sits above the profile's duration (an event pair's own cost is ~1.25x here);
                          # beyond 1.5x k_step itself has changed since the profile
@@ -715,7 +740,7 @@ def main():
                          # counters and algorithmic bytes of ONE pass (the PMC passes' own timed window): reproducible from profiles/
                          "pmc_window": pmc_window},
             "survey_a_sim_bytes": a_sim_survey,
-            "step_split_us": {"k_step": t_step * 1e6, "evaluator": t_net * 1e6},
+            "step_split_us": {"k_step": (t_step * 1e6 if t_step == t_step else None), "evaluator": (t_net * 1e6 if t_net == t_net else None)},
             "trainer_updates": (train_steps[0] if trainer is not None else 0),
             "net_roofline": net_roofline,
             # rows the network really computed per step (with the evaluation cache: fewer than B) x 8.551 GFLOP

@@ -262,6 +262,8 @@ class AsyncRecordExchange(_FusedGather):
         self._last_ready_check = 0.0
         self._closing = False
         self._all_closed = False
+        self._handed_over = None     # receive slot whose union was handed to the caller by the last tick (its consumer is being enqueued)
+        self._consumed_ev = [None, None]   # per receive slot: recorded on the main stream one call after the hand-over
         self.issued = 0              # exchanges issued / completed so far (the next one has index ``issued``)
         self.completed = 0
         self.moves_posted = 0
@@ -303,6 +305,7 @@ class AsyncRecordExchange(_FusedGather):
         nearly always). ``block``: wait for the collective in flight (used by :meth:`flush`)."""
         t0 = time.perf_counter()
         out = []
+        self._mark_consumed()
         if self._solo():
             if self._backlog or self._games_pending:
                 union = self._backlog[0] if len(self._backlog) == 1 else (torch.cat(self._backlog) if self._backlog else
@@ -321,6 +324,19 @@ class AsyncRecordExchange(_FusedGather):
         elif self._work is None and self._announced >= self.issued and self._everyone_ready(block):
             self._issue()
         self._account(t0)
+        return out
+
+    def tick_until(self, event, poll_s: float = 0.002):
+        """The rank is about to block on the GPU (the launch loop runs ahead of the device; a move boundary starts with a read-back
+        that waits for everything queued): wait for ``event`` (a recorded ``torch.cuda.Event``) HERE instead, ticking meanwhile, so
+        that an exchange every other rank has announced is not left waiting -- its kernel spinning on the peers' CUs -- until this
+        rank's host comes back from its sync. Returns the completed exchanges (consume them before the next call)."""
+        out = []
+        while not event.query():
+            out += self.tick()
+            if out:          # hand over at once: the caller consumes before the next tick (receive-slot reuse is ordered on that)
+                return out
+            time.sleep(poll_s)
         return out
 
     def flush(self):
@@ -346,6 +362,16 @@ class AsyncRecordExchange(_FusedGather):
             self._closing = False
 
     # ---- internals -------------------------------------------------------------------------------------------------------
+    def _mark_consumed(self):
+        """The union handed over by the previous call has been consumed -- or its consumer enqueued on the current stream -- by now
+        (the caller does that before it calls again): an event on the current stream marks the point after which that receive slot
+        may be overwritten. The collective that reuses the slot (two exchanges later) waits for it: by stream order, not by luck."""
+        if self._handed_over is not None and self._xs is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._consumed_ev[self._handed_over] = ev
+        self._handed_over = None
+
     def _account(self, t0):
         dt = time.perf_counter() - t0
         self.host_seconds += dt
@@ -425,6 +451,8 @@ class AsyncRecordExchange(_FusedGather):
         with ctx:
             if self._xs is not None and getattr(self, "_harvest_ev", None) is not None:
                 self._xs.wait_event(self._harvest_ev)
+            if self._xs is not None and self._consumed_ev[j & 1] is not None:   # the consumer of exchange j - 2 read this receive slot
+                self._xs.wait_event(self._consumed_ev[j & 1])
             m, abort = self._fill(self._payload_of(self._send))
             hdr = torch.tensor([m, self._backlog_plies, 1 if self._closing else 0, self._games_pending, abort, j,
                                 self.moves_posted, 0], dtype=torch.int64)
@@ -473,6 +501,7 @@ class AsyncRecordExchange(_FusedGather):
         union = (segs[0] if len(segs) == 1 else torch.cat(segs)) if segs else torch.empty((0, REC_BYTES), dtype=torch.uint8, device=self.device)
         self._all_closed = bool((heads[:, 2] == 1).all()) and bool((heads[:, 1] == 0).all())
         self.user_sum = int(heads[:, 3].sum())
+        self._handed_over = j & 1
         return Exchanged(union, self.user_sum, list(self.rows_per_rank), j)
 
 

@@ -210,6 +210,26 @@ def test_group_of_one_hands_the_backlog_straight_over():
     assert len(done) == 1 and torch.equal(done[0].union, b)
 
 
+def test_tick_until_polls_the_event_and_hands_over_what_completes():
+    from chinesechesszero_amd.replay import AsyncRecordExchange
+
+    class Ev:
+        def __init__(self, n):
+            self.n = n
+
+        def query(self):
+            self.n -= 1
+            return self.n < 0
+
+    ex = AsyncRecordExchange(16, "cpu")
+    ev = Ev(3)
+    assert ex.tick_until(ev, poll_s=0.001) == [] and ev.n < 0         # nothing pending: polled until the event was done
+    ex._backlog.append(_games(0, 0, (3,)))                            # (a record that arrives while the rank waits for its GPU)
+    ex._backlog_plies = 3
+    got = ex.tick_until(Ev(50), poll_s=0.001)
+    assert len(got) == 1 and got[0].union.shape[0] == 3               # handed over at once, before the event completed
+
+
 def test_board_partition_prefix_sums():
     """Per-rank board counts (a lighter rank 0 next to the trainer): global board ids are a prefix sum, so every board keeps its
     RNG stream whatever the split."""
