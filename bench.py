@@ -554,7 +554,7 @@ def main():
     if ex is not None:      # drain what the untimed moves left (and set the communicator up): nothing is in flight at the window's barrier
         for x in ex.flush_iter():
             consume([x])
-        ex_stats0 = (ex.issued, ex.host_seconds, ex.plies_sent)
+        ex_stats0 = (ex.collectives, ex.host_seconds, ex.plies_sent, ex.issued, ex.bytes_sent)
         ex.max_call_s = 0.0
     torch.cuda.synchronize()
     s0 = e.stats()
@@ -580,7 +580,7 @@ def main():
         # INSIDE the job's timed region: every record harvested in the window is delivered to every rank before the clock stops
         # (the drain waits for the slowest rank, as the barrier behind it would anyway)
         d0 = time.perf_counter()
-        ex_window = (ex.issued - ex_stats0[0], ex.host_seconds - ex_stats0[1], ex.plies_sent - ex_stats0[2], ex.max_call_s)
+        ex_window = (ex.collectives - ex_stats0[0], ex.host_seconds - ex_stats0[1], ex.plies_sent - ex_stats0[2], ex.max_call_s, ex.issued - ex_stats0[3])
         timing[0] = True
         for x in ex.flush_iter():
             consume([x])
@@ -781,7 +781,11 @@ def main():
             if ex is not None:
                 out["multi_gpu"].update({
                     # collectives ISSUED between the window's start and the end of its K steps, and by the drain behind them
-                    "collectives_in_window": ex_window[0], "collectives_in_drain": ex.issued - ex_stats0[0] - ex_window[0],
+                    "collectives_in_window": ex_window[0], "collectives_in_drain": ex.collectives - ex_stats0[0] - ex_window[0],
+                    # exchanges DECIDED (window + drain), and how many of them were virtual: every rank had announced "nothing to send",
+                    # so no collective was issued (the drain's closing exchange is normally one of these)
+                    "exchanges_decided": ex.issued - ex_stats0[3], "exchanges_without_a_collective": ex.issued - ex_stats0[3] - (ex.collectives - ex_stats0[0]),
+                    "bytes_sent_rank0": ex.bytes_sent - ex_stats0[4],
                     "exchanges_completed_in_window_and_drain": boundary["exchanges_completed"],
                     "games_gathered": boundary["games"],
                     # what rank 0's launch loop spent inside the exchange during its K steps (host seconds: announcements, store
@@ -789,9 +793,10 @@ def main():
                     "exchange_host_ms_rank0": 1e3 * ex_window[1], "exchange_max_call_ms_per_rank": rank_xchg_max_call_ms,
                     "plies_sent_rank0": ex.plies_sent - ex_stats0[2], "backlog_peak_plies_rank0": ex.max_backlog_plies,
                     "drain_ms_rank0": 1e3 * drain_s,
-                    "what": "replay.AsyncRecordExchange: post at the move boundary (backlog + announcement on the job's TCPStore), ONE async "
-                            "all_gather_into_tensor from a side stream once every rank has announced it, picked up by a later step's tick; "
-                            "the drain (every record of the window delivered to every rank) is inside the timed region"})
+                    "what": "replay.AsyncRecordExchange: post at the move boundary (backlog; staged + announced on the job's TCPStore: plies, flags), "
+                            "ONE async all_gather_into_tensor of the smallest power-of-two slot that holds the largest announcement, from a side "
+                            "stream, once every rank has announced; picked up by a later step's tick; an exchange in which nobody sends is decided "
+                            "from the announcements alone. The drain (every record of the window delivered to every rank) is inside the timed region"})
             else:
                 out["multi_gpu"].update({"collectives_in_window": boundary["collectives"],
                                          "gather_ms": 1e3 * boundary["gather_s"] / max(1, boundary["n"])})

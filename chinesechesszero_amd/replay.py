@@ -211,32 +211,37 @@ class AsyncRecordExchange(_FusedGather):
     Here a rank only ever does three non-blocking things:
 
     * :meth:`post` -- at its move boundary: the finished games (compact ply records, whole games) join a local BACKLOG in
-      device memory, and the rank announces on the job's key-value store (the rendezvous TCPStore) that it is ready for
-      exchange ``j``;
-    * :meth:`tick` -- any time (bench.py: after every simulation step): when ALL ranks have announced ``j``, the backlog goes
-      into the send slot and ONE ``all_gather_into_tensor(async_op=True)`` is issued from a side stream (it depends on the
-      harvest only, not on the simulation steps queued on the main stream); a completed exchange is handed over as an
-      :class:`Exchanged` ``(union = records uint8 [P, 880], rank-major, whole games; games; rows_per_rank; index)``;
+      device memory; as soon as no exchange of its own is in flight the rank STAGES what fits the slot into its send buffer
+      and ANNOUNCES exchange ``j`` on the job's key-value store (the rendezvous TCPStore): how many plies it will send, how many
+      it holds back, the finished-game counter, and the closing / abort flags;
+    * :meth:`tick` -- any time (bench.py: after every simulation step): when ALL ranks have announced ``j`` every rank reads the
+      same announcements and therefore takes the same decision: nobody has anything -> the exchange is VIRTUAL (no collective at
+      all); somebody aborted -> every rank raises; otherwise ONE ``all_gather_into_tensor(async_op=True)`` of the smallest
+      power-of-two slot that holds the largest announcement is issued from a side stream (it depends on the harvest only, not on
+      the simulation steps queued on the main stream). A completed exchange is handed over as an :class:`Exchanged`
+      ``(union = records uint8 [P, 880], rank-major, whole games; games; rows_per_rank; index)``;
     * the collective itself runs on the process group's own stream while the search goes on.
 
     Exchanges pair by their index ``j``, not by move number: a fast rank posts several moves into one exchange, a slow rank
-    delays DATA, never its peers' launch loops. The store handshake keeps the collective's kernel from spinning on a fast
-    rank's CUs while a slow rank is still a move away: it is launched only once every rank is known to be within one
-    ``tick`` of launching it too. At most ONE exchange is in flight; the receive slot is double-buffered, so a handed-over
-    union stays valid until the second-next exchange is issued (consume it, or enqueue its consumer, before that).
+    delays DATA, never its peers' launch loops. The store is the control plane (counts, flags), the collective pure payload.
+    The handshake also keeps the collective's kernel from spinning on a fast rank's CUs while a slow rank is still a move away:
+    it is launched only once every rank is known to be within one ``tick`` of launching it too. At most ONE exchange is in
+    flight; the receive slot is double-buffered, so a handed-over union stays valid until the second-next exchange is issued
+    (consume it, or enqueue its consumer on the current stream, before the next call into the exchange).
 
-    What stays of :class:`RecordGatherer`: the fused ``[header 64 B | payload]`` slot (counts ride in the collective), whole
-    games only, and the abort flag -- a rank that cannot take part (one game longer than the slot) joins with the flag up and
-    EVERY rank raises :class:`GatherAborted` when it completes that exchange. A peer that never announces makes :meth:`tick`
-    raise after ``timeout_s`` (naming the missing ranks) instead of leaving anyone inside a collective.
-    :meth:`flush` (blocking; end of a run, or before any other collective of the job) drains: exchanges are repeated until every
-    rank's header says "closing, nothing left" -- every rank sees the same headers, so all stop after the same exchange.
+    What stays of :class:`RecordGatherer`: the fused ``[header 64 B | payload]`` slot, whole games only, and the abort rule --
+    a rank that cannot take part (one game longer than the slot) says so in its announcement and EVERY rank raises
+    :class:`GatherAborted` at that exchange. A peer that never announces makes :meth:`tick` raise after ``timeout_s`` (naming the
+    missing ranks) instead of leaving anyone inside a collective. :meth:`flush_iter` (blocking; end of a run, or before any other
+    collective of the job) drains: exchanges are repeated until every rank announces "closing, nothing to send, nothing held
+    back" -- all ranks read the same announcements, so all stop at the same exchange, and that last one costs no collective.
     """
 
     READY_POLL_S = 0.02   # a waiting rank asks the store at most this often (one ~0.1 ms round trip)
+    MIN_CLASS = 64        # smallest payload class (plies) of a collective
     _instances = 0
 
-    def __init__(self, capacity_plies: int = 65536, device="cpu", group=None, always_collective: bool = False,
+    def __init__(self, capacity_plies: int = 32768, device="cpu", group=None, always_collective: bool = False,
                  store=None, timeout_s: float = 180.0, name: str = "ccz_xchg"):
         self.cap = int(capacity_plies)
         if self.cap <= 0:
@@ -255,33 +260,38 @@ class AsyncRecordExchange(_FusedGather):
         self._backlog: list[torch.Tensor] = []
         self._backlog_plies = 0
         self._games_pending = 0
+        self._want = False           # this rank has something to say (a boundary was posted / it is draining) and has not announced it yet
+        self._staged = None          # (plies staged in the send slot, abort flag, games) of the announced exchange
+        self._harvest_ev = None
         self._work = None
-        self._inflight = None        # (index, receive buffer) of the exchange in flight
+        self._inflight = None        # (index, receive buffer, slot bytes, announcements) of the exchange in flight
         self._announced = -1         # highest exchange index this rank has announced
         self._announced_at = 0.0
         self._last_ready_check = 0.0
         self._closing = False
         self._all_closed = False
-        self._handed_over = None     # receive slot whose union was handed to the caller by the last tick (its consumer is being enqueued)
+        self._handed_over = None     # receive slot whose union was handed to the caller by the last call (its consumer is being enqueued)
         self._consumed_ev = [None, None]   # per receive slot: recorded on the main stream one call after the hand-over
-        self.issued = 0              # exchanges issued / completed so far (the next one has index ``issued``)
+        self.issued = 0              # exchanges decided so far, virtual ones included (the next one has index ``issued``)
         self.completed = 0
+        self.virtual = 0             # of those: exchanges in which no rank had anything to send (no collective)
         self.moves_posted = 0
         # statistics (bench.py reports them): host seconds spent inside post()/tick() -- what this rank's launch loop lost
         self.host_seconds = 0.0
         self.max_call_s = 0.0
         self.max_backlog_plies = 0
         self.plies_sent = 0
-        self.last_heads = None
+        self.bytes_sent = 0
+        self.last_slot_bytes = 0
+        self.last_plan = None
 
-    # ---- the three non-blocking calls ------------------------------------------------------------------------------------
+    # ---- the non-blocking calls ------------------------------------------------------------------------------------------
     def post(self, chunks, games: int = 0):
         """This rank's finished games of one move boundary: ``chunks`` = iterable of uint8 [P, 880] tensors, whole games each
         (``engine.harvest_record_chunks``), possibly empty. Never waits for a peer. Returns what :meth:`tick` returns."""
         t0 = time.perf_counter()
         if isinstance(chunks, torch.Tensor):
             chunks = [chunks]
-        ev = None
         for c in chunks:
             if int(c.shape[0]) == 0:
                 continue
@@ -295,36 +305,47 @@ class AsyncRecordExchange(_FusedGather):
         self._games_pending += int(games)
         self.moves_posted += 1
         self.max_backlog_plies = max(self.max_backlog_plies, self._backlog_plies)
-        self._announce()
+        self._want = True
         self._account(t0)
         return self.tick()
 
     def tick(self, block: bool = False):
-        """Advance the exchange without waiting for anybody: complete the collective in flight if it has finished, issue the
-        next one if every rank has announced it. Returns the list of completed exchanges (:class:`Exchanged`; empty
-        nearly always). ``block``: wait for the collective in flight (used by :meth:`flush`)."""
+        """Advance the exchange without waiting for anybody: complete the collective in flight if it has finished; announce what
+        this rank has posted; decide the next exchange if every rank has announced it. Returns the list of completed exchanges
+        (:class:`Exchanged`; empty nearly always). ``block``: wait for the collective in flight / for the announcements (used
+        by :meth:`flush_iter`)."""
         t0 = time.perf_counter()
         out = []
         self._mark_consumed()
-        if self._solo():
-            if self._backlog or self._games_pending:
-                union = self._backlog[0] if len(self._backlog) == 1 else (torch.cat(self._backlog) if self._backlog else
-                                                                          torch.empty((0, REC_BYTES), dtype=torch.uint8, device=self.device))
-                out.append(Exchanged(union, self._games_pending, [int(union.shape[0])], self.issued))
-                self.rows_per_rank = [int(union.shape[0])]
-                self.plies_sent += int(union.shape[0])
-                self._backlog, self._backlog_plies, self._games_pending = [], 0, 0
-                self.issued += 1
-                self.completed += 1
-            self._all_closed = self._closing
-            self._account(t0)
+        try:
+            if self._solo():
+                if self._backlog or self._games_pending:
+                    union = self._backlog[0] if len(self._backlog) == 1 else (torch.cat(self._backlog) if self._backlog else
+                                                                              torch.empty((0, REC_BYTES), dtype=torch.uint8, device=self.device))
+                    out.append(Exchanged(union, self._games_pending, [int(union.shape[0])], self.issued))
+                    self.rows_per_rank = [int(union.shape[0])]
+                    self.plies_sent += int(union.shape[0])
+                    self._backlog, self._backlog_plies, self._games_pending = [], 0, 0
+                    self.issued += 1
+                    self.completed += 1
+                self._all_closed = self._closing
+                self._want = False
+                return out
+            if self._work is not None:
+                if block or self._work.is_completed():
+                    out.append(self._complete())
+                return out
+            if self._want and self._announced < self.issued:
+                self._announce()
+            if self._announced >= self.issued:
+                plan = self._everyone_announced(block)
+                if plan is not None:
+                    done = self._decide(plan)
+                    if done is not None:
+                        out.append(done)
             return out
-        if self._work is not None and (block or self._work.is_completed()):
-            out.append(self._complete())
-        elif self._work is None and self._announced >= self.issued and self._everyone_ready(block):
-            self._issue()
-        self._account(t0)
-        return out
+        finally:
+            self._account(t0)
 
     def tick_until(self, event, poll_s: float = 0.002):
         """The rank is about to block on the GPU (the launch loop runs ahead of the device; a move boundary starts with a read-back
@@ -341,25 +362,28 @@ class AsyncRecordExchange(_FusedGather):
 
     def flush(self):
         """Blocking drain (end of a run; before any OTHER collective of the job is issued): waits for the exchange in flight and
-        repeats exchanges until every rank is closing with an empty backlog. Returns the completed exchanges, in order; their
+        repeats exchanges until every rank is closing with nothing left. Returns the completed exchanges, in order; their
         unions are COPIES (the drain may run through more exchanges than the receive slots hold)."""
         return [x._replace(union=x.union.clone()) for x in self.flush_iter()]
 
     def flush_iter(self):
-        """:meth:`flush` as a generator: every completed exchange is yielded before the next one is issued, so the union (a view
+        """:meth:`flush` as a generator: every completed exchange is yielded before the next one is decided, so the union (a view
         of a receive slot) can be consumed in place. Iterate it to the end."""
         self._closing = True
         self._all_closed = False
         try:
             while True:
-                if self._work is None:
-                    self._announce()
-                for x in self.tick(block=True):       # completes the exchange in flight, else waits for all ranks and issues
+                self._want = True
+                for x in self.tick(block=True):       # completes the exchange in flight, else announces, waits for all ranks, decides
                     yield x
                 if self._all_closed:
                     return
         finally:
             self._closing = False
+
+    def bytes_per_exchange(self) -> int:
+        """Bytes this rank sent in its last collective (the slot class of that exchange; the full slot before the first one)."""
+        return self.last_slot_bytes or self.slot_bytes
 
     # ---- internals -------------------------------------------------------------------------------------------------------
     def _mark_consumed(self):
@@ -381,27 +405,41 @@ class AsyncRecordExchange(_FusedGather):
         return f"x{j}" if rank is None else f"x{j}r{rank}"
 
     def _announce(self):
-        j = self.issued   # the next exchange to be issued (one in flight has index issued - 1 and completes without this rank's help)
-        if self._announced >= j or self._solo():
-            return
+        """Stage what fits the slot (whole games) into the send buffer and tell the job: ``plies, held back, closing, abort, games``.
+        Only while no exchange of this rank is in flight (the send buffer is free). What is posted later waits for the next exchange."""
+        j = self.issued
+        with (torch.cuda.stream(self._xs) if self._xs is not None else _NullCtx()):
+            if self._xs is not None and self._harvest_ev is not None:
+                self._xs.wait_event(self._harvest_ev)
+            m, abort = self._fill(self._payload_of(self._send))
+        self._staged = (m, abort, self._games_pending)
+        self._games_pending = 0
+        self._want = False
         self._announced = j
         self._announced_at = time.perf_counter()
         if self._store is not None:
-            self._store.set(self._key(j, self.rank), b"1")
+            self._store.set(self._key(j, self.rank), f"{m},{self._backlog_plies},{1 if self._closing else 0},{abort},{self._staged[2]}")
             self._store.add(self._key(j), 1)
 
-    def _everyone_ready(self, block: bool) -> bool:
-        """Have all ranks announced exchange ``issued``? One store round trip, rate-limited; ``block`` polls until they have
-        (or the timeout names the ranks that have not)."""
-        if self._store is None:
-            return True
+    def _everyone_announced(self, block: bool):
+        """All ranks' announcements of exchange ``issued`` -- int64 [world, 5] (plies, held back, closing, abort, games) -- or None
+        while some are missing. One store round trip per poll, rate-limited; ``block`` polls until they are there (or the timeout
+        names the ranks that are not)."""
         j = self.issued
+        if self._store is None:
+            m, abort, games = self._staged
+            return [[m, self._backlog_plies, 1 if self._closing else 0, abort, games]]
         while True:
             now = time.perf_counter()
             if block or now - self._last_ready_check >= self.READY_POLL_S:
                 self._last_ready_check = now
                 if int(self._store.add(self._key(j), 0)) >= self.world:
-                    return True
+                    keys = [self._key(j, k) for k in range(self.world)]
+                    try:
+                        vals = self._store.multi_get(keys)
+                    except Exception:
+                        vals = [self._store.get(k) for k in keys]
+                    return [[int(x) for x in (v.decode() if isinstance(v, (bytes, bytearray)) else str(v)).split(",")] for v in vals]
             if now - self._announced_at > self.timeout_s:
                 missing = []
                 for k in range(self.world):
@@ -411,10 +449,47 @@ class AsyncRecordExchange(_FusedGather):
                     except Exception:
                         missing.append(k)
                 raise RuntimeError(f"exchange {j}: rank(s) {missing} did not announce within {self.timeout_s:.0f} s "
-                                   f"(this rank {self.rank} has {self._backlog_plies} plies waiting)")
+                                   f"(this rank {self.rank} has {self._backlog_plies + (self._staged[0] if self._staged else 0)} plies waiting)")
             if not block:
-                return False
+                return None
             time.sleep(0.002)
+
+    def _decide(self, plan):
+        """Every rank holds the same ``plan`` (the announcements of exchange ``issued``) and takes the same branch."""
+        j = self.issued
+        self.last_plan = plan
+        if self._store is not None and self.rank == 0 and j >= 2:   # the announcements of exchange j - 2 are history
+            try:
+                for key in [self._key(j - 2)] + [self._key(j - 2, k) for k in range(self.world)]:
+                    self._store.delete_key(key)
+            except Exception:
+                pass
+        bad = [k for k in range(self.world) if plan[k][3]]
+        if bad:
+            self.issued += 1
+            self.completed += 1
+            self._staged = None
+            raise GatherAborted(f"rank(s) {bad} aborted the exchange" + (f": {self._abort_why}" if self.rank in bad and self._abort_why else ""))
+        most = max(p[0] for p in plan)
+        if most == 0:
+            # nobody sends anything: no collective. (Games announced without records cannot happen -- they ride with their records --
+            # but the counter is passed on all the same.)
+            self.issued += 1
+            self.completed += 1
+            self.virtual += 1
+            self._staged = None
+            self.rows_per_rank = [0] * self.world
+            self.user_sum = sum(p[4] for p in plan)
+            self._all_closed = all(p[2] for p in plan) and all(p[1] == 0 for p in plan)
+            if self.user_sum:
+                return Exchanged(torch.empty((0, REC_BYTES), dtype=torch.uint8, device=self.device), self.user_sum, list(self.rows_per_rank), j)
+            return None
+        cls = self.MIN_CLASS
+        while cls < most:
+            cls *= 2
+        cls = min(cls, self.cap)
+        self._issue(j, plan, -(-(self.HEADER + cls * REC_BYTES) // 64) * 64)
+        return None
 
     def _fill(self, payload) -> tuple[int, int]:
         """Move whole games from the backlog into the send slot: (records placed, abort flag)."""
@@ -428,7 +503,7 @@ class AsyncRecordExchange(_FusedGather):
                     break
                 try:
                     take = self._whole_games(c, 0, self.cap)
-                except ValueError as e:   # one game longer than the slot: join the collective with the abort flag up
+                except ValueError as e:   # one game longer than the slot: say so in the announcement, every rank raises
                     self._abort_why = str(e)
                     return m, 1
             payload[m:m + take].copy_(c[:take], non_blocking=True)
@@ -444,63 +519,55 @@ class AsyncRecordExchange(_FusedGather):
 
     _whole_games = staticmethod(RecordGatherer._whole_games)
 
-    def _issue(self):
-        j = self.issued
-        recv = self._recv2[j & 1]
-        ctx = torch.cuda.stream(self._xs) if self._xs is not None else _NullCtx()
-        with ctx:
-            if self._xs is not None and getattr(self, "_harvest_ev", None) is not None:
-                self._xs.wait_event(self._harvest_ev)
+    def _issue(self, j, plan, sz):
+        """ONE collective of ``sz`` bytes per rank: ``[header 64 B | staged records]``, the smallest class that holds every rank's."""
+        recv = self._recv2[j & 1][: self.world * sz]
+        m, abort, games = self._staged
+        with (torch.cuda.stream(self._xs) if self._xs is not None else _NullCtx()):
             if self._xs is not None and self._consumed_ev[j & 1] is not None:   # the consumer of exchange j - 2 read this receive slot
                 self._xs.wait_event(self._consumed_ev[j & 1])
-            m, abort = self._fill(self._payload_of(self._send))
-            hdr = torch.tensor([m, self._backlog_plies, 1 if self._closing else 0, self._games_pending, abort, j,
-                                self.moves_posted, 0], dtype=torch.int64)
+            hdr = torch.tensor([m, self._backlog_plies, 1 if self._closing else 0, games, abort, j, self.moves_posted, sz], dtype=torch.int64)
             self._send[:self.HEADER].view(torch.int64).copy_(hdr)       # (blocking on the side stream only)
-            self._work = dist.all_gather_into_tensor(recv, self._send, group=self.group, async_op=True)
-        self._inflight = (j, recv)
-        self._games_pending = 0
+            self._work = dist.all_gather_into_tensor(recv, self._send[:sz], group=self.group, async_op=True)
+        self._inflight = (j, recv, sz, plan)
+        self._staged = None
         self.plies_sent += m
+        self.bytes_sent += sz
+        self.last_slot_bytes = sz
         self.issued += 1
         self.collectives += 1
 
-    def _payload_of(self, buf, k: int = 0):
-        base = k * self.slot_bytes + self.HEADER
-        return buf[base: base + self.cap * REC_BYTES].view(self.cap, REC_BYTES)
+    def _payload_of(self, buf, k: int = 0, sz: int | None = None):
+        sz = self.slot_bytes if sz is None else sz
+        base = k * sz + self.HEADER
+        n = (sz - self.HEADER) // REC_BYTES
+        return buf[base: base + n * REC_BYTES].view(n, REC_BYTES)
 
     def _complete(self):
-        """The exchange in flight has finished (or: wait for it): read the headers, hand over the union."""
-        j, recv = self._inflight
+        """The exchange in flight has finished (or: wait for it): check the headers against the announcements, hand over the union."""
+        j, recv, sz, plan = self._inflight
         work, self._work, self._inflight = self._work, None, None
         # the headers are read on the SIDE stream (which waits for the collective's stream only): the host does not wait for the
         # simulation steps queued on the main stream. gloo: a host wait.
         with (torch.cuda.stream(self._xs) if self._xs is not None else _NullCtx()):
             work.wait()
-            heads = recv.view(self.world, self.slot_bytes)[:, :self.HEADER].contiguous().view(torch.int64).view(self.world, 8).cpu()
+            heads = recv.view(self.world, sz)[:, :self.HEADER].contiguous().view(torch.int64).view(self.world, 8).cpu()
         if self._xs is not None:   # consumers of the union are enqueued on the current stream: behind the collective
             torch.cuda.current_stream(self.device).wait_stream(self._xs)
-        self.last_heads = heads
         self.completed += 1
-        if self._store is not None and self.rank == 0 and j >= 2:   # the announcements of exchange j - 2 are history
-            try:
-                for key in [self._key(j - 2)] + [self._key(j - 2, k) for k in range(self.world)]:
-                    self._store.delete_key(key)
-            except Exception:
-                pass
-        if any(int(heads[k, 5]) != j for k in range(self.world)):
-            raise RuntimeError(f"exchange {j}: the ranks paired different exchanges {heads[:, 5].tolist()} (a collective was issued "
-                               f"on this group outside the exchange)")
-        bad = [k for k in range(self.world) if int(heads[k, 4])]
-        if bad:
-            raise GatherAborted(f"rank(s) {bad} aborted the exchange" + (f": {self._abort_why}" if self.rank in bad and self._abort_why else ""))
+        got = [[int(heads[k, 5]), int(heads[k, 0]), int(heads[k, 7])] for k in range(self.world)]
+        want = [[j, plan[k][0], sz] for k in range(self.world)]
+        if got != want:
+            raise RuntimeError(f"exchange {j}: what arrived (index, plies, slot bytes per rank) {got} is not what was announced {want} "
+                               f"(a collective was issued on this group outside the exchange?)")
         segs = []
-        self.rows_per_rank = [int(heads[k, 0]) for k in range(self.world)]
+        self.rows_per_rank = [plan[k][0] for k in range(self.world)]
         for k in range(self.world):
             if self.rows_per_rank[k]:
-                segs.append(self._payload_of(recv, k)[:self.rows_per_rank[k]])
-        union = (segs[0] if len(segs) == 1 else torch.cat(segs)) if segs else torch.empty((0, REC_BYTES), dtype=torch.uint8, device=self.device)
-        self._all_closed = bool((heads[:, 2] == 1).all()) and bool((heads[:, 1] == 0).all())
-        self.user_sum = int(heads[:, 3].sum())
+                segs.append(self._payload_of(recv, k, sz)[:self.rows_per_rank[k]])
+        union = segs[0] if len(segs) == 1 else torch.cat(segs)
+        self._all_closed = False      # somebody sent something: the closing exchange is the (virtual) one after it
+        self.user_sum = sum(p[4] for p in plan)
         self._handed_over = j & 1
         return Exchanged(union, self.user_sum, list(self.rows_per_rank), j)
 
