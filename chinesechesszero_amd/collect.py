@@ -4,8 +4,10 @@ Two modes behind the same class:
   * ``n_boards == 1``: the reference's own control flow -- ``Game.start_self_play`` with an ``MCTS_AI``
     player, ``preprocess`` and ``flip_data`` on the host -- for drop-in use and parity tests;
   * ``n_boards > 1``: the MI355X-native path -- ``BatchedSelfPlay`` runs all games in lockstep on the
-    GPU, ``harvest`` materialises (state, pi, z) rows incl. the mirror images on the device, and (with
-    ``torch.distributed`` initialised) rows are all-gathered over RCCL.
+    GPU, ``harvest`` materialises (state, pi, z) rows incl. the mirror images on the device; with several ranks
+    (``python -m torch.distributed.run --nproc-per-node N -m chinesechesszero_amd.collect --boards 4096``: the N collectors of the
+    reference's README.md:31-48 as one job) finished games are all-gathered over RCCL as compact records without any rank waiting
+    for another (``replay.AsyncRecordExchange``) and rank 0 stores the union: what N collectors appending to one file produce.
 Rows go to a ``TupleSink``: shard files while collecting, merged by ``TupleSink.finalize()`` into ``states.npy /
 mcts.npy / winners.npy / meta.json`` with the array names, dtypes and ``meta.json`` keys of the reference's
 convert.py:84-99 (what dataset.py:45-89 reads). h5py is not part of this image: the per-game HDF5 groups of
@@ -318,7 +320,7 @@ def write_games_hdf5(records: torch.Tensor, h5_path: str, flags: int = 0, plane_
 class CollectPipeline:
     def __init__(self, init_model=None, n_boards: int = 1, n_playout: int = PLAYOUT, device: int = 0, seed: int = 0,
                  data_dir: str = DATA_DIR, reference_quirks: bool = False, num_channels: int = 256, resblocks_num: int = 40,
-                 finalize_every: int = 0, on_playout=None, max_plies: int = 0, eval_cache_log2: int | None = None):
+                 finalize_every: int = 0, on_playout=None, max_plies: int = 0, eval_cache_log2: int | None = None, gatherer=None):
         self.board = Board()                       # collect.py:28 (never advanced: source of the turn-plane quirk)
         self.game = Game(self.board, reference_quirks=reference_quirks)
         self.temp = 1.0
@@ -342,6 +344,8 @@ class CollectPipeline:
         self.finalize_every = finalize_every
         self._finalized_at = self.sink.games
         self.on_playout = on_playout  # progress sink of the batched path (reference game.py:162-185 feeds a progress bar)
+        # several ranks: the exchange of finished games (replay.AsyncRecordExchange / RecordGatherer / TupleGatherer); rank 0 stores the union
+        self.gatherer = gatherer
 
     def load_model(self):
         """collect.py:48-62: load once; on failure fall back to a random-init net."""
@@ -355,6 +359,11 @@ class CollectPipeline:
             except Exception as e:
                 log(f"Failed to load model {model_path}: {e}", "ERROR")
                 self.policy_value_net = PolicyValueNet(device=dev, num_channels=self._net_shape[0], resblocks_num=self._net_shape[1])
+            if self.gatherer is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+                # one job, one net: every rank plays with rank 0's weights (a model file that is missing on some rank, or the random
+                # fallback above, must not give the ranks different evaluators) -- ONE broadcast of the fp32 state, before any exchange
+                from .replay import broadcast_model
+                broadcast_model(self.policy_value_net, src=0, what="state")
             self.mcts_ai = MCTS_AI(self.policy_value_net.policy_value_fn, c_puct=self.c_puct, n_playout=self.n_playout,
                                    is_selfplay=True, device=self.device, seed=self.seed)
 
@@ -395,7 +404,7 @@ class CollectPipeline:
         """collect.py:133-176 (n_boards == 1) or one lockstep move of all boards + harvest (n_boards > 1)."""
         self.load_model()
         if self.n_boards > 1:
-            return self.collect_batched(1)
+            return self.collect_batched(1, gatherer=self.gatherer)
         self.current_game_index = self.iters + 1
         play_data = self.game.start_self_play(self.mcts_ai, is_shown=is_shown, game_index=self.current_game_index)
         play_data = self.flip_data(self.preprocess(play_data))
@@ -518,6 +527,8 @@ class CollectPipeline:
         except KeyboardInterrupt:
             log("Exit")
         finally:
+            if self.gatherer is not None and hasattr(self.gatherer, "flush_iter") and self.selfplay is not None:
+                self.drain_exchange(self.gatherer)   # every rank's last games reach rank 0's store (blocking; all ranks call it)
             self.sink.finalize()
 
 
@@ -535,7 +546,22 @@ if __name__ == "__main__":
     parser.add_argument("--channels", type=int, default=256)
     parser.add_argument("--blocks", type=int, default=40)
     parser.add_argument("--seed", type=int, default=0)
+    parser.add_argument("--backend", default="nccl", help="several ranks (under torch.distributed.run): nccl = RCCL, one GPU per rank; gloo to rehearse")
+    parser.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
     args = parser.parse_args()
+    # N collectors as ONE job (the reference starts N shell commands, README.md:31-48): python -m torch.distributed.run --nproc-per-node N
+    # -m chinesechesszero_amd.collect ... -- every rank plays --boards boards, rank 0 stores the union of the finished games
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    gatherer, device = None, 0
+    if world > 1:
+        from . import launch
+        from .replay import AsyncRecordExchange
+        device = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(device)
+        launch.init_distributed(args.backend, torch.device("cuda", device))
+        gatherer = AsyncRecordExchange(max(32768, args.max_plies or 2048), torch.device("cuda", device) if args.backend == "nccl" else "cpu")
+        if rank > 0:   # these ranks store nothing (their sink only counts games): keep them out of rank 0's directory lock
+            args.data_dir = os.path.join(args.data_dir, f".rank{rank}")
     viewer = None
     if args.show:   # the window is an example, not part of the package: found when run from a checkout of the repository
         try:
@@ -545,6 +571,16 @@ if __name__ == "__main__":
             viewer = get_chess_window()
         except Exception as exc:
             log(f"--show: examples/viewer.py is not importable here ({exc}); running without a window", "WARNING")
-    CollectPipeline(init_model=args.model, n_boards=args.boards, n_playout=args.playout, data_dir=args.data_dir, seed=args.seed,
-                    num_channels=args.channels, resblocks_num=args.blocks, max_plies=args.max_plies,
-                    eval_cache_log2=args.eval_cache_log2).run(is_shown=args.show, max_calls=args.moves, viewer=viewer)
+    pipe = CollectPipeline(init_model=args.model, n_boards=args.boards, n_playout=args.playout, data_dir=args.data_dir, seed=args.seed,
+                           num_channels=args.channels, resblocks_num=args.blocks, max_plies=args.max_plies, device=device,
+                           eval_cache_log2=args.eval_cache_log2, gatherer=gatherer)
+    if world > 1:
+        from .launch import guarded
+
+        def _job():
+            pipe.run(is_shown=args.show and rank == 0, max_calls=args.moves, viewer=viewer)
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+            return 0
+        raise SystemExit(guarded(_job))
+    pipe.run(is_shown=args.show, max_calls=args.moves, viewer=viewer)

@@ -378,6 +378,25 @@ def test_collect_cli_writes_the_trainer_files(tmp_path):
     assert not [f for f in os.listdir(tmp_path / "data") if f.startswith(".shard_")]
 
 
+def test_collect_cli_two_ranks_one_store(tmp_path):
+    """The reference's N collectors (README.md:31-48: N shell commands appending to one file) as ONE job: `torch.distributed.run
+    --nproc-per-node 2 -m chinesechesszero_amd.collect`. Both ranks play their boards with rank 0's weights, finished games travel
+    through the asynchronous exchange, rank 0 stores the union and writes the trainer's files; rank 1 stores nothing."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "-m", "chinesechesszero_amd.collect", "--boards", "32", "--playout", "4", "--blocks", "1",
+           "--channels", "32", "--max-plies", "5", "--moves", "13", "--model", "no_such_model.pkl", "--data-dir", str(tmp_path / "data"),
+           "--backend", "gloo", "--share-gpu"]
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    import numpy as np
+    meta = json.load(open(tmp_path / "data" / "meta.json"))
+    # 13 moves with a 5-ply cap: every board of BOTH ranks is adjudicated twice -> 2 ranks x 32 boards x 2 games x 5 plies x 2 (mirror)
+    assert meta["total_count"] == 2 * 32 * 2 * 5 * 2 and meta["iters"] == 128
+    pi = np.load(tmp_path / "data" / "mcts.npy", mmap_mode="r")
+    assert pi.shape == (1280, 2086) and np.allclose(np.asarray(pi).sum(1), 1.0, atol=1e-5)
+    assert not os.path.exists(tmp_path / "data" / ".rank1" / "states.npy")       # the union lives in ONE store
+
+
 def test_uci_cli_over_stdin_with_the_real_net():
     """`python -m chinesechesszero_amd.uci` (the README's "standard UCI protocol", README.md:3, which the reference never
     implemented): a session over stdin/stdout with the default 40x256 net, single-board search replayed as a hipGraph."""
