@@ -25,11 +25,12 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import chinesechesszero_amd  # noqa: E402,F401  (first: sets GPU_MAX_HW_QUEUES before anything initialises HIP -- see its __init__)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md (6.29e12 measured copy peak)
 MFMA_PEAK_F16 = 2.5e15  # FLOP/s dense fp16/bf16, MI355X_MICROARCH.md (never the 2:1-sparsity figure)
@@ -71,6 +72,9 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="simulator-only runs (--evaluator stub, one GPU): replay evaluator + k_step as ONE captured hipGraph "
                     "per simulation (BatchedSelfPlay(use_graph=True)) without per-step HIP events -- the Python launch loop with its events costs "
                     "~75 us per step, k_step ~30: this is the device-bound figure")
+    ap.add_argument("--rccl-group-of-one", action="store_true", help="one GPU: run the N>1 exchange path for real on backend nccl (= RCCL) in a process "
+                    "group of ONE rank -- the asynchronous all-gather from the side stream, the store handshake, the expansion into the replay ring, "
+                    "inside the full-size timed loop (what one GPU can show of the exchange's cost on the rank that issues it)")
     ap.add_argument("--slow-rank", default="", help="testing: RANK:SECONDS -- that rank sleeps this long at every move boundary of the timed window "
                     "(with --exchange async its peers' step rates must not change)")
     ap.add_argument("--replay-rows", type=int, default=0, help="N>1 / trainer: rows of the dense replay ring every rank keeps in HBM "
@@ -248,6 +252,8 @@ def main():
         raise SystemExit(launch.self_launch(__file__, a.gpus, sys.argv[1:], share_gpu=a.share_gpu, cores=host_cores()))
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    solo_group = bool(a.rccl_group_of_one and world == 1)
+    multi = world > 1 or solo_group   # the N>1 code path: process group, exchange, replay ring, multi_gpu block
     if a.graph and (a.evaluator != "stub" or world > 1 or a.train_every > 0):
         raise SystemExit("--graph is for the simulator-only line: --evaluator stub on one GPU without a trainer")
     if not torch.cuda.is_available():
@@ -263,7 +269,12 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if solo_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(launch.free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if multi:
         # 180 s, not torch's 10 minutes: a rank that dies mid-window must not keep its peers in the all-gather for long
         launch.init_distributed(a.backend, dev, timeout_s=a.dist_timeout)
     xdev = dev if a.backend == "nccl" else torch.device("cpu")  # where the exchange buffers live
@@ -286,7 +297,7 @@ def main():
     # every rank without a trainer ("all": any rank may sample), rank 0 only when a trainer runs there (configs[4]: the other
     # ranks would write 8 x 28 k rows x 29,768 B = 6.8 GB per move into rings nobody reads)
     ring_ranks = a.ring_ranks if a.ring_ranks != "auto" else ("0" if a.train_every > 0 else "all")
-    has_ring = (world > 1 or a.train_every > 0) and (ring_ranks == "all" or rank == 0)
+    has_ring = (multi or a.train_every > 0) and (ring_ranks == "all" or rank == 0)
     rb = ReplayBuffer(a.replay_rows or 40000 * world, dev) if has_ring else None
     bad_records = torch.zeros(1, dtype=torch.int32, device=dev)
 
@@ -318,11 +329,11 @@ def main():
     mul = 2   # dense rows per ply record (the sample and its mirror image, collect.py:112-131)
     max_plies_eff = a.max_plies if a.max_plies > 0 else 2048
     gather = ex = None
-    if world > 1:
+    if multi:
         if a.exchange == "sync":
-            gather = RecordGatherer(max(a.gather_plies, max_plies_eff), xdev)
+            gather = RecordGatherer(max(a.gather_plies, max_plies_eff), xdev, always_collective=solo_group)
         else:
-            ex = AsyncRecordExchange(max(a.gather_plies, max_plies_eff), xdev, timeout_s=a.dist_timeout)
+            ex = AsyncRecordExchange(max(a.gather_plies, max_plies_eff), xdev, timeout_s=a.dist_timeout, always_collective=solo_group)
     slow_rank, slow_s = (int(a.slow_rank.split(":")[0]), float(a.slow_rank.split(":")[1])) if a.slow_rank else (-1, 0.0)
     sp = e = None              # this rank's engine: made by make_engine() below, once the rank's board count is known
     calibrating = [False]      # rank 0 measuring itself for --boards-rank0 auto: finished games are dropped, not exchanged
@@ -516,7 +527,7 @@ def main():
                 e.close()
                 sp = e = None
                 torch.cuda.empty_cache()
-        if world > 1:
+        if multi:
             dist.broadcast(t, src=0)
         boards_rank0 = int(t.item())
     elif a.boards_rank0:
@@ -561,7 +572,7 @@ def main():
     tower_probe = None
     if a.evaluator == "net":
         tower_probe = pvn._infer.tower_probe = []   # one HIP-event pair around the tower's 2 x blocks launches of every timed step
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -587,7 +598,7 @@ def main():
         timing[0] = False
         torch.cuda.synchronize()
         drain_s = time.perf_counter() - d0
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -595,7 +606,7 @@ def main():
         pvn._infer.tower_probe = None
     s1 = e.stats()
     ranks_seen, per_rank, err_any, bad_total = 1, None, int(s1["error_flags"]), int(bad_records.item())
-    if world > 1:
+    if multi:
         t = torch.zeros(3 * world + 4, dtype=torch.float64, device=xdev)
         t[0] = dt
         mx = t[:1].clone()
@@ -720,7 +731,7 @@ def main():
             "moves_per_sec": moves_per_sec,
             "move_boundary": {"in_window": boundary["n"], "ms_events": mb_ev, "ms_host": mb_host,
                               "games_finished": boundary["games"], "rows_harvested_rank0": boundary["rows_local"],
-                              "what": "k_finish_move + k_flip_half + status readback + " + ("k_harvest + restart" if world == 1 else
+                              "what": "k_finish_move + k_flip_half + status readback + " + ("k_harvest + restart" if not multi else
                                       "k_harvest_records + restart + all-gather of the records + k_expand_records into the replay ring"),
                               "moves_per_sec_formula": "n_gpus * boards / (sims_per_move * (ms_per_step without the boundary) + ms_host)"},
             "roofline": {"bound": "hbm", "kernel": "k_step (fused expand+backup+select+movegen+encode)",
@@ -758,8 +769,9 @@ def main():
             "error_flags_any": err_any,
             "plies": {"start_mean": float(plies0.mean()), "start_max": int(plies0.max()), "end_mean": float(plies1.mean())},
             "setup_seconds": setup_s,
+            "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),   # (chinesechesszero_amd/__init__.py: the tower's launch chains need queues of their own)
         }
-        if world > 1:
+        if multi:
             xg = gather if gather is not None else ex
             out["multi_gpu"] = {"world_size": world, "ranks_seen": ranks_seen, "backend": a.backend,
                                 "error_flags_any": err_any, "bad_records": bad_total,
@@ -800,14 +812,17 @@ def main():
             else:
                 out["multi_gpu"].update({"collectives_in_window": boundary["collectives"],
                                          "gather_ms": 1e3 * boundary["gather_s"] / max(1, boundary["n"])})
+            if solo_group:
+                out["multi_gpu"]["rccl_group_of_one"] = ("one rank on backend nccl (= RCCL): the exchange path run for real on one GPU -- async all-gather from the "
+                                                         "side stream, store handshake, expansion into the replay ring -- next to the full-size search")
             if slow_rank >= 0:
                 out["multi_gpu"]["slow_rank"] = {"rank": slow_rank, "sleep_s_per_boundary": slow_s}
         if calibration is not None:
             out["rank0_calibration"] = calibration
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not solo_group and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_seconds, a.blocks, a.channels)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     return 0

@@ -6,4 +6,14 @@ Only what the hot path needs: the gfx950 HIP engine behind
 (``replay``). There is no CPU fallback: the engine fails loudly when ``libcczero.so`` or a GPU is
 missing.
 """
+import os as _os
+
+# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4). The evaluator runs its tower as three concurrent launch chains
+# on streams of its own; as soon as a process also holds the streams of the multi-GPU exchange (the process group's RCCL stream, the
+# exchange's side stream), four queues are not enough: chains end up sharing a queue and run one after the other -- measured on one
+# MI355X with the N>1 path in a group of one on RCCL: 26.6 ms per step instead of 21.2 (tower layer 330 us instead of 262), with 8
+# queues 21.1 (profiles/r05_h_*.json, r05_g1_*.json). The variable is read when the HIP runtime initialises, i.e. at the first device
+# call, not at ``import torch``: importing this package first is early enough. A value set by the user wins.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 __version__ = "0.1.0"

@@ -131,6 +131,36 @@ class EvalOptions:
         return {f: getattr(self, f) for f in self.FIELDS if getattr(self, f) != getattr(d, f)}
 
 
+_CHAIN_STREAMS: dict = {}
+
+
+def chain_streams(device):
+    """The tower's launch-chain streams of ``device``, one set per process: created on the first call with a first (tiny) piece of work
+    on each, so that the HIP runtime binds them to hardware queues THEN. Which queue a stream gets depends on the ORDER of first use
+    across the whole process (HIP: GPU_MAX_HW_QUEUES queues, later streams share); measured on one MI355X
+    (profiles/r05_hwq_probe.txt): chains bound after the multi-GPU exchange's streams were in use cost the evaluator +6 % (eight or
+    sixteen queues) to +21 % (HIP's default four), chains bound before them nothing. ``PolicyValueNet.refresh_inference_copy`` calls
+    this as soon as the first inference copy is on the device -- in every flow before the exchange is first used."""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    got = _CHAIN_STREAMS.get(device)
+    if got is None:
+        got = [torch.cuda.Stream(device=device) for _ in range(7)]
+        cur = torch.cuda.current_stream(device)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        for st in got:
+            st.wait_event(ev)
+            with torch.cuda.stream(st):
+                torch.zeros(1, device=device).add_(1.0)       # a real dispatch: the queue exists from here on
+            done = torch.cuda.Event()
+            done.record(st)
+            cur.wait_event(done)
+        _CHAIN_STREAMS[device] = got
+    return got
+
+
 class InferenceNet(nn.Module):
     """Inference copy of ``Net`` for the lockstep evaluator: BN folded, fp16, channels-last.
 
@@ -251,6 +281,14 @@ class InferenceNet(nn.Module):
     def tower_chains(self, B: int, groups: int = 1, edge: bool = False) -> int:
         """Concurrent launch chains per group (one HIP stream each)."""
         return max(1, min(self.opt.chains or (self.TOWER_CHAINS_EDGE if edge else self.TOWER_CHAINS), 8, -(-B // groups) // 256))
+
+    def bind_chain_streams(self, device):
+        """Give this inference copy the process-wide launch-chain streams of ``device`` (:func:`chain_streams`): created and first used
+        ONCE per process, as early as the first inference copy is built, and reused by every later copy (a weight reload builds a new
+        ``InferenceNet``; new streams at that point would be bound AFTER the exchange's)."""
+        device = torch.device(device)
+        if device.type == "cuda":
+            self._chain_streams = (device, chain_streams(device))
 
     def derived_parameter_names(self) -> set:
         """Names (as in ``named_parameters()``) of the parameters that are pure functions of OTHER parameters of this module -- the
@@ -383,7 +421,7 @@ class InferenceNet(nn.Module):
         if chains > 1:
             pool = getattr(self, "_chain_streams", None)
             if pool is None or pool[0] != x.device or len(pool[1]) < chains - 1:
-                pool = (x.device, [torch.cuda.Stream(device=x.device) for _ in range(7)])
+                pool = (x.device, chain_streams(x.device))
                 self._chain_streams = pool
         live = C.c_void_p(plan[1].data_ptr())
         xp, yp = C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr())
@@ -426,7 +464,7 @@ class InferenceNet(nn.Module):
         if len(bounds) > 1:
             pool = getattr(self, "_chain_streams", None)
             if pool is None or pool[0] != x.device or len(pool[1]) < len(bounds) - 1:
-                pool = (x.device, [torch.cuda.Stream(device=x.device) for _ in range(7)])
+                pool = (x.device, chain_streams(x.device))
                 self._chain_streams = pool
             fork = torch.cuda.Event()
             fork.record(cur)
@@ -696,6 +734,7 @@ class PolicyValueNet:
         self._require_current_fp32("refresh_inference_copy")
         self.policy_value_net.eval()
         self._infer = InferenceNet(self.policy_value_net).to(self.device).eval()
+        self._infer.bind_chain_streams(self.device)   # hardware queues for the tower's launch chains, before anything else asks for streams
         self._graph = None
         self.weights_version += 1
         return self._infer

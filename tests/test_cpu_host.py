@@ -241,3 +241,17 @@ def test_parameters_are_the_references(golden):
     ref = golden["meta"]["parameters"]
     assert ref["C_PUCT"] == 5 and ref["PLAYOUT"] == 1600
     assert {k: getattr(parameters, k) for k in ref} == ref
+
+
+def test_the_package_asks_for_eight_hardware_queues_unless_the_user_chose():
+    """chinesechesszero_amd/__init__.py: GPU_MAX_HW_QUEUES defaults to 8 (the tower's launch chains next to the exchange's streams:
+    DESIGN section 7); a value the user exported wins."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import os, chinesechesszero_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    assert subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True).stdout.strip() == "8"
+    env["GPU_MAX_HW_QUEUES"] = "2"
+    assert subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True).stdout.strip() == "2"

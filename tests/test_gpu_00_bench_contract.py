@@ -359,6 +359,32 @@ def test_fused_gather_on_the_rccl_backend_group_of_one():
     assert r.returncode == 0 and "RCCL_PROBE_OK 128" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
+def test_the_exchange_streams_do_not_serialise_the_towers_launch_chains():
+    """Found in round 5 by running the N>1 path on RCCL in a group of one at full size: the tower's three launch chains shared hardware
+    queues with the process group's stream and the exchange's side stream and ran one after the other -- 26.6 ms per step instead of
+    21.2 (profiles/r05_g1_*.json, r05_h_*.json, r05_hwq_probe.txt). Two remedies, both checked here through profiles/hwq_probe.py (the
+    40x256 evaluator on 4096 rows in a process of its own): the package asks for eight hardware queues at import, and the launch-chain
+    streams are bound when the first inference copy is built (net.chain_streams), before the exchange is first used."""
+    def run(*cfg, queues=None):
+        env = _env()
+        env.pop("GPU_MAX_HW_QUEUES", None)
+        if queues:
+            env["GPU_MAX_HW_QUEUES"] = queues
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "hwq_probe.py")] + list(cfg), cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("HWQ_PROBE")][0][len("HWQ_PROBE "):])
+        d["ms"] = min(d["ms"])
+        return d
+    alone = run("0", "none")
+    bench_order = run("1", "eval_first")               # bench.py: process group, first evaluation, then the first move boundary's exchange
+    cli_order = run("1", "net_then_exchange")          # collector CLI: process group, net built, weights broadcast / exchange, first evaluation
+    assert alone["queues"] == bench_order["queues"] == cli_order["queues"] == "8"      # the package's default reached the HIP runtime's environment
+    assert bench_order["ms"] < 1.03 * alone["ms"] and cli_order["ms"] < 1.03 * alone["ms"], (alone, bench_order, cli_order)
+    four = run("1", "eval_first", queues="4")          # the control: HIP's default (reported, not asserted: driver versions may differ)
+    print("evaluator ms: alone %.2f; behind a process group + used exchange, bench order %.2f, CLI order %.2f; bench order with four queues %.2f"
+          % (alone["ms"], bench_order["ms"], cli_order["ms"], four["ms"]))
+
+
 def test_collect_cli_writes_the_trainer_files(tmp_path):
     """`python -m chinesechesszero_amd.collect` as a user runs it (reference collect.py:188-198 CLI: --show / --model; here also
     --boards / --playout / --moves ...): lockstep self-play on the GPU, harvest, shards, and on exit the converter step."""
