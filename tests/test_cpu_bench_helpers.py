@@ -49,6 +49,17 @@ def test_the_committed_profile_names_its_head_and_holds_no_kernel_that_no_longer
             assert k in names, f"{k}: in the PMC summary, not in {pm['tag']}_kernel_stats.csv"
 
 
+def test_the_committed_profile_is_of_this_code():
+    """The profile bench.py will quote was taken with the code in this tree: whoever changes a kernel, the C ABI, the launch loop or the
+    evaluator re-runs profiles/run_profile.sh (or this test says so). bench.py itself would fall back to its raw HIP-event figure."""
+    from chinesechesszero_amd.build import code_hash
+    with open(os.path.join(ROOT, "profiles", "pmc_summary.json")) as f:
+        pm = json.load(f)
+    assert pm["head"] == code_hash(), (f"profiles/pmc_summary.json was taken with code {pm['head']}, the tree is {code_hash()}: "
+                                       "re-run `bash profiles/run_profile.sh rNN trace fetch write sq` (and the c* passes) on a GPU box")
+    assert "head_warning" not in pm, pm.get("head_warning")
+
+
 def test_code_hash_follows_the_kernel_sources(tmp_path, monkeypatch):
     from chinesechesszero_amd import build
     h0 = build.code_hash()
