@@ -194,6 +194,29 @@ def test_bench_under_the_launcher_with_one_rank_prints_the_single_gpu_line():
     assert a["nodes_peak"] == b["nodes_peak"] and a["roofline"]["k_bar"] == b["roofline"]["k_bar"] and a["roofline"]["d_bar"] == b["roofline"]["d_bar"]
 
 
+def test_bench_group_of_one_on_rccl_and_the_graph_replayed_simulator_line():
+    """Two command shapes the round-5 evidence rests on, kept alive at test size: `--rccl-group-of-one` (the whole N > 1 path -- process
+    group on backend nccl, asynchronous exchange, replay ring -- with ONE rank, i.e. real RCCL collectives on the one GPU) and
+    `--evaluator stub --graph` (the simulator alone, evaluator + k_step replayed as one captured hipGraph per simulation)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "24", "--warmup", "2", "--playout", "16", "--rccl-group-of-one",
+                        "--gather-plies", "1024", "--no-cpu-baseline"] + SMALL, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    j = _json_line(r.stdout)
+    m = j["multi_gpu"]
+    assert j["n_gpus"] == 1 and m["world_size"] == 1 and m["backend"] == "nccl" and "rccl_group_of_one" in m and j["gpu_max_hw_queues"] == "8"
+    assert m["collectives_in_window"] + m["collectives_in_drain"] >= 1 and m["rows_gathered"] >= 22 * 12 * 2 and m["bad_records"] == 0
+    assert m["replay_rows_total"] >= m["rows_gathered"] and m["error_flags_any"] == 0 and "cpu_baseline" not in j
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "48", "--warmup", "2", "--playout", "16", "--evaluator", "stub", "--graph",
+                        "--no-cpu-baseline"] + SMALL, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    j = _json_line(r.stdout)
+    rf = j["roofline"]
+    assert j["config"]["evaluator"] == "stub" and "hipGraph replay" in rf["duration_source"] and rf["avg_launch_us_hip_events_raw"] is None
+    assert 0 < rf["frac"] < 1 and j["move_boundary"]["in_window"] == 3 and j["error_flags_any"] == 0
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--graph"] + SMALL, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--graph is for the simulator-only line" in (r.stdout + r.stderr)
+
+
 def test_bench_refuses_a_gpu_count_that_contradicts_the_launcher():
     env = _env()
     env.update({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
