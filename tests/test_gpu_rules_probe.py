@@ -51,14 +51,13 @@ def _records(path):
     return g, json.loads(str(g["meta"]))
 
 
-def test_host_board_on_the_movegen_kernel_replays_the_probe(probe_files):
+def _replay_on_host_board(preset, golden, real, allow_unsupported=False):
     """Every golden record against chinesechesszero_amd.game.Board (legal moves from ccz_legal_moves, ordered by the installed
-    tables): ids IN ORDER, position, the four predicates, the winner."""
+    tables): ids IN ORDER, position, the four predicates, the winner. AssertionError names the first record that differs."""
     from fake_cchess import parse_fen
     from chinesechesszero_amd import tools
     from chinesechesszero_amd.game import Board
-    preset, golden, real = probe_files
-    tools.set_rules(preset=preset)     # raises if the probe found behaviours no table expresses
+    tools.set_rules(preset=preset, allow_unsupported=allow_unsupported)     # raises if the probe found behaviours no table expresses
     try:
         g, meta = _records(golden)
         for j, rec in enumerate(meta):
@@ -80,7 +79,11 @@ def test_host_board_on_the_movegen_kernel_replays_the_probe(probe_files):
         tools.set_rules()
 
 
-def test_engine_kernels_replay_the_probe(probe_files):
+def test_host_board_on_the_movegen_kernel_replays_the_probe(probe_files):
+    _replay_on_host_board(*probe_files)
+
+
+def _replay_on_engine(preset, golden, real, allow_unsupported=False):
     """The same records through the ENGINE: positions set with ccz_set_position, the recorded moves forced through k_finish_move one
     ply at a time (make-move, clock, repetition chain, game end, winner), then one selection on the fresh root for the kernel-side
     ``legal_moves`` order. over = is_game_over() or is_tie() (game.py:208); winner as game.py:210-219."""
@@ -88,8 +91,7 @@ def test_engine_kernels_replay_the_probe(probe_files):
     from fake_cchess import parse_fen
     from chinesechesszero_amd import _lib, tools
     from chinesechesszero_amd.engine import SelfPlayEngine
-    preset, golden, real = probe_files
-    tools.set_rules(preset=preset)
+    tools.set_rules(preset=preset, allow_unsupported=allow_unsupported)
     L = oracle.lib()                    # (the checker's action table: uci -> id; no rules asked of it)
     names = {}
     for i in range(2086):
@@ -147,6 +149,43 @@ def test_engine_kernels_replay_the_probe(probe_files):
         assert checked == len(meta) and (ended >= 8 or real)
     finally:
         tools.set_rules()
+
+
+def test_engine_kernels_replay_the_probe(probe_files):
+    _replay_on_engine(*probe_files)
+
+
+def test_a_cchess_that_differs_makes_both_replays_fail(tmp_path):
+    """The negative control: a "cchess" that scores stalemate as a draw and never claims the fourfold repetition (what an unmodified
+    python-chess port would do). The probe says so (`unsupported_differences`), the product refuses the preset -- and when it is forced
+    in, the golden file does NOT replay: the host Board and the engine kernels both name a record of exactly those endings. A replay
+    that could not fail would not be evidence the day someone runs it against the real module."""
+    from fake_cchess import make_module
+    from chinesechesszero_amd import tools
+    mod = make_module("oracle")
+    Base = mod.Board
+
+    class Lax(Base):
+        def outcome(self):
+            o = super().outcome()
+            if o is not None and not self.legal_moves and not self.b.in_check():
+                o.winner = None          # stalemate = draw
+            return o
+
+        def is_fourfold_repetition(self):
+            return False                 # never claims the draw at four occurrences
+
+    mod.Board = Lax
+    got, golden = _probe_module().probe(mod, str(tmp_path), n_games=2, plies=8)
+    assert got["unsupported_differences"]
+    files = (str(tmp_path / "preset.json"), str(tmp_path / "cchess_golden.npz"), True)
+    with pytest.raises(ValueError, match="no table expresses"):
+        _replay_on_host_board(*files)
+    for replay in (_replay_on_host_board, _replay_on_engine):
+        with pytest.raises(AssertionError) as err:
+            replay(*files, allow_unsupported=True)
+        assert any(word in str(err.value) for word in ("stalemate", "repetition", "fourfold", "perpetual")), str(err.value)[:300]
+    assert tools.PRESET == "canonical"                                          # (the helpers restore the defaults)
 
 
 def test_product_refuses_a_preset_with_unsupported_differences(tmp_path):
