@@ -121,6 +121,40 @@ PROTOTYPES = {
 _lib = None
 
 
+def source_hash() -> str | None:
+    """16 hex digits over the library's sources as they lie in the tree (the csrc Makefile writes the same digest next to the library when
+    it builds it: ``libcczero.so.srchash``); None where the sources are not there (an installed copy)."""
+    import glob
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.hip")), key=os.path.basename)
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "cczero.h"))
+    if len(files) < 2 or not all(os.path.exists(f) for f in files):
+        return None
+    h = hashlib.sha256()
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def stale_build() -> str | None:
+    """Why the in-tree libcczero.so must not be used (it was built from other sources than the ones in the tree), or None."""
+    if LIB_PATH != os.path.join(_HERE, "libcczero.so"):
+        return None                                  # a diagnostic build chosen with CCZ_LIB: its own business
+    want = source_hash()
+    if want is None:
+        return None
+    stamp = LIB_PATH + ".srchash"
+    if not os.path.exists(stamp):
+        return f"{LIB_PATH} carries no source stamp ({stamp} is missing): it was not built by the current Makefile"
+    with open(stamp) as f:
+        got = f.read().strip()
+    if got != want:
+        return f"{LIB_PATH} was built from other sources (stamp {got}, the tree hashes to {want}): a kernel was edited after the last build"
+    return None
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
@@ -128,6 +162,9 @@ def lib() -> C.CDLL:
             raise CczError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). The engine has no CPU fallback.")
+        why = stale_build()
+        if why:
+            raise CczError(why + " -- rebuild with `python -c 'import __graft_entry__ as g; g.build()'`")
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol

@@ -13,7 +13,11 @@ if ROOT not in sys.path:
 def _ensure_built():
     """A fresh checkout has no libcczero.so (built artefacts are git-ignored): build it once if hipcc is here."""
     so = os.path.join(ROOT, "chinesechesszero_amd", "libcczero.so")
-    if not os.path.exists(so) and os.path.exists("/opt/rocm/bin/hipcc"):
+    stale = False
+    if os.path.exists(so):
+        from chinesechesszero_amd import _lib
+        stale = _lib.stale_build() is not None      # built before the last kernel edit (libcczero.so.srchash vs the sources in the tree)
+    if (stale or not os.path.exists(so)) and os.path.exists("/opt/rocm/bin/hipcc"):
         sys.path.insert(0, ROOT)
         import __graft_entry__
         __graft_entry__.build()

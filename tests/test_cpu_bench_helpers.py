@@ -73,3 +73,26 @@ def test_code_hash_follows_the_kernel_sources(tmp_path, monkeypatch):
     with open(dst / "csrc" / "cczero_kernels.h", "a") as f:
         f.write("\n")
     assert build.code_hash() != h0
+
+
+def test_a_library_older_than_its_sources_is_refused(tmp_path, monkeypatch):
+    """The csrc Makefile stamps libcczero.so with a digest of the sources it was built from; `_lib.lib()` refuses a library whose stamp is
+    not the digest of the sources in the tree (round 5 ran a whole round of GPU calls through a library built before the last kernel edit)."""
+    import shutil
+    from chinesechesszero_amd import _lib
+    assert _lib.stale_build() is None and _lib.source_hash() == open(_lib.LIB_PATH + ".srchash").read().strip()
+    root = tmp_path / "repo"
+    shutil.copytree(os.path.join(ROOT, "chinesechesszero_amd"), root / "chinesechesszero_amd", ignore=shutil.ignore_patterns("__pycache__", ".pytest_cache"))
+    shutil.copytree(os.path.join(ROOT, "include"), root / "include")
+    monkeypatch.setattr(_lib, "_HERE", str(root / "chinesechesszero_amd"))
+    monkeypatch.setattr(_lib, "LIB_PATH", str(root / "chinesechesszero_amd" / "libcczero.so"))
+    assert _lib.stale_build() is None
+    with open(root / "chinesechesszero_amd" / "csrc" / "cczero_kernels.h", "a") as f:
+        f.write("// edited after the build\n")
+    assert "built from other sources" in _lib.stale_build()
+    monkeypatch.setattr(_lib, "_lib", None)
+    import pytest
+    with pytest.raises(_lib.CczError, match="rebuild"):
+        _lib.lib()
+    os.remove(root / "chinesechesszero_amd" / "libcczero.so.srchash")
+    assert "carries no source stamp" in _lib.stale_build()
