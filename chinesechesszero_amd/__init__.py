@@ -15,5 +15,12 @@ import os as _os
 # queues 21.1 (profiles/r05_h_*.json, r05_g1_*.json). The variable is read when the HIP runtime initialises, i.e. at the first device
 # call, not at ``import torch``: importing this package first is early enough. A value set by the user wins.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+try:
+    if int(_os.environ["GPU_MAX_HW_QUEUES"]) < 8:
+        import warnings as _warnings
+        _warnings.warn(f"GPU_MAX_HW_QUEUES={_os.environ['GPU_MAX_HW_QUEUES']} (set by the caller): with fewer than 8 hardware queues the evaluator's "
+                       "launch chains can share queues with the streams of a multi-GPU process group and run ~20 % slower (DESIGN.md section 7)")
+except ValueError:
+    pass
 
 __version__ = "0.1.0"

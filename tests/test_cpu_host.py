@@ -254,4 +254,5 @@ def test_the_package_asks_for_eight_hardware_queues_unless_the_user_chose():
     env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
     assert subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True).stdout.strip() == "8"
     env["GPU_MAX_HW_QUEUES"] = "2"
-    assert subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True).stdout.strip() == "2"
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True)
+    assert r.stdout.strip() == "2" and "fewer than 8 hardware queues" in r.stderr      # respected, and said out loud
