@@ -41,6 +41,13 @@ class TupleSink:
     dtype the reference stores (mcts.py:212 ``np.zeros(2086)`` kept as is by collect.py:157-160); ``pi_dtype=np.float32``
     halves the file. One collector per directory (a pid lock file; a dead collector's lock is taken over and its shards
     adopted). ``finalize`` is journaled: validated before the first write, idempotent after a crash at any point.
+
+    ``append_records`` (round 5) is what the batched collector writes while it runs: the finished games as COMPACT ply records
+    (880 B per ply, ``include/cczero.h`` CCZ_REC_*) instead of the dense rows they stand for (2 x 29,768 B + a float64 pi per
+    ply): 12.5 MB per move of 4096 boards instead of 1.07 GB -- which took the build container's host 10.4 s to convert and
+    write, longer than the move's search on the GPU. ``finalize`` expands the record shards with the GPU expander
+    (``ccz_expand_records``: byte for byte the rows ``ccz_harvest`` writes, tests/test_gpu_harvest.py) before it merges; the
+    reference, too, converts offline (convert.py).
     """
 
     ARRAYS = {"states": ("_s.npy", np.float16, (17, 7, 10, 9)), "mcts": ("_p.npy", None, (2086,)), "winners": ("_z.npy", np.float32, ())}
@@ -49,6 +56,7 @@ class TupleSink:
         self.out_dir = out_dir
         self.pi_dtype = np.dtype(pi_dtype)
         self._shards: list[tuple[str, int]] = []
+        self._rshards: list[tuple[str, int, int, tuple]] = []   # record shards: (path, plies, flags, plane_of_type)
         self._next = 0
         self.games = 0
         os.makedirs(out_dir, exist_ok=True)
@@ -68,8 +76,16 @@ class TupleSink:
         # shards a previous (crashed or still unmerged) collector left behind are part of the data set; a LIVE collector's
         # directory is refused by the lock above
         for name in sorted(os.listdir(out_dir)):
+            if name.startswith(".rshard_") and name.endswith(".npy"):
+                got = self._parse_rshard(os.path.join(out_dir, name))
+                if got is not None:
+                    self._rshards.append(got)
+        unexpanded = tuple(".shard_r" + os.path.basename(p)[len(".rshard_"):-len(".npy")] + "_" for p, _, _, _ in self._rshards)
+        for name in sorted(os.listdir(out_dir)):
             if name.startswith(".shard_") and name.endswith("_z.npy"):
                 base = os.path.join(out_dir, name[:-len("_z.npy")])
+                if unexpanded and name.startswith(unexpanded):
+                    continue   # dense rows of a record shard whose expansion was interrupted: it is still there and will be expanded again
                 if all(os.path.exists(base + sfx) for sfx, _, _ in self.ARRAYS.values()):
                     self._shards.append((base, int(np.load(base + "_z.npy", mmap_mode="r").shape[0])))
 
@@ -150,29 +166,102 @@ class TupleSink:
     def _dtype(self, key):
         return self.pi_dtype if key == "mcts" else np.dtype(self.ARRAYS[key][1])
 
-    def append(self, states, pi, z, games: int = 1):
-        to_np = lambda t: t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
-        s, p, w = to_np(states), to_np(pi), to_np(z)
+    def _write_dense_shard(self, base: str, s, p, w):
+        np.save(base + "_s.npy", s.astype(np.float16, copy=False).reshape(-1, 17, 7, 10, 9))
+        np.save(base + "_p.npy", p.astype(self.pi_dtype, copy=False).reshape(-1, 2086))
+        np.save(base + "_z.npy", w.astype(np.float32, copy=False).reshape(-1))   # (written last: a shard counts once its z file exists)
+        self._shards.append((base, int(len(w))))
+
+    def _count_games(self, games: int):
         self.games += games
-        if len(w):
-            base = os.path.join(self.out_dir, f".shard_{os.getpid()}_{self._next:06d}")
-            while os.path.exists(base + "_z.npy"):
-                self._next += 1
-                base = os.path.join(self.out_dir, f".shard_{os.getpid()}_{self._next:06d}")
-            self._next += 1
-            np.save(base + "_s.npy", s.astype(np.float16, copy=False).reshape(-1, 17, 7, 10, 9))
-            np.save(base + "_p.npy", p.astype(self.pi_dtype, copy=False).reshape(-1, 2086))
-            np.save(base + "_z.npy", w.astype(np.float32, copy=False).reshape(-1))
-            self._shards.append((base, int(len(w))))
         if games:
             tmp = os.path.join(self.out_dir, "collect_state.json.tmp")
             with open(tmp, "w", encoding="utf-8") as f:
                 json.dump({"iters": self.games}, f)
             os.replace(tmp, os.path.join(self.out_dir, "collect_state.json"))
 
+    def append(self, states, pi, z, games: int = 1):
+        to_np = lambda t: t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+        s, p, w = to_np(states), to_np(pi), to_np(z)
+        if len(w):
+            base = os.path.join(self.out_dir, f".shard_{os.getpid()}_{self._next:06d}")
+            while os.path.exists(base + "_z.npy"):
+                self._next += 1
+                base = os.path.join(self.out_dir, f".shard_{os.getpid()}_{self._next:06d}")
+            self._next += 1
+            self._write_dense_shard(base, s, p, w)
+        self._count_games(games)
+
+    # ---- compact record shards (what the batched collector writes while it runs) ----------------------
+    @staticmethod
+    def _parse_rshard(path: str):
+        """(path, plies, flags, plane_of_type) of a record shard, from its NAME (``.rshard_<pid>_<seq>_f<flags>_p<8 digits>.npy``)
+        and its length; None for a file that is not one (e.g. a partial write: np.save goes through a temporary name)."""
+        name = os.path.basename(path)
+        try:
+            parts = name[:-len(".npy")].split("_")
+            flags = int(parts[-2][1:])
+            pot = tuple(int(c) for c in parts[-1][1:])
+            if not (parts[-2].startswith("f") and parts[-1].startswith("p") and len(pot) == 8):
+                return None
+            a = np.load(path, mmap_mode="r")
+            if a.dtype != np.uint8 or a.ndim != 2 or a.shape[1] != 880:
+                return None
+            return (path, int(a.shape[0]), flags, pot)
+        except Exception:
+            return None
+
+    def append_records(self, records, flags: int = 0, plane_of_type=None, games: int = 0):
+        """Finished games as compact ply records: uint8 [P, 880] (torch or numpy; whole games, plies in order -- what
+        ``engine.harvest_record_chunks`` / the exchange hand over). ``flags`` / ``plane_of_type`` = the engine's ``record_flags()`` /
+        ``plane_of_type``: what :func:`engine.expand_records` needs to rebuild the rows at :meth:`finalize`."""
+        rec = records.detach().cpu().numpy() if isinstance(records, torch.Tensor) else np.asarray(records)
+        rec = np.ascontiguousarray(rec, dtype=np.uint8).reshape(-1, 880)
+        pot = (0, 0, 1, 2, 3, 4, 5, 6) if plane_of_type is None else tuple(int(x) for x in plane_of_type)
+        if len(pot) != 8 or max(pot) > 9 or min(pot) < 0:
+            raise ValueError("plane_of_type must be 8 entries in 0..6")
+        if len(rec):
+            tail = f"_f{int(flags)}_p{''.join(str(x) for x in pot)}"
+            path = os.path.join(self.out_dir, f".rshard_{os.getpid()}_{self._next:06d}{tail}.npy")
+            while os.path.exists(path):
+                self._next += 1
+                path = os.path.join(self.out_dir, f".rshard_{os.getpid()}_{self._next:06d}{tail}.npy")
+            self._next += 1
+            tmp = path + ".tmp.npy"
+            np.save(tmp, rec)
+            os.replace(tmp, path)
+            self._rshards.append((path, int(len(rec)), int(flags), pot))
+        self._count_games(games)
+
+    def _expand_record_shards(self):
+        """Record shards -> dense shards, on the GPU (``ccz_expand_records``). A record shard is removed only after ALL its dense
+        shards are written; dense shards carry its name (``.shard_r<tag>_k``), so an expansion that was interrupted is redone from
+        the record shard without counting any row twice."""
+        if not self._rshards:
+            return
+        if not torch.cuda.is_available():
+            from ._lib import CczError
+            raise CczError(f"{self.out_dir}: {len(self._rshards)} record shard(s) ({sum(r[1] for r in self._rshards)} plies) wait for the GPU expander "
+                           "(ccz_expand_records): run finalize() where the collector ran; nothing was changed")
+        from .engine import expand_records, game_aligned_chunks
+        for path, plies, flags, pot in list(self._rshards):
+            tag = os.path.basename(path)[len(".rshard_"):-len(".npy")]
+            prefix = f".shard_r{tag}_"
+            for name in os.listdir(self.out_dir):            # leftovers of an interrupted expansion of THIS shard
+                if name.startswith(prefix):
+                    os.remove(os.path.join(self.out_dir, name))
+            self._shards = [(b, n) for b, n in self._shards if not os.path.basename(b).startswith(prefix)]
+            rec = torch.from_numpy(np.load(path)).cuda()
+            for k, part in enumerate(game_aligned_chunks(rec, 1 << 14)):   # bounds the dense temporary (2^15 rows = 1 GB)
+                s, p, z = expand_records(part.contiguous(), flags, pot)
+                self._write_dense_shard(os.path.join(self.out_dir, f"{prefix}{k:04d}"), s.cpu().numpy(), p.cpu().numpy(), z.cpu().numpy())
+            os.remove(path)
+            self._rshards.remove((path, plies, flags, pot))
+
     def rows(self) -> int:
-        """Rows waiting in shards (not yet merged)."""
-        return int(sum(n for _, n in self._shards))
+        """Rows waiting in shards (not yet merged): dense shards + what the record shards expand to (two rows per ply with mirror images)."""
+        from ._lib import FLAG_NO_MIRROR
+        return int(sum(n for _, n in self._shards) + sum(p * (1 if f & FLAG_NO_MIRROR else 2) for _, p, f, _ in self._rshards))
 
     def finalize(self) -> int:
         """Merge what is on disk with the pending shards (the reference's converter step); returns the total row count.
@@ -181,6 +270,7 @@ class TupleSink:
         naming ``n_old``, ``total`` and the shard files of THIS merge is written first and removed last, so a merge killed at
         any point -- also between ``meta.json`` and the deletion of its shards -- is completed by the next sink exactly once
         (:meth:`_recover`), never repeated; (3) ``meta.json`` changes after the arrays, the shards go after ``meta.json``."""
+        self._expand_record_shards()
         n_old = self._rows_on_disk()
         if n_old != self._merged_rows:
             raise ValueError(f"{self.out_dir}: the arrays hold {n_old} rows, this sink merged {self._merged_rows}: another writer?")
@@ -320,7 +410,8 @@ def write_games_hdf5(records: torch.Tensor, h5_path: str, flags: int = 0, plane_
 class CollectPipeline:
     def __init__(self, init_model=None, n_boards: int = 1, n_playout: int = PLAYOUT, device: int = 0, seed: int = 0,
                  data_dir: str = DATA_DIR, reference_quirks: bool = False, num_channels: int = 256, resblocks_num: int = 40,
-                 finalize_every: int = 0, on_playout=None, max_plies: int = 0, eval_cache_log2: int | None = None, gatherer=None):
+                 finalize_every: int = 0, on_playout=None, max_plies: int = 0, eval_cache_log2: int | None = None, gatherer=None,
+                 dense_shards: bool = False):
         self.board = Board()                       # collect.py:28 (never advanced: source of the turn-plane quirk)
         self.game = Game(self.board, reference_quirks=reference_quirks)
         self.temp = 1.0
@@ -346,6 +437,9 @@ class CollectPipeline:
         self.on_playout = on_playout  # progress sink of the batched path (reference game.py:162-185 feeds a progress bar)
         # several ranks: the exchange of finished games (replay.AsyncRecordExchange / RecordGatherer / TupleGatherer); rank 0 stores the union
         self.gatherer = gatherer
+        # batched path: False (default) = finished games go to disk as compact ply records and are expanded when the sink is finalized;
+        # True = the dense rows themselves while collecting (rounds 1-4: 85 x the bytes through the host per move)
+        self.dense_shards = bool(dense_shards)
 
     def load_model(self):
         """collect.py:48-62: load once; on failure fall back to a random-init net."""
@@ -443,9 +537,15 @@ class CollectPipeline:
             if gatherer is None:
                 if done:
                     first = True
-                    for chunk in self.selfplay.harvest_chunks(1 << 19):
-                        self.sink.append(*chunk, games=done if first else 0)
-                        first = False
+                    if self.dense_shards:   # round 1-4: the dense rows themselves (1.07 GB per move of 4096 boards through the host)
+                        for chunk in self.selfplay.harvest_chunks(1 << 19):
+                            self.sink.append(*chunk, games=done if first else 0)
+                            first = False
+                    else:                   # compact records (12.5 MB per move); TupleSink.finalize expands them on the GPU
+                        e = self.selfplay.engine
+                        for chunk in self.selfplay.harvest_record_chunks(1 << 16):
+                            self.sink.append_records(chunk, e.record_flags(), e.plane_of_type, games=done if first else 0)
+                            first = False
             elif hasattr(gatherer, "post"):
                 # asynchronous exchange (replay.AsyncRecordExchange): this rank never waits for its peers -- the finished games join
                 # its backlog, whatever exchange has completed meanwhile is stored; :meth:`drain_exchange` delivers the rest at the end
@@ -489,12 +589,15 @@ class CollectPipeline:
         from .engine import expand_records, game_aligned_chunks
         e = self.selfplay.engine
         if gatherer.rank == 0:
-            first = True
-            for part in game_aligned_chunks(union.to(e.device), 1 << 14):  # bounds the dense temporary (2^15 rows = 1 GB)
-                self.sink.append(*expand_records(part.contiguous(), e.record_flags(), e.plane_of_type), games=games if first else 0)
-                first = False
-            if first:
-                self.sink.append(e.leaf_input[:0], torch.empty((0, 2086)), torch.empty((0,)), games=games)
+            if not self.dense_shards:   # the records as they are (880 B per ply); TupleSink.finalize expands them on the GPU
+                self.sink.append_records(union, e.record_flags(), e.plane_of_type, games=games)
+            else:
+                first = True
+                for part in game_aligned_chunks(union.to(e.device), 1 << 14):  # bounds the dense temporary (2^15 rows = 1 GB)
+                    self.sink.append(*expand_records(part.contiguous(), e.record_flags(), e.plane_of_type), games=games if first else 0)
+                    first = False
+                if first:
+                    self.sink.append(e.leaf_input[:0], torch.empty((0, 2086)), torch.empty((0,)), games=games)
         else:
             self.sink.games += games
         self.iters = self.sink.games

@@ -222,3 +222,54 @@ def test_the_references_own_dataset_reads_what_the_sink_writes(tmp_path):
     from chinesechesszero_amd.dataset import NpyMemmapDataset
     mine = NpyMemmapDataset(str(tmp_path))
     assert len(mine) == len(ds) and np.array_equal(mine[31][0].numpy(), st)
+
+
+def _fake_records(lengths, seed=0):
+    """Synthetic compact ply records (include/cczero.h CCZ_REC_*): whole games, valid (t, T) headers, random payload."""
+    rs = np.random.RandomState(seed)
+    P = sum(lengths)
+    rec = rs.randint(0, 256, size=(P, 880)).astype(np.uint8)
+    hdr = np.zeros((P, 4), np.uint16)
+    p = 0
+    for T in lengths:
+        for t in range(T):
+            hdr[p] = (t, T, 0, 0)
+            p += 1
+    rec[:, 96:104] = hdr.view(np.uint8).reshape(P, 8)
+    return rec
+
+
+def test_record_shards_are_what_the_batched_collector_writes(tmp_path):
+    """Round 5: while it runs the batched collector writes COMPACT ply records (880 B per ply) -- 85 x fewer bytes through the host
+    than the dense rows (float16 planes + float64 pi) -- and finalize() expands them with the GPU expander. Without a GPU that
+    step says so loudly and changes nothing; a new sink adopts the shards (flags and plane map ride in the file name)."""
+    import pytest
+    import torch
+    from chinesechesszero_amd._lib import CczError, FLAG_NO_MIRROR
+    from chinesechesszero_amd.collect import TupleSink
+    d = str(tmp_path)
+    s = TupleSink(d)
+    a, b = _fake_records((5, 3, 9), 1), _fake_records((4,), 2)
+    s.append_records(torch.from_numpy(a), flags=0, plane_of_type=(0, 0, 6, 1, 2, 3, 4, 5), games=3)
+    s.append_records(b, flags=FLAG_NO_MIRROR, games=1)
+    s.append_records(a[:0], games=2)                                  # games without records (another rank's count): only counted
+    assert s.rows() == 17 * 2 + 4 * 1 and s.games == 6                # mirror images double the rows unless switched off
+    names = sorted(n for n in os.listdir(d) if n.startswith(".rshard_"))
+    assert len(names) == 2 and names[0].endswith("_f0_p00612345.npy") and names[1].endswith(f"_f{FLAG_NO_MIRROR}_p00123456.npy")
+    assert sum(os.path.getsize(os.path.join(d, n)) for n in names) < 21 * 880 + 2 * 200      # 880 B per ply + the .npy headers
+    assert np.array_equal(np.load(os.path.join(d, names[0])), a)
+    if not torch.cuda.is_available():
+        with pytest.raises(CczError, match="GPU expander"):
+            s.finalize()
+        assert sorted(n for n in os.listdir(d) if n.startswith(".rshard_")) == names and not os.path.exists(os.path.join(d, "meta.json"))
+    s.close()
+    s2 = TupleSink(d)                                                 # the next collector adopts the shards and the game count
+    assert s2.rows() == 38 and s2.games == 6 and [r[1:] for r in s2._rshards] == [(17, 0, (0, 0, 6, 1, 2, 3, 4, 5)), (4, FLAG_NO_MIRROR, (0, 0, 1, 2, 3, 4, 5, 6))]
+    # dense shards left by an INTERRUPTED expansion of a record shard that is still there are not adopted (they would count twice)
+    tag = names[0][len(".rshard_"):-len(".npy")]
+    for sfx, arr in (("_s.npy", np.zeros((2, 17, 7, 10, 9), np.float16)), ("_p.npy", np.zeros((2, 2086), np.float64)), ("_z.npy", np.zeros(2, np.float32))):
+        np.save(os.path.join(d, f".shard_r{tag}_0000{sfx}"), arr)
+    s2.close()
+    s3 = TupleSink(d)
+    assert s3.rows() == 38 and s3._shards == []
+    s3.close()

@@ -1,4 +1,6 @@
 """GPU: the host mirror of the reference call surface (tools / mcts / game / collect) on the HIP engine."""
+import os
+
 import numpy as np
 import torch
 import pytest
@@ -132,6 +134,42 @@ def test_collect_pipeline_batched_writes_trainer_format(tmp_path):
     assert states.shape[0] == 16 * 5 * 2  # every board was adjudicated at 5 plies once, mirrored
     assert np.allclose(pi.sum(1), 1.0, atol=1e-4)
     assert cp.iters == 16
+
+
+def test_record_shards_and_dense_shards_give_the_same_trainer_files(tmp_path):
+    """Round 5: the batched collector writes compact ply records while it runs (12.5 MB per move of 4096 boards instead of 1.07 GB of
+    dense rows) and TupleSink.finalize() expands them on the GPU: the trainer's files are byte for byte those of the dense path, also
+    in the reference's quirk mode and when the expansion is redone after an interruption."""
+    from chinesechesszero_amd.collect import CollectPipeline, TupleSink
+    from chinesechesszero_amd.selfplay import BatchedSelfPlay
+    for quirks in (False, True):
+        out = {}
+        for name in ("dense", "records"):
+            d = tmp_path / f"{name}{int(quirks)}"
+            cp = CollectPipeline(init_model=None, n_boards=16, n_playout=4, data_dir=str(d), num_channels=16, resblocks_num=1,
+                                 dense_shards=(name == "dense"), reference_quirks=quirks)
+            torch.manual_seed(4)
+            cp.load_model()
+            cp.selfplay = BatchedSelfPlay(cp.policy_value_net.evaluate_leaves, 16, n_playout=4, max_plies=5, seed=2, reference_quirks=quirks)
+            cp.collect_batched(13)
+            assert cp.sink.rows() == 16 * 5 * 2 * 2 and cp.iters == 32
+            shard_bytes = sum(os.path.getsize(d / f) for f in os.listdir(d) if f.startswith((".shard_", ".rshard_")))
+            if name == "records":
+                assert shard_bytes < 16 * 5 * 2 * 1000                         # 880 B per ply (+ .npy headers)
+                # an expansion that was interrupted after its first dense shard: the next sink starts it again, nothing counts twice
+                cp.sink.close()
+                rs = sorted(f for f in os.listdir(d) if f.startswith(".rshard_"))
+                tag = rs[0][len(".rshard_"):-len(".npy")]
+                for sfx, arr in (("_s.npy", np.zeros((3, 17, 7, 10, 9), np.float16)), ("_p.npy", np.zeros((3, 2086), np.float64)), ("_z.npy", np.zeros(3, np.float32))):
+                    np.save(d / f".shard_r{tag}_0000{sfx}", arr)
+                cp.sink = TupleSink(str(d))
+            else:
+                assert shard_bytes > 16 * 5 * 2 * 2 * 29768
+            assert cp.sink.finalize() == 320
+            assert not [f for f in os.listdir(d) if f.startswith((".shard_", ".rshard_"))]
+            out[name] = [np.load(d / f) for f in ("states.npy", "mcts.npy", "winners.npy")]
+        for a, b in zip(out["dense"], out["records"]):
+            assert a.dtype == b.dtype and np.array_equal(a, b)
 
 
 def test_collect_pipeline_batched_through_the_async_exchange_stores_the_same_rows(tmp_path):
