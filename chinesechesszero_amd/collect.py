@@ -531,7 +531,10 @@ class CollectPipeline:
             if getattr(self, "_viewer", None) is not None:
                 self.selfplay.watch(0, self._viewer)
         for _ in range(n_moves):
-            self.selfplay.run_move(on_playout=self.on_playout)
+            if hasattr(gatherer, "tick_until"):
+                self._run_move_ticking(gatherer)
+            else:
+                self.selfplay.run_move(on_playout=self.on_playout)
             st = self.selfplay.engine.game_status()
             done = int(st["over"].sum())
             if gatherer is None:
@@ -582,6 +585,45 @@ class CollectPipeline:
             self._maybe_finalize()
         self.selfplay.engine.check_healthy()
         return self.iters
+
+    def _run_move_ticking(self, gatherer):
+        """One move of all boards with the asynchronous exchange kept moving meanwhile, as bench.py does it: ``tick()`` from the search's
+        throttled ``on_playout`` callback (every n/100 simulations: an exchange every rank has announced is issued within a few steps,
+        not at this rank's next move boundary -- its kernel would spin on the peers' CUs until then) and ``tick_until`` while the host
+        waits for the GPU in front of the move. An exception raised by the exchange inside the callback (a peer's abort, the
+        announcement timeout) is re-raised here: the search swallows what its callback raises (mcts.py:156-159)."""
+        sp = self.selfplay
+        failed = []
+
+        def store(done):
+            for x in done:
+                self._store_union(x.union, x.games, gatherer)
+
+        def on_playout(k):
+            if self.on_playout is not None:
+                try:
+                    self.on_playout(k)
+                except Exception:
+                    pass
+            if not failed:
+                try:
+                    store(gatherer.tick())
+                except BaseException as exc:   # noqa: BLE001  (kept for the caller: see above)
+                    failed.append(exc)
+
+        def boundary():
+            dev = sp.engine.device
+            if not failed and dev.type == "cuda":
+                caught_up = torch.cuda.Event()
+                caught_up.record(torch.cuda.current_stream(dev))
+                while not caught_up.query():
+                    store(gatherer.tick_until(caught_up))
+            return sp.finish_move()
+
+        moves = sp.advance(sp.n_playout - sp._sim, on_playout=on_playout, boundary=boundary)
+        if failed:
+            raise failed[0]
+        return moves
 
     def _store_union(self, union, games: int, gatherer):
         """Records of ALL ranks' finished games (one exchange): rank 0 rebuilds the dense rows (ccz_expand_records) and appends them

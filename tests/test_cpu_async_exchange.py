@@ -239,3 +239,49 @@ def test_board_partition_prefix_sums():
     assert board_partition(1, 64, 16) == ([16], [0])
     with pytest.raises(ValueError):
         board_partition(2, 64, 0)
+
+
+def test_the_collector_keeps_the_exchange_moving_during_a_move_and_does_not_lose_its_errors():
+    """CollectPipeline._run_move_ticking: tick() from the search's on_playout callback (the search swallows what a callback raises,
+    mcts.py:156-159 -- an exchange error must still reach the caller), the user's own callback still served."""
+    from chinesechesszero_amd.collect import CollectPipeline
+
+    class Engine:
+        device = torch.device("cpu")
+
+    class FakeSelfPlay:
+        n_playout, _sim, engine = 8, 0, Engine()
+
+        def advance(self, steps, on_playout=None, boundary=None):
+            for k in range(steps):
+                try:
+                    on_playout(1)
+                except Exception:
+                    pass                       # what selfplay.advance does with a callback's exception
+            return boundary()
+
+        def finish_move(self):
+            return "moves"
+
+    class FakeExchange:
+        def __init__(self, fail_at=None):
+            self.ticks, self.fail_at = 0, fail_at
+
+        def tick(self):
+            self.ticks += 1
+            if self.fail_at == self.ticks:
+                raise RuntimeError("exchange 3: rank(s) [1] did not announce within 180 s")
+            return []
+
+        def tick_until(self, ev):
+            return []
+
+    cp = CollectPipeline.__new__(CollectPipeline)
+    cp.selfplay, seen = FakeSelfPlay(), []
+    cp.on_playout = lambda k: seen.append(k)
+    ex = FakeExchange()
+    assert cp._run_move_ticking(ex) == "moves" and ex.ticks == 8 and len(seen) == 8
+    ex = FakeExchange(fail_at=3)
+    with pytest.raises(RuntimeError, match="did not announce"):
+        cp._run_move_ticking(ex)
+    assert ex.ticks == 3                                                  # after the failure the exchange is left alone
