@@ -215,6 +215,9 @@ def preroll(e, plies: int, stagger: bool):
     e.check_healthy()
 
 
+LIVE_OVER_PROFILE_BAND = (1.15, 1.4)   # this run's raw HIP-event k_step figure over the committed rocprofv3 average: what an event pair's overhead explains
+
+
 def committed_profile(path: str, head: str, workload: dict):
     """The committed rocprofv3 summary (profiles/pmc_summary.json) IF it describes what this process runs: taken with the same
     code (``head`` == build.code_hash() of the run that was profiled) on the same workload. Returns ``(summary | None, why not |
@@ -665,13 +668,13 @@ def main():
         a_exp = (4 * kbar + 4) + 18 * kbar + 16 * (dbar + 1)
         a_step = a_sel + a_exp
         a_sim_survey = a_step - 3780 + 21420
-        # roofline.frac / achieved = THIS run's algorithmic bytes over k_step's average launch duration:
-        #  (1) the rocprofv3 --kernel-trace --stats average of profiles/<tag>_kernel_stats.csv -- when profiles/pmc_summary.json says it
-        #      was taken with the code this process runs (``head`` == build.code_hash(): kernels, C ABI, launch loop, evaluator) on
-        #      this workload: the profiler's clock has no per-launch overhead, and anyone can recompute the figure from the CSV;
-        #  (2) otherwise the RAW HIP-event figure measured live around every k_step launch of the window on its stream. An event
-        #      pair adds ~9 us to a ~33 us kernel, and nothing is subtracted (round 4 subtracted a separately measured "floor" and
-        #      over-corrected by 6 us): the raw figure is a LOWER bound of the fraction, and named as one.
+        # roofline.frac / achieved = THIS run's algorithmic bytes over k_step's average launch duration MEASURED LIVE by this run: the
+        # median of the HIP-event pairs around every k_step launch of the window, on its stream. An event pair adds ~9 us to a ~33 us
+        # kernel and nothing is subtracted (round 4 subtracted a separately measured "floor" and over-corrected by 6 us): the figure is
+        # a LOWER bound of the fraction, named as one. (Round 5 put the committed rocprofv3 average into the headline when the code
+        # hash matched: a slower or throttled box then still reported the profiled box's fraction -- ADVICE r05.) The committed
+        # profile's duration is quoted under its OWN keys, only when it is of this code and workload AND this run's live figure sits
+        # where an event pair's overhead puts it (1.15 .. 1.4 x the profile's): otherwise k_step, the box or the clock differ.
         head = code_hash()
         ach_raw = a_step * B / t_step if t_step == t_step else 0.0
         traffic = traffic_source = rocprof_ns = pmc_window = None
@@ -690,17 +693,22 @@ def main():
                 # kernel; the committed counter is the average over ALL k_conv3x3* launches (middle and edge alike)
                 net_roofline["traffic"] = per_kernel * net_roofline["chains"] * net_roofline["groups"] * net_roofline["kernel_launches_per_chain_and_layer"] if per_kernel else None
                 net_roofline["traffic_source"] = traffic_source
-        if rocprof_ns:
-            t_used, dur_src = rocprof_ns * 1e-9, (f"rocprofv3 --kernel-trace --stats average of k_step, profiles/{pm.get('tag', 'rNN')}_kernel_stats.csv, "
-                                                  f"taken with this code (head {head}) on this workload")
-        else:
-            t_used, dur_src = (t_step if t_step == t_step else None), ("the whole step by the host clock under hipGraph replay, move boundaries removed (graph launch + k_step: an upper "
-                                                                       "bound of k_step's duration, a lower bound of the fraction)" if graph_step is not None else
-                                                                       "RAW HIP events around every k_step launch of the timed window on its stream (median; "
-                                                                       "the ~9 us an event pair adds are NOT subtracted: a lower bound of the fraction)"
-                                                                       + (f" -- {profile_why}" if profile_why else ""))
+        t_used, dur_src = (t_step if t_step == t_step else None), ("the whole step by the host clock under hipGraph replay, move boundaries removed (graph launch + k_step: an upper "
+                                                                   "bound of k_step's duration, a lower bound of the fraction)" if graph_step is not None else
+                                                                   "LIVE: RAW HIP events around every k_step launch of the timed window on its stream (median; "
+                                                                   "the ~9 us an event pair adds are NOT subtracted: a lower bound of the fraction)")
         ach = a_step * B / t_used if t_used else 0.0
-        live_vs_profile = (t_step / (rocprof_ns * 1e-9)) if (rocprof_ns and t_step == t_step) else None
+        live_vs_profile = (t_step / (rocprof_ns * 1e-9)) if (rocprof_ns and t_step == t_step and graph_step is None) else None
+        frac_profile = us_profile = None
+        if rocprof_ns and live_vs_profile is not None and LIVE_OVER_PROFILE_BAND[0] <= live_vs_profile <= LIVE_OVER_PROFILE_BAND[1]:
+            us_profile, frac_profile = rocprof_ns * 1e-3, a_step * B / (rocprof_ns * 1e-9) / HBM_PEAK
+            profile_note = (f"rocprofv3 --kernel-trace --stats average of k_step in profiles/{pm.get('tag', 'rNN')}_kernel_stats.csv, taken with this code "
+                            f"(head {head}) on this workload; this run's live figure is {live_vs_profile:.2f} x that (an event pair's own cost)")
+        elif rocprof_ns and live_vs_profile is not None:
+            profile_note = (f"the committed profile is of this code and workload, but this run's live k_step figure is {live_vs_profile:.2f} x its duration "
+                            f"(expected {LIVE_OVER_PROFILE_BAND[0]} .. {LIVE_OVER_PROFILE_BAND[1]}): another box, clock or tree shape -- not quoted")
+        else:
+            profile_note = profile_why or ("no per-launch events under hipGraph replay" if graph_step is not None else None)
         # the move boundary, measured: HIP events around finish_move + harvest/restart (+ exchange) and the host wall
         # around the same region (the harvest and the exchange read counts on the host)
         mb_ev = float(np.mean([x.elapsed_time(y) for x, y in boundary["events"]])) if boundary["events"] else None
@@ -739,15 +747,14 @@ def main():
                          "duration_source": dur_src, "avg_launch_us": (t_used or 0) * 1e6,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": a_step * B, "k_bar": kbar, "d_bar": dbar,
-                         # always: the raw live HIP-event figure of this run (a lower bound of the fraction)
+                         # (kept for readers of earlier rounds' lines: the same numbers as frac / avg_launch_us without --graph)
                          "avg_launch_us_hip_events_raw": (t_step * 1e6 if (t_step == t_step and graph_step is None) else None),
                          "frac_hip_events_raw": (ach_raw / HBM_PEAK if graph_step is None else None),
+                         # the committed rocprofv3 profile's duration for k_step, under its own name (None + the reason when it does not apply)
+                         "frac_at_committed_rocprofv3_duration": frac_profile, "avg_launch_us_committed_rocprofv3": us_profile,
+                         "committed_profile_note": profile_note,
                          "code_hash": head, "profile_head": profile_head,
-                         # how far this run's raw event figure sits above the profile's duration (an event pair's own cost is ~1.25x here);
-                         # beyond 1.5x k_step itself has changed since the profile
                          "live_over_profile": live_vs_profile,
-                         "warning": ("this run's k_step (HIP events) is more than 1.5x the committed profile's: re-profile"
-                                     if (live_vs_profile and live_vs_profile > 1.5) else None),
                          # counters and algorithmic bytes of ONE pass (the PMC passes' own timed window): reproducible from profiles/
                          "pmc_window": pmc_window},
             "survey_a_sim_bytes": a_sim_survey,
@@ -765,6 +772,17 @@ def main():
                             "verify": ({"hits_evaluated_again": s1["cache_verified"], "mismatches": s1["cache_verify_mismatches"]} if a.cache_verify else None),
                             "what": "positions evaluated before (this board / another board / another board of the same step) skip the network; "
                                     "the same trees bit for bit (tests/test_gpu_timed_path.py: cache on vs off at 4096 boards, oracle mirror through the planned boundary)"} if planned else None),
+            # Where this engine departs from the reference, COUNTED (VERDICT r05 task 3; strict mode -- CCZ_FLAG_STRICT, what MCTS_AI and
+            # the parity tests run with -- turns the first two into error bits): kept subtrees pruned at re-root time to fit the node
+            # pool (the reference's tree is unbounded, mcts.py:31-39); games adjudicated as draws at max_plies (its game loop has no
+            # cap, game.py:155; the workload string says what max_plies is here and why); table hits of the evaluation cache that were
+            # evaluated again and disagreed (--cache-verify; None without it)
+            "deviations": {"pruned_subtrees_in_window": s1["pruned_subtrees"] - s0["pruned_subtrees"], "pruned_subtrees_total": s1["pruned_subtrees"],
+                           "truncated_games_in_window": s1["truncated_games"] - s0["truncated_games"], "truncated_games_total": s1["truncated_games"],
+                           "games_finished_total": s1["games"], "max_plies": a.max_plies,
+                           "cache_verify_mismatches": (s1["cache_verify_mismatches"] if (planned and a.cache_verify) else None),
+                           "cache_verify_hits_evaluated_again": (s1["cache_verified"] if (planned and a.cache_verify) else None),
+                           "node_pool": {"nodes_peak": s1["nodes_peak"], "what": "pruning starts when a kept subtree exceeds cap - reserve nodes (ccz_config.max_nodes / reserve_nodes)"}},
             "engine_hbm_gb": s1["hbm_bytes"] / 1e9, "nodes_peak": s1["nodes_peak"], "depth_peak": s1["depth_peak"],
             "error_flags_any": err_any,
             "plies": {"start_mean": float(plies0.mean()), "start_max": int(plies0.max()), "end_mean": float(plies1.mean())},

@@ -23,20 +23,24 @@ PLANES = 10710
 REC_BYTES, REC_HDR, REC_IDS, REC_PI = 880, 96, 112, 368  # compact ply record (include/cczero.h CCZ_REC_*)
 HEAD_POL_STRIDE, HEAD_VAL_STRIDE = 1536, 640  # CCZ_HEAD_*_STRIDE: fp16 elements per board of the head kernels' outputs
 
-ABI_VERSION = 6
-CONV_RELU, CONV_DESCENDING, CONV_FORCE_SMALL, CONV_FORCE_TILE, CONV_G16, CONV_G16_EDGE_TILES = 1, 2, 16, 32, 64, 128  # CCZ_CONV_* flag bits
+ABI_VERSION = 7
+CONV_RELU, CONV_DESCENDING, CONV_FORCE_SMALL, CONV_FORCE_TILE, CONV_G16, CONV_G16_EDGE_TILES, CONV_G16_PERSISTENT = 1, 2, 16, 32, 64, 128, 256  # CCZ_CONV_* flag bits
 RULE_PERPETUAL_CHECK = 1
 RULE_PAWN_MOVE_RESETS_CLOCK = 2
 FLAG_REFERENCE_QUIRKS = 1
 FLAG_NO_MIRROR = 2
 FLAG_VALUE_F16 = 4
 FLAG_CACHE_VERIFY = 8
+ERR_PRUNED, ERR_TRUNCATED = 256, 512   # CCZ_ERR_* set in strict mode only
+FLAG_STRICT = 16   # parity mode: pruning a kept subtree / adjudicating at max_plies are error bits, not counters
 LEAF_EXPAND, LEAF_DRAW, LEAF_LOSS, LEAF_SKIP = 0, 1, 2, 3
 
 ERR_BITS = {1: "node pool exhausted (raise max_nodes)", 2: "selection path deeper than max_depth", 64: "history chain overflow (> 128 positions since the last capture)",
             4: "more than 128 legal moves or pseudo-move overflow", 8: "pi record arena overflow",
             16: "forced move is not a child of the root / root not expanded", 32: "NaN priors",
-            128: "index out of bounds (bounds-checked diagnostic build)"}
+            128: "index out of bounds (bounds-checked diagnostic build)",
+            256: "strict mode: a kept subtree was pruned to fit the node pool (the reference's tree is unbounded: raise max_nodes)",
+            512: "strict mode: a game was adjudicated at max_plies (the reference's game has no ply cap: raise max_plies)"}
 
 
 class CczError(RuntimeError):

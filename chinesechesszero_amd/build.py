@@ -23,7 +23,7 @@ def build(verbose: bool = False) -> str:
 
 # what decides the kernels a bench line times and the launches around them: a committed rocprofv3 profile describes a bench run
 # only while these files are the ones it was taken with (bench.py prints the hash, profiles/summarize.py stores it as ``head``)
-_HASHED = ("csrc/*.h", "csrc/*.hip", "csrc/Makefile", "engine.py", "selfplay.py", "net.py", "_lib.py")
+_HASHED = ("csrc/*.h", "csrc/*.hip", "csrc/Makefile", "engine.py", "selfplay.py", "net.py", "_lib.py", "replay.py", "../include/cczero.h", "../bench.py")
 
 
 def code_hash() -> str:

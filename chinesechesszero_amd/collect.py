@@ -80,6 +80,12 @@ class TupleSink:
                 got = self._parse_rshard(os.path.join(out_dir, name))
                 if got is not None:
                     self._rshards.append(got)
+        # Shard names never repeat within a directory: the sequence number starts above every one already used there, by ANY process id
+        # and in ANY of the three name forms. (a restarted collector with the same pid -- usual in containers -- started at
+        # 0 and only looked at `.rshard_` names; the dense shards `.shard_r<pid>_<seq>_..` of an expansion whose record shard was already
+        # gone were adopted below, a new record shard then took their tag, and the next finalize deleted them as "leftovers of an
+        # interrupted expansion of THIS shard": finished games lost.)
+        self._next = self._first_free_seq(os.listdir(out_dir))
         unexpanded = tuple(".shard_r" + os.path.basename(p)[len(".rshard_"):-len(".npy")] + "_" for p, _, _, _ in self._rshards)
         for name in sorted(os.listdir(out_dir)):
             if name.startswith(".shard_") and name.endswith("_z.npy"):
@@ -88,6 +94,19 @@ class TupleSink:
                     continue   # dense rows of a record shard whose expansion was interrupted: it is still there and will be expanded again
                 if all(os.path.exists(base + sfx) for sfx, _, _ in self.ARRAYS.values()):
                     self._shards.append((base, int(np.load(base + "_z.npy", mmap_mode="r").shape[0])))
+
+    @staticmethod
+    def _first_free_seq(names) -> int:
+        """1 + the highest sequence number in the shard names ``.rshard_<pid>_<seq>_..``, ``.shard_r<pid>_<seq>_..`` and
+        ``.shard_<pid>_<seq>_..`` among ``names`` (0 for a directory without shards)."""
+        import re
+        pat = re.compile(r"^\.(?:rshard_|shard_r|shard_)(\d+)_(\d+)[_.]")
+        top = -1
+        for name in names:
+            m = pat.match(name)
+            if m:
+                top = max(top, int(m.group(2)))
+        return top + 1
 
     # ---- one collector per directory ------------------------------------------------------------------
     def _take_lock(self):
@@ -512,6 +531,13 @@ class CollectPipeline:
         """Rows stay in shards while collecting (the reference appends one group per game, collect.py:146-167, and converts
         offline); ``finalize_every`` > 0 merges them into the trainer's .npy files every that many games."""
         if self.finalize_every > 0 and self.sink.games - self._finalized_at >= self.finalize_every:
+            if getattr(self, "gatherer", None) is not None and getattr(self.gatherer, "world", 1) > 1:
+                # a merge on the launch thread of a rank whose peers expect its announcements (and, with a blocking gatherer, its
+                # collective) within launch.DIST_TIMEOUT_S would make THEM fail: several ranks merge once, after the job's last exchange
+                if not getattr(self, "_finalize_every_warned", False):
+                    self._finalize_every_warned = True
+                    log("finalize_every is ignored while an exchange with other ranks is live: the shards are merged once, at the end", "WARNING")
+                return
             self.sink.finalize()
             self._finalized_at = self.sink.games
 
@@ -652,11 +678,19 @@ class CollectPipeline:
         self._maybe_finalize()
         return self.iters
 
-    def run(self, is_shown=False, max_calls: int = 0, viewer=None):
+    def run(self, is_shown=False, max_calls: int = 0, viewer=None, finalize: bool = True):
         """collect.py:178-186: collect until interrupted (``max_calls`` > 0 stops after that many ``collect_data`` calls:
         games on the single-board path, lockstep moves on the batched one). ``is_shown`` (reference ``--show``) pushes the single
         game, or board 0 of the batch, to ``viewer`` -- anything with ``update_board(svg, status)``; the HTTP window itself is not
-        part of the package (``examples/viewer.py``)."""
+        part of the package (``examples/viewer.py``).
+
+        The end of a run. Normal end or Ctrl-C: the exchange is drained (blocking, every rank), then the shards are merged into the
+        trainer's files -- unless ``finalize=False``: a multi-rank job merges AFTER its process group is gone (the CLI below), because
+        rank 0's merge takes minutes for a long collection while its peers would sit in a barrier under the group's 180-s timeout.
+        An exception (a peer's abort, the announcement timeout, an engine error flag): no drain -- it would block for another timeout
+        on peers that will never announce and bury the first error under a second one -- and, with other ranks in the job, no merge:
+        the error goes straight up (``launch.guarded`` ends the process, the launcher the job); the shards stay on disk and the next
+        sink adopts them."""
         if is_shown and self.n_boards > 1:
             if viewer is None:
                 log("--show without a viewer: pass viewer=... (e.g. examples/viewer.py get_chess_window()); nothing is displayed", "WARNING")
@@ -664,16 +698,22 @@ class CollectPipeline:
         elif is_shown and viewer is not None and getattr(self, "game", None) is not None:
             self.game.viewer = viewer   # the one-game-at-a-time loop: Game.graphic pushes every position (game.py:47-75)
         calls = 0
+        multi = self.gatherer is not None and getattr(self.gatherer, "world", 1) > 1
         try:
-            while max_calls <= 0 or calls < max_calls:
-                iters = self.collect_data(is_shown=is_shown)
-                calls += 1
-                log(f"Episode {iters}, steps {self.episode_len}")
-        except KeyboardInterrupt:
-            log("Exit")
-        finally:
+            try:
+                while max_calls <= 0 or calls < max_calls:
+                    iters = self.collect_data(is_shown=is_shown)
+                    calls += 1
+                    log(f"Episode {iters}, steps {self.episode_len}")
+            except KeyboardInterrupt:
+                log("Exit")
             if self.gatherer is not None and hasattr(self.gatherer, "flush_iter") and self.selfplay is not None:
                 self.drain_exchange(self.gatherer)   # every rank's last games reach rank 0's store (blocking; all ranks call it)
+        except BaseException:
+            if not multi:
+                self.sink.finalize()   # one process, nobody waits for it: what was collected is merged before the error goes up
+            raise
+        if finalize:
             self.sink.finalize()
 
 
@@ -723,9 +763,13 @@ if __name__ == "__main__":
         from .launch import guarded
 
         def _job():
-            pipe.run(is_shown=args.show and rank == 0, max_calls=args.moves, viewer=viewer)
+            # the merge (rank 0 expands every record shard on the GPU -- 85x the bytes -- and writes the trainer's files) runs AFTER the
+            # group is gone: under the barrier it kept the peers waiting past the group's timeout for any collection of more than
+            # ~15 moves, and the launcher then killed rank 0 in the middle of it
+            pipe.run(is_shown=args.show and rank == 0, max_calls=args.moves, viewer=viewer, finalize=False)
             torch.distributed.barrier()
             torch.distributed.destroy_process_group()
+            pipe.sink.finalize()
             return 0
         raise SystemExit(guarded(_job))
     pipe.run(is_shown=args.show, max_calls=args.moves, viewer=viewer)

@@ -18,6 +18,7 @@
 #include "cczero_conv_small.h"
 #include "cczero_conv_g16.h"
 #include "cczero_conv_g16e.h"
+#include "cczero_conv_g16p.h"
 #include "cczero_heads.h"
 
 using namespace ccz;
@@ -148,7 +149,7 @@ int ccz_create(const ccz_config *cfg, ccz_engine **out)
     d.board_id_base = cfg->board_id_base;
     // ---- run-time rule tables (ABI 2)
     if ((cfg->flags & CCZ_FLAG_CACHE_VERIFY) && !cfg->eval_cache_log2) { delete e; return fail(-1, "ccz_create: CCZ_FLAG_CACHE_VERIFY without an evaluation cache (eval_cache_log2)"); }
-    if (cfg->flags & ~(CCZ_FLAG_REFERENCE_QUIRKS | CCZ_FLAG_NO_MIRROR | CCZ_FLAG_VALUE_F16 | CCZ_FLAG_CACHE_VERIFY)) { delete e; return fail(-1, "ccz_create: unknown flags 0x%x", cfg->flags); }
+    if (cfg->flags & ~(CCZ_FLAG_REFERENCE_QUIRKS | CCZ_FLAG_NO_MIRROR | CCZ_FLAG_VALUE_F16 | CCZ_FLAG_CACHE_VERIFY | CCZ_FLAG_STRICT)) { delete e; return fail(-1, "ccz_create: unknown flags 0x%x", cfg->flags); }
     if (cfg->eval_cache_log2 && (cfg->eval_cache_log2 < 10 || cfg->eval_cache_log2 > 28)) { delete e; return fail(-1, "ccz_create: eval_cache_log2 must be 0 (no cache) or 10..28"); }
     if (cfg->rule_flags & ~(CCZ_RULE_PERPETUAL_CHECK | CCZ_RULE_PAWN_MOVE_RESETS_CLOCK)) { delete e; return fail(-1, "ccz_create: unknown rule_flags 0x%x", cfg->rule_flags); }
     d.rule_flags = cfg->rule_flags;
@@ -209,6 +210,7 @@ int ccz_create(const ccz_config *cfg, ccz_engine **out)
         ALLOC(d.cache, slots);
         ALLOC(d.claim, slots);
         ALLOC(d.cslot, B);
+        ALLOC(d.ctag, B);
         ALLOC(d.cstate, B);
         ALLOC(d.cins, B);
         ALLOC(d.cver, B);
@@ -791,11 +793,19 @@ static int conv3x3_launch(const char *who, void *stream, const void *x_dev, cons
             HIP_TRY(hipGetLastError());
             return 0;
         }
+        // CCZ_CONV_G16_PERSISTENT: the same tiles on a fixed number of workgroups that walk tile lists (cczero_conv_g16p.h); bits 16..27 =
+        // the number of workgroups (0: one per CU)
+        int pers = (relu & CCZ_CONV_G16_PERSISTENT) ? (((relu >> 16) & 0xfff) ? ((relu >> 16) & 0xfff) : 256) : 0;
+        if (pers && pers < 8) pers = 8; // every XCD that owns tiles needs a workgroup (tile lists are per XCD)
+        if (pers && cin != 256) return fail(-1, "%s: CCZ_CONV_G16_PERSISTENT is the tower shape only (256 input channels)", who);
         if (!(relu & CCZ_CONV_G16_EDGE_TILES) || groups < 2) {
-            CCZ_G16(k_conv3x3_g16, groups * 5, s, fl);
+            if (pers) CCZ_G16(k_conv3x3_g16_pers, groups * 5 < pers ? groups * 5 : pers, s, fl);
+            else CCZ_G16(k_conv3x3_g16, groups * 5, s, fl);
             HIP_TRY(hipGetLastError());
             return 0;
         }
+        if (pers) CCZ_G16(k_conv3x3_g16_pers, groups * 4 < pers ? groups * 4 : pers, s, fl | 4);
+        else
         CCZ_G16(k_conv3x3_g16, groups * 4, s, fl | 4);   // (edge launch first: measured the same, 194.4 / 194.3 k against 194.8 / 194.0 k sims/s)
         HIP_TRY(hipGetLastError());
         CCZ_G16(k_conv3x3_g16_edge, 2 * ((groups + 1) / 2), s, fl);

@@ -68,7 +68,26 @@ struct G5Ctx {
     int a_off;               // weight fragment offset inside a ring slot (tile 0; tile i: + 1024 i)
     int vb[2];               // this lane's pixel-fragment base in slab 0 / 1 (cell 0 of the wave's rank at tap offset 0 = + 9 * 1024)
     int cin, cmask;          // input channels; number of 32-channel chunks - 1
+    // persistent form only (cczero_conv_g16p.h; all SCALAR): xoff[] is then tile-independent and everything that depends on the tile is
+    // derived at its use from these four numbers (a handful of SALU per DMA: kept as ready-made offsets they cost 16 SGPRs and spill)
+    int p0, k;               // the CURRENT tile: first tensor row; ranks 2k, 2k + 1 of its group (2 = no edge rank next to it)
+    int p0n, kn;             // the NEXT tile of this workgroup (the current one again when there is none)
+    int m_w0, m_w3, rows4;   // wave masks: -1 for wave 0 / waves 3..7, else 0; slab row of staging pass 4 (512; waves 4-7: 384 = pass 3 again)
+    int za[2], zb[2];        // this wave's zero stores j = 0, 1 for a tile with k = 0 / k = 4: offset inside a slab, +1 so that 0 = none
 };
+
+// LDS layout of the persistent form: [ring slots 0-2 | slab 0 | ring slots 3-4 | slab 1 | dump]. Between two tiles of a workgroup the next
+// tile's first three weight half-tiles sit in slots 0-2 and its first slab in slab 0; what is left -- slots 3-4, slab 1 and the dump area
+// = one contiguous 76 KB -- holds the epilogue image of ONE rank (144 rows of 528 B), so the epilogue runs in two passes.
+constexpr int kP5Slab0 = 3 * kG5WBytes;                     // 49,152
+constexpr int kP5Ring3 = kP5Slab0 + kG5SlabBytes;           // 86,016: ring slots 3 and 4; also the epilogue image
+constexpr int kP5Slab1 = kP5Ring3 + 2 * kG5WBytes;          // 118,784
+constexpr int kP5Img = kP5Ring3;
+constexpr int kP5Bias = kG5Lds - 1024;                      // the layer's 256 biases (float): behind the image, in the last KB of the dump area
+static_assert(kP5Img + 144 * kG5ERow <= kP5Bias, "persistent layout: the bias copy sits behind the epilogue image");
+static_assert(kP5Slab1 + kG5SlabBytes == kG5Dump, "persistent layout: the dump area stays where it is");
+static_assert(kP5Img + 144 * kG5ERow <= kG5Lds, "persistent layout: one rank's epilogue image must fit behind slab 0");
+__device__ __forceinline__ int p5_ring(int slot) { return slot * kG5WBytes + (slot >= 3 ? kG5SlabBytes : 0); }
 
 __host__ __device__ constexpr bool g5_slab_tap(int t) { return t >= 1 && t <= 5; }
 // DMA loads younger than the weight half-tile the NEXT half-step reads (issue order per half-step: slab piece, 2 weight loads)
@@ -96,9 +115,50 @@ __device__ __forceinline__ void g5_zero_ranks(const G5Ctx &c, int buf)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
+// persistent form. Staging pass `it` of wave w covers slab rows it * 128 + 16 w .. + 15 (waves 4-7 repeat pass 3 in pass 4): rows 0..143
+// are the rank above the tile (pass 0 of every wave, pass 1 of wave 0), rows 432..575 the rank below it (pass 3 of waves 3-7, pass 4).
+// A rank that does not exist (k = 0: above, k = 4: below; zeroed after it has landed) is staged from the tile's own edge rank.
+// The per-thread part of a slab source is the SAME in every pass (xoff[0]: row tid / 4 of the pass's 128, swizzled 16-byte chunk -- the
+// swizzle depends on the row modulo 16 only), so the pass is part of the scalar too: one address register instead of five.
+// Everything here is SCALAR and BRANCH-FREE (a scalar branch inside the loop body costs the register allocation its balance): the
+// conditions on the wave are precomputed masks (G5Ctx::m_*), the conditions on the tile are one compare + select each.
+template <int IT> __device__ __forceinline__ unsigned p5_slab_src(const G5Ctx &c, int p0, int k)
+{
+    const int is0 = k == 0 ? -1 : 0, is4 = k == 4 ? -1 : 0;
+    int fix = 0, rows = IT * 128;
+    if constexpr (IT == 0) fix = 144 & is0;
+    if constexpr (IT == 1) fix = 144 & is0 & c.m_w0;
+    if constexpr (IT == 3) fix = -(144 & is4 & c.m_w3);
+    if constexpr (IT == 4) {
+        fix = -(144 & is4);
+        rows = c.rows4; // waves 4-7 repeat their pass-3 piece
+    }
+    return (unsigned)((p0 - 144 + fix + rows) * c.cin);
+}
+// LDS offset of this wave's zero store j for slab buffer `buf` of a tile with edge index k (the dump KB when it has nothing to zero)
+__device__ __forceinline__ int p5_zero_dst(const G5Ctx &c, int k, int j, int buf)
+{
+    const int is0 = k == 0 ? -1 : 0, is4 = k == 4 ? -1 : 0;
+    const int d = (is0 & c.za[j]) | (is4 & c.zb[j]);       // this wave's piece relative to slab 0, or 0
+    const int real = d != 0 ? -1 : 0;
+    return kG5Dump + (real & (kP5Slab0 - kG5Dump + d - 1 + (buf ? kP5Slab1 - kP5Slab0 : 0)));
+}
+// the slab staged during a tile's LAST chunk is the next tile's first one (buffer 0; the chunk count is even)
+__device__ __forceinline__ void p5_zero_ranks(const G5Ctx &c, int buf, bool next_tile)
+{
+    int l16 = c.lane16, zero = 0;
+    asm volatile("" : "+v"(l16), "+v"(zero));
+    typedef int g5_int4 __attribute__((ext_vector_type(4)));
+    const g5_int4 z = {zero, zero, zero, zero};
+    const int k = next_tile ? c.kn : c.k;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) *(g5_int4 *)(c.lds + (l16 + p5_zero_dst(c, k, j, buf))) = z;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 // One half-step = tap T of a 32-channel chunk; J = its index inside the unrolled pair of chunks (parity of the A register
 // set = J & 1, slab buffer = J / 9).
-template <int J>
+template <int J, bool PERS = false>
 __device__ __forceinline__ void g5_step(const G5Ctx &c, cv_f32x4 (&acc)[4][9], int chunk, int &ring_rd, int &ring_wr,
                                          cv_half8 (&a0)[4], cv_half8 (&a1)[4], cv_half8 (&b)[9])
 {
@@ -149,6 +209,11 @@ __device__ __forceinline__ void g5_step(const G5Ctx &c, cv_f32x4 (&acc)[4][9], i
     if constexpr (g5_slab_tap(T)) { // the next chunk's slab: 5 pieces per thread, in taps 1..5
         constexpr int pass = T - 1;
         const int nxt = (chunk + 1) & c.cmask; // past the last chunk: re-stage chunk 0 into the free buffer (keeps every count static)
+        if constexpr (PERS) { // ... of the workgroup's NEXT tile (of this one again when there is none)
+            const bool last = chunk == c.cmask;
+            const unsigned so = p5_slab_src<pass>(c, last ? c.p0n : c.p0, last ? c.kn : c.k) + (unsigned)(nxt * 32);
+            cv_glds16(c.X + (c.xoff[0] + so), lds + (BUF ? kP5Slab0 : kP5Slab1) + (pass < 4 ? pass * 8192 + c.wave_dst : c.wave_dst4));
+        } else
         cv_glds16(c.X + (c.xoff[pass] + (unsigned)(nxt * 32)), lds + kG5AOff + (1 - BUF) * kG5SlabBytes + (pass < 4 ? pass * 8192 + c.wave_dst : c.wave_dst4));
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -158,7 +223,7 @@ __device__ __forceinline__ void g5_step(const G5Ctx &c, cv_f32x4 (&acc)[4][9], i
         asm volatile("" : "+v"(wo)); // the address is formed here, per half-step: hoisted for 9 taps x 2 pieces it costs 36 registers
         const unsigned o = wo + (unsigned)((T2 + 9 * chunk2) * 8192); // half-tile (chunk2, T2): one contiguous 16 KB block
         const unsigned o2 = o + 4096u;                                 // its rows 128..255
-        unsigned char *const d = lds + ring_wr * kG5WBytes + c.wave_dst;
+        unsigned char *const d = lds + (PERS ? p5_ring(ring_wr) : ring_wr * kG5WBytes) + c.wave_dst;
         cv_glds16(c.W + o, d);
         __builtin_amdgcn_sched_barrier(0);
         G5_CELLS(2, 3)
@@ -169,13 +234,14 @@ __device__ __forceinline__ void g5_step(const G5Ctx &c, cv_f32x4 (&acc)[4][9], i
 
     ring_rd = ring_rd + 1 == kG5Ring ? 0 : ring_rd + 1;
     cv_wait_vm<g5_vmcnt(T)>();
-    if constexpr (T == 7) g5_zero_ranks(c, 1 - BUF); // this thread's slab pieces of the next chunk have landed (all but the youngest weight loads)
+    if constexpr (T == 7 && PERS) p5_zero_ranks(c, 1 - BUF, chunk == c.cmask);
+    else if constexpr (T == 7) g5_zero_ranks(c, 1 - BUF); // this thread's slab pieces of the next chunk have landed (all but the youngest weight loads)
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
     {
-        const unsigned char *wa = lds + (ring_rd * kG5WBytes + c.a_off);
+        const unsigned char *wa = lds + ((PERS ? p5_ring(ring_rd) : ring_rd * kG5WBytes) + c.a_off);
 #pragma unroll
         for (int i = 0; i < 4; ++i) anxt[i] = *(const cv_half8 *)(wa + i * 1024);
         __builtin_amdgcn_sched_barrier(0);

@@ -93,6 +93,7 @@ struct Dev {
     uint32_t cache_mask;
     int32_t *claim;       // [cache_mask + 1] lowest board index that missed on this slot in the current step (INT_MAX: nobody)
     uint32_t *cslot;      // [B] slot of the pending leaf
+    uint32_t *ctag;       // [B] cache_tag of the pending leaf's legal-move list (count | 24-bit hash): compared with the key wherever two leaves are called the same position
     uint8_t *cstate;      // [B] 0 = miss: needs a row of the evaluator, 1 = hit, 2 = no evaluation needed (terminal leaf, none)
     uint8_t *cins;        // [B] this board's fresh evaluation is stored (it is the slot's claim winner)
     uint8_t *cver;        // [B] CCZ_FLAG_CACHE_VERIFY: a hit that is evaluated again and compared with what the table returned

@@ -703,6 +703,7 @@ __global__ __launch_bounds__(64) void k_cache_probe(Dev D)
     const bool verify = hit && (D.flags & 8u) && (mix64(key + 0x632BE59BD9B4E019ull * (uint64_t)st.cache_probes + 0xD1342543DE82EF95ull * (uint64_t)b) & 127ull) == 0ull;
     if (lane == 0) {
         D.cslot[b] = slot;
+        D.ctag[b] = tag;
         D.cstate[b] = hit && !verify ? 1 : 0;
         D.cver[b] = verify ? 1 : 0;
         if (hit) D.vleaf[b] = ev;
@@ -727,15 +728,16 @@ __global__ __launch_bounds__(1024) void k_cache_plan(Dev D, int32_t *miss_rows, 
     // round trips instead of twelve (this kernel is one workgroup: nothing else hides its latency)
     for (int b0 = 0; b0 < D.B; b0 += 4096) {
         int st[4], w[4], rep[4];
-        uint32_t slot[4];
+        uint32_t slot[4], tag[4];
         uint64_t key[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int b = b0 + i * 1024 + tid;
             st[i] = 3;
             slot[i] = 0;
+            tag[i] = 0;
             key[i] = 0;
-            if (b < D.B) { st[i] = D.cstate[b]; slot[i] = D.cslot[b]; key[i] = D.leaf_key[b]; }
+            if (b < D.B) { st[i] = D.cstate[b]; slot[i] = D.cslot[b]; key[i] = D.leaf_key[b]; tag[i] = D.ctag[b]; }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) w[i] = st[i] == 0 ? D.claim[slot[i]] : -1;
@@ -746,7 +748,9 @@ __global__ __launch_bounds__(1024) void k_cache_plan(Dev D, int32_t *miss_rows, 
             // (w < b: a bidder's claim winner is never above it; a CACHE_VERIFY board did not bid, and must not take the row of a
             // higher board -- possibly of a later pass, not assigned yet -- on a full 64-bit key collision)
             if (st[i] == 0 && w[i] >= 0 && w[i] < b) {
-                const bool same = D.cstate[w[i]] == 0 && D.leaf_key[w[i]] == key[i];
+                // the same position = the same 64-bit key AND the same legal-move list (count + 24-bit hash of the list in prior order):
+                // what a table hit is checked against (k_cache_probe), now also between two leaves of one step (round 6)
+                const bool same = D.cstate[w[i]] == 0 && D.leaf_key[w[i]] == key[i] && D.ctag[w[i]] == tag[i];
                 rep[i] = same ? w[i] : b;
             }
         }
@@ -910,6 +914,7 @@ __global__ __launch_bounds__(64) void k_finish_move(Dev D, const int32_t *forced
         // documented cap: the game is adjudicated a draw, its records so far stay valid
         if (lane == 0) {
             if (m.ply < D.max_plies) set_err(D, 8);
+            else if (D.flags & CCZ_FLAG_STRICT) set_err(D, CCZ_ERR_TRUNCATED); // the reference's game has no ply cap (game.py:155)
             m.over = 1; m.winner = -1;
             D.meta[b] = m;
             D.stats[b].truncated += 1;
@@ -1015,7 +1020,10 @@ __global__ __launch_bounds__(64) void k_finish_move(Dev D, const int32_t *forced
             n_new += total;
             __syncthreads();
         }
-        if (pruned && lane == 0) D.stats[b].pruned += (unsigned long long)pruned;
+        if (pruned && lane == 0) {
+            D.stats[b].pruned += (unsigned long long)pruned;
+            if (D.flags & CCZ_FLAG_STRICT) set_err(D, CCZ_ERR_PRUNED); // the reference's tree is unbounded (mcts.py:31-39)
+        }
     }
     if (!keep_tree || n_new == 0) {
         if (lane == 0) { NA[0] = NodeA{0, 0.0f, 1.0f, -1}; NB[0] = 0u; }

@@ -33,13 +33,16 @@ class SelfPlayEngine:
                  reference_quirks: bool = False, mirror: bool = True, reserve_nodes: int = 0,
                  move_rank="tools", plane_of_type="tools", value_f16: bool = False, type_rank="tools",
                  pawn_move_resets_clock="tools", perpetual_check="tools", eval_cache_log2: int = 0,
-                 cache_verify: bool = False):
+                 cache_verify: bool = False, strict: bool = False):
         """``move_rank`` (uint16[2086] permutation, None = ascending id) and ``plane_of_type`` (8 entries, None = type-1)
         are the run-time rule tables of ``ccz_config`` (ABI 2); the default "tools" takes the process-wide choice of
         :func:`chinesechesszero_amd.tools.set_rules`. ``eval_cache_log2`` = n > 0: an evaluation cache of 2^n positions
         (528 B each) for the planned evaluator boundary (:meth:`eval_plan`, ``include/cczero.h`` ccz_eval_plan);
         ``cache_verify``: its debug mode (CCZ_FLAG_CACHE_VERIFY): one hit in 128 is evaluated again and compared bit for bit
-        (``stats()['cache_verified']`` / ``['cache_verify_mismatches']``)."""
+        (``stats()['cache_verified']`` / ``['cache_verify_mismatches']``). ``strict`` (CCZ_FLAG_STRICT): parity mode -- a kept
+        subtree pruned to fit the node pool and a game adjudicated at ``max_plies`` (the reference knows neither: mcts.py:31-39,
+        game.py:155) set sticky error bits that :meth:`check_healthy` raises on, instead of only moving ``pruned_subtrees`` /
+        ``truncated_games``."""
         self.L = _lib.lib()
         if not torch.cuda.is_available():
             raise CczError("no GPU visible to PyTorch-ROCm; the engine has no CPU fallback")
@@ -47,7 +50,8 @@ class SelfPlayEngine:
         self.B = int(n_boards)
         self.n_playout = int(n_playout)
         flags = (_lib.FLAG_REFERENCE_QUIRKS if reference_quirks else 0) | (0 if mirror else _lib.FLAG_NO_MIRROR) \
-            | (_lib.FLAG_VALUE_F16 if value_f16 else 0) | (_lib.FLAG_CACHE_VERIFY if cache_verify else 0)
+            | (_lib.FLAG_VALUE_F16 if value_f16 else 0) | (_lib.FLAG_CACHE_VERIFY if cache_verify else 0) | (_lib.FLAG_STRICT if strict else 0)
+        self.strict = bool(strict)
         # value_f16: Q accumulated in float16 as on the reference's CUDA path
         self.mirror = mirror
         self.reference_quirks = bool(reference_quirks)

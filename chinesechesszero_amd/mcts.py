@@ -87,7 +87,8 @@ class MCTS:
     def _ensure_engine(self):
         if self._engine is None:
             self._engine = SelfPlayEngine(1, n_playout=max(1, self.n_playout), c_puct=self.c_puct, eps=EPS, alpha=ALPHA,
-                                          device=self._device, seed=self._seed, mirror=True)
+                                          device=self._device, seed=self._seed, mirror=True,
+                                          strict=True)   # the reference's tree and game are unbounded: a prune or an adjudication raises here
         return self._engine
 
     def _sync_root(self, board):

@@ -106,9 +106,11 @@ class EvalOptions:
     interleaved pairs on one box, profiles/r04_conv_g16.json); below, the launches get too small: -1.4 % at 3072 boards, -5 % at 2048,
     -14 % at 1024 (where round 3's single launch per layer stays);
     ``CCZ_FUSED_LAST=0`` (fused_last): the head convolutions as a pass of their own over the stored output of the tower instead of in
-    the last layer's epilogue (group-of-16 rows; same bits either way)."""
+    the last layer's epilogue (group-of-16 rows; same bits either way);
+    ``CCZ_CONV_PERSISTENT=N`` (persistent; round 6, A/B): the group-of-16 tower layers on N persistent workgroups per launch that walk
+    tile lists (k_conv3x3_g16_pers, csrc/cczero_conv_g16p.h; same bits); 0 = one tile per workgroup (default)."""
 
-    FIELDS = ("fused_conv", "fused_stem", "fused_heads", "fused_last", "layout", "force", "groups", "chains", "zigzag", "edge_tiles")
+    FIELDS = ("fused_conv", "fused_stem", "fused_heads", "fused_last", "layout", "force", "groups", "chains", "zigzag", "edge_tiles", "persistent")
 
     def __init__(self, env=None):
         env = os.environ if env is None else env
@@ -123,6 +125,7 @@ class EvalOptions:
         self.zigzag = env.get("CCZ_CONV_ZIGZAG", "1") == "1"
         # group-of-16 layout: ranks 0 / 9 on the edge-pair kernel (round 4): "auto" = from 4096 boards on, together with three launch chains
         self.edge_tiles = {"0": False, "1": True}.get(env.get("CCZ_CONV_EDGE_TILES", "auto"), "auto")
+        self.persistent = int(env.get("CCZ_CONV_PERSISTENT", "0"))
         if self.layout not in ("auto", "nhwc", "g16"):
             raise ValueError("CCZ_CONV_LAYOUT must be auto, nhwc or g16")
 
@@ -417,7 +420,7 @@ class InferenceNet(nn.Module):
             cap = -(-(B // 16) // n_parts) * 1440            # whole 16-board groups (B is padded to a multiple of 16)
         else:
             cap = -(-(-(-B // n_parts)) // 8) * 8 * 90       # pixels of the largest range a launch may get
-        lay = (_lib.CONV_G16 | (_lib.CONV_G16_EDGE_TILES if edge else 0)) if g16 else 0
+        lay = (_lib.CONV_G16 | (_lib.CONV_G16_EDGE_TILES if edge else 0) | self._persistent_flag()) if g16 else 0
         if chains > 1:
             pool = getattr(self, "_chain_streams", None)
             if pool is None or pool[0] != x.device or len(pool[1]) < chains - 1:
@@ -480,7 +483,7 @@ class InferenceNet(nn.Module):
         # alternates from layer to layer: what the previous layer wrote last (still in the Infinity Cache) is read
         # first (-0.7 % on the step; zigzag=False / CCZ_CONV_ZIGZAG=0 switches it off).
         down = 2 if self.opt.zigzag else 0
-        v2 = self.opt.force | ((_lib.CONV_G16 | (_lib.CONV_G16_EDGE_TILES if edge else 0)) if g16 else 0)
+        v2 = self.opt.force | ((_lib.CONV_G16 | (_lib.CONV_G16_EDGE_TILES if edge else 0) | self._persistent_flag()) if g16 else 0)
         wsrc = self.ws_g16 if g16 else self.ws
         for i in range(0, len(self.ws), 2):
             w1, b1_, w2, b2_ = (C.c_void_p(t.data_ptr()) for t in (wsrc[i], self.bs32[i], wsrc[i + 1], self.bs32[i + 1]))
@@ -499,6 +502,12 @@ class InferenceNet(nn.Module):
             join = torch.cuda.Event()
             join.record(st)
             cur.wait_event(join)
+
+    def _persistent_flag(self) -> int:
+        """A/B switch ``persistent`` (``CCZ_CONV_PERSISTENT=N``): flag bits that run a group-of-16 tower layer on N persistent workgroups."""
+        from . import _lib
+        n = self.opt.persistent
+        return (_lib.CONV_G16_PERSISTENT | ((n & 0xfff) << 16)) if n > 0 else 0
 
     def _force_flag(self) -> int:
         """A/B switch ``force`` (``CCZ_CONV_FORCE=small|tile``): run every convolution on k_conv3x3_small / on the 256-pixel tile
@@ -818,6 +827,7 @@ class PolicyValueNet:
 
     def train_step(self, state_batch, mcts_probs, winner_batch, lr=0.002):
         """net.py:212-247 (plain PyTorch; the trainer is a consumer of the rollout path, not part of it)."""
+        self._require_current_fp32("train_step")
         self.policy_value_net.train()
         to = lambda t: (t if isinstance(t, torch.Tensor) else torch.as_tensor(np.asarray(t))).to(self.device, dtype=torch.float)
         state_batch, mcts_probs, winner_batch = to(state_batch), to(mcts_probs), to(winner_batch)

@@ -32,6 +32,7 @@ class Trainer:
         self.steps = 0
 
     def step(self, states: torch.Tensor, pi: torch.Tensor, z: torch.Tensor, sync: bool = True) -> dict:
+        self.pvn._require_current_fp32("Trainer.step")   # a rank that received only the inference copy holds OLD fp32 weights
         self.net.train()
         dev = next(self.net.parameters()).device
         states, pi, z = states.to(dev).float(), pi.to(dev).float(), z.to(dev).float()

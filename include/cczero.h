@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define CCZ_ABI_VERSION 6
+#define CCZ_ABI_VERSION 7
 #define CCZ_NSQ 90
 #define CCZ_SQ_STRIDE 96            /* mailbox row stride in bytes (90 squares + 6 pad)         */
 #define CCZ_NMOVES 2086             /* action space, reference tools.py:172-272                 */
@@ -75,6 +75,13 @@ extern "C" {
                                         again and its fresh priors / value are compared, bit for bit, with what the table
                                         returned (ccz_stats.cache_verified / cache_verify_mismatches). Results are unchanged;
                                         the evaluator computes ~0.8 % of the hits again. Needs eval_cache_log2 > 0           */
+
+#define CCZ_FLAG_STRICT 16u          /* parity mode (ABI 7): the two places where this engine silently departs from the reference become
+                                        sticky error bits instead of counters -- a kept subtree that had to be pruned to fit the node
+                                        pool (CCZ_ERR_PRUNED; the reference's tree is unbounded, mcts.py:31-39) and a game adjudicated
+                                        at max_plies (CCZ_ERR_TRUNCATED; the reference's game ends by the rules only, game.py:155).
+                                        The search results are what they are without the flag; MCTS_AI, the UCI loop and the parity
+                                        tests run with it, the throughput paths (bench, collector) count and report instead          */
 
 /* leaf status written by ccz_select_leaves */
 #define CCZ_LEAF_EXPAND 0 /* non-terminal: children are created from the evaluator's priors */
@@ -158,6 +165,8 @@ typedef struct ccz_stats {
 #define CCZ_ERR_BAD_MOVE 16   /* forced move id invalid / nothing searched and nothing forced    */
 #define CCZ_ERR_NAN 32        /* NaN priors: no comparable child during selection                */
 #define CCZ_ERR_BOUNDS 128    /* bounds-checked diagnostic build only (-DCCZ_BOUNDS): an index left its array      */
+#define CCZ_ERR_PRUNED 256    /* CCZ_FLAG_STRICT: a kept subtree lost nodes at re-root time (raise max_nodes / lower reserve_nodes) */
+#define CCZ_ERR_TRUNCATED 512 /* CCZ_FLAG_STRICT: a game reached max_plies and was adjudicated a draw (raise max_plies)            */
 
 /* ---- library ---------------------------------------------------------------------------- */
 int ccz_abi_version(void);
@@ -382,6 +391,10 @@ int ccz_bias_act_f16(void *stream, void *y_dev, const void *bias_dev, const void
                                        zeroed ranks. Same values; -3 % per layer at 4096 boards in isolation; in the workload it pays only
                                        with three launch chains and from ~4096 boards on (+0.7...0.9 % sims/s), where the evaluator
                                        sets it (InferenceNet edge_tiles=auto); smaller launches lose (profiles/r04_conv_g16.json) */
+#define CCZ_CONV_G16_PERSISTENT 256 /* with CCZ_CONV_G16 (round 6, opt-in, 256 input channels): the same tiles on a FIXED number of workgroups
+                                       that walk tile lists -- no prologue after a workgroup's first tile, the next tile's operands arrive
+                                       while the epilogue's stores drain (csrc/cczero_conv_g16p.h). Bits 16..27 of the flag word = number of
+                                       workgroups (0 = 256, one per CU). Same values */
 int ccz_conv3x3_c256_f16(void *stream, const void *x_dev, const void *w_dev, const void *bias_f32_dev,
                          const void *residual_dev, void *y_dev, int64_t n_pixels, int32_t relu);
 /* Weights for the CCZ_CONV_G16 form, once per weight set: w [256, 3, 3, cin] fp16 (cin = 256: tower, 64: stem) ->

@@ -285,3 +285,63 @@ def test_the_collector_keeps_the_exchange_moving_during_a_move_and_does_not_lose
     with pytest.raises(RuntimeError, match="did not announce"):
         cp._run_move_ticking(ex)
     assert ex.ticks == 3                                                  # after the failure the exchange is left alone
+
+
+def test_the_collector_ends_a_run_in_the_right_order():
+    """CollectPipeline.run: a normal end drains the exchange, then merges -- or leaves the merge to the caller
+    (finalize=False: the multi-rank CLI merges after its process group is gone, so no peer waits in a barrier for rank 0's minutes
+    of expansion); an error inside a multi-rank run goes straight up -- no blocking drain on peers that will never announce, no
+    second error over the first, no merge; a single process still merges what it has; finalize_every is ignored while an
+    exchange with other ranks is live."""
+    from chinesechesszero_amd.collect import CollectPipeline
+
+    class Sink:
+        def __init__(self):
+            self.calls, self.games = [], 0
+
+        def finalize(self):
+            self.calls.append("finalize")
+
+    class Exchange:
+        def __init__(self, world):
+            self.world, self.calls = world, []
+
+        def flush_iter(self):
+            self.calls.append("drain")
+            return iter(())
+
+    def pipe(world, fail_at=None, finalize_every=0):
+        cp = CollectPipeline.__new__(CollectPipeline)
+        cp.sink, cp.gatherer, cp.selfplay, cp.n_boards, cp.episode_len = Sink(), (Exchange(world) if world else None), object(), 64, 0
+        cp.finalize_every, cp._finalized_at, cp.iters, n = finalize_every, 0, 0, [0]
+
+        def collect_data(is_shown=False):
+            n[0] += 1
+            if fail_at == n[0]:
+                raise RuntimeError("exchange 3: rank(s) [1] did not announce within 180 s")
+            cp.sink.games += 10
+            cp._maybe_finalize()
+            return n[0]
+        cp.collect_data = collect_data
+        return cp
+
+    cp = pipe(world=2)
+    cp.run(max_calls=3)
+    assert cp.gatherer.calls == ["drain"] and cp.sink.calls == ["finalize"]
+    cp = pipe(world=2)
+    cp.run(max_calls=3, finalize=False)                    # the CLI: barrier + destroy_process_group come next, THEN sink.finalize()
+    assert cp.gatherer.calls == ["drain"] and cp.sink.calls == []
+    cp = pipe(world=2, fail_at=2)
+    with pytest.raises(RuntimeError, match="did not announce"):
+        cp.run(max_calls=3)
+    assert cp.gatherer.calls == [] and cp.sink.calls == []  # straight up: launch.guarded ends the process
+    cp = pipe(world=0, fail_at=2)
+    with pytest.raises(RuntimeError):
+        cp.run(max_calls=3)
+    assert cp.sink.calls == ["finalize"]                   # one process: what was collected is merged before the error goes up
+    cp = pipe(world=2, finalize_every=10)
+    cp.run(max_calls=3, finalize=False)
+    assert cp.sink.calls == []                             # no merge on the launch thread while peers expect announcements
+    cp = pipe(world=0, finalize_every=10)
+    cp.run(max_calls=3)
+    assert cp.sink.calls == ["finalize"] * 4               # one process: every 10 games, and at the end

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(L, name), name
         assert name in _lib.PROTOTYPES, f"{name} not bound in _lib.PROTOTYPES"
     assert set(_lib.PROTOTYPES) == declared
-    assert L.ccz_abi_version() == 6 == _lib.ABI_VERSION   # ABI 5: ccz_leaf_priors, CCZ_FLAG_CACHE_VERIFY + two ccz_stats counters; ABI 6: ccz_conv3x3_c256_heads_f16, ccz_fc_f16 relu bits 1 / 2
+    assert L.ccz_abi_version() == 7 == _lib.ABI_VERSION   # ABI 7: CCZ_FLAG_STRICT + CCZ_ERR_PRUNED / _TRUNCATED, CCZ_CONV_G16_PERSISTENT; ABI 5: ccz_leaf_priors, CCZ_FLAG_CACHE_VERIFY + two ccz_stats counters; ABI 6: ccz_conv3x3_c256_heads_f16, ccz_fc_f16 relu bits 1 / 2
     assert ctypes.sizeof(_lib.Config) == 96 and ctypes.sizeof(_lib.Stats) == 152      # ABI 3: four evaluation-cache counters appended; ABI 5: two verify counters
     # ABI 2 fields sit where include/cczero.h puts them (pointer at 64, plane map at 72, rule flags at 80); ABI 3 gives the word
     # behind rule_flags a meaning (eval_cache_log2) without moving anything

@@ -170,7 +170,10 @@ def _bcast_worker(rank, world, port, what, q):
         guarded = None
         if what == "inference":
             guarded = []
-            for call in (pvn.refresh_inference_copy, lambda: pvn.save_model(os.devnull)):
+            from chinesechesszero_amd.trainer import Trainer
+            batch = (torch.zeros(2, 119, 10, 9), torch.full((2, 2086), 1.0 / 2086), torch.zeros(2))
+            for call in (pvn.refresh_inference_copy, lambda: pvn.save_model(os.devnull), lambda: pvn.train_step(*batch),
+                         lambda: Trainer(pvn).step(*batch)):      # ... and training the old weights
                 try:
                     call()
                     guarded.append(False)
@@ -206,4 +209,4 @@ def test_weight_broadcast_is_one_collective_of_one_flat_buffer(what):
     assert all(r[6] for r in res)                              # weights_version moved: evaluation caches keyed to it are emptied
     if what == "inference":
         assert res[1][5]                                       # in place: what captured hipGraphs point at is still valid
-        assert res[1][7] == [True, True] and res[0][7] == [False, False]   # the receiver is guarded, the source (whose fp32 IS the truth) is not
+        assert res[1][7] == [True] * 4 and res[0][7] == [False] * 4   # the receiver is guarded, the source (whose fp32 IS the truth) is not

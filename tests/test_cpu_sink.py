@@ -273,3 +273,28 @@ def test_record_shards_are_what_the_batched_collector_writes(tmp_path):
     s3 = TupleSink(d)
     assert s3.rows() == 38 and s3._shards == []
     s3.close()
+
+
+def test_a_restarted_collector_never_reuses_a_shard_tag(tmp_path):
+    """an expansion that crashed after removing a record shard leaves complete dense shards `.shard_r<pid>_<seq>_..`
+    whose record shard is gone. The next sink adopts them -- and, started with the SAME pid (usual in containers), must not hand their
+    tag to a new record shard: the following finalize would delete them as 'leftovers of an interrupted expansion of THIS shard'."""
+    from chinesechesszero_amd.collect import TupleSink
+    d = str(tmp_path)
+    pid = os.getpid()
+    tag = f"{pid}_000000_f0_p00123456"
+    for k in range(2):                                                  # dense shards of record shard 000000; the record shard itself is gone
+        for sfx, arr in (("_s.npy", np.zeros((3, 17, 7, 10, 9), np.float16)), ("_p.npy", np.full((3, 2086), 1.0 / 2086)), ("_z.npy", np.ones(3, np.float32))):
+            np.save(os.path.join(d, f".shard_r{tag}_{k:04d}{sfx}"), arr)
+    np.save(os.path.join(d, f".shard_{pid + 1}_000004_z.npy"), np.zeros(0, np.float32))   # (an incomplete dense shard of another pid: its number counts too)
+    s = TupleSink(d)
+    assert s.rows() == 6 and len(s._shards) == 2 and s._next == 5      # above every number used in the directory, whatever the name form
+    s.append_records(_fake_records((4,), 3), games=1)
+    s.append(np.zeros((1, 17, 7, 10, 9), np.float16), np.full((1, 2086), 1.0 / 2086), np.zeros(1, np.float32), games=1)
+    new = sorted(n for n in os.listdir(d) if n.startswith(".rshard_") or n.startswith(f".shard_{pid}_"))
+    assert new[0].startswith(f".rshard_{pid}_000005_") and new[1].startswith(f".shard_{pid}_000006_")
+    # what the next finalize treats as leftovers of an interrupted expansion of the NEW record shard: nothing that exists
+    prefix = ".shard_r" + new[0][len(".rshard_"):-len(".npy")] + "_"
+    assert not [n for n in os.listdir(d) if n.startswith(prefix)]
+    assert TupleSink._first_free_seq([]) == 0 and TupleSink._first_free_seq(["states.npy", ".shard_7_000010_s.npy", ".rshard_7_000002_f0_p00123456.npy"]) == 11
+    s.close()

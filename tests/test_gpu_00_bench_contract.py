@@ -269,9 +269,10 @@ def test_bench_single_gpu_line_contract():
     assert mb["ms_events"] > 0 and mb["ms_host"] > 0 and j["moves_per_sec"] > 0
     # this small workload is not the profiled one: the fraction is THIS run's raw HIP-event figure (nothing subtracted: a lower bound),
     # and the line says which code it ran and why the committed profile does not apply
-    assert "RAW HIP events" in rf["duration_source"] and "another workload" in rf["duration_source"]
+    assert "LIVE" in rf["duration_source"] and "RAW HIP events" in rf["duration_source"] and "another workload" in rf["committed_profile_note"]
     assert rf["avg_launch_us"] == rf["avg_launch_us_hip_events_raw"] > 0 and rf["frac"] == rf["frac_hip_events_raw"]
-    assert len(rf["code_hash"]) == 16 and "profile_head" in rf and rf["live_over_profile"] is None and rf["warning"] is None
+    assert rf["frac_at_committed_rocprofv3_duration"] is None and rf["avg_launch_us_committed_rocprofv3"] is None
+    assert len(rf["code_hash"]) == 16 and "profile_head" in rf and rf["live_over_profile"] is None
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     # the split net / rules / tree of a CPU playout, and the same loop with a constant-time stub evaluator
@@ -285,6 +286,9 @@ def test_bench_single_gpu_line_contract():
     assert "in the window" in nr["duration_source"] and nr["launches_per_step"] * nr["avg_launch_us"] <= j["ms_per_step"] * 1e3
     assert nr["rows_per_launch"] <= 256 and 0 < nr["frac_full_batch"] < 1
     assert j["error_flags_any"] == 0
+    dv = j["deviations"]                     # where the engine departs from the reference, counted in the line itself
+    assert dv["pruned_subtrees_in_window"] == 0 and dv["pruned_subtrees_total"] == 0 and dv["cache_verify_mismatches"] is None
+    assert 0 <= dv["truncated_games_in_window"] <= dv["truncated_games_total"] <= dv["games_finished_total"] and dv["max_plies"] > 0
     assert j["plies"]["start_mean"] > 3
 
 

@@ -388,6 +388,54 @@ def test_group_of_16_kernel_gives_the_tile_kernels_values(boards):
                                   (boards - 1) * 90, 1 | _lib.CONV_G16) != 0
 
 
+@pytest.mark.parametrize("boards,nwg", [(16, 0), (80, 8), (96, 16), (272, 24), (272, 40), (1024, 0), (1040, 248)])
+def test_persistent_group_of_16_kernel_is_bit_identical(boards, nwg):
+    """k_conv3x3_g16_pers (CCZ_CONV_G16_PERSISTENT: a fixed number of workgroups walking tile lists, the next tile's slab staged during
+    the last chunk, two-pass epilogue, missing ranks staged from the tile's own edge rank) against k_conv3x3_g16: the same bits -- one
+    to seven tiles per workgroup, fewer tiles than workgroups, with and without residual / ReLU, both tile orders, output over the
+    residual, the middle launch of the edge-pair form, and the planned boundary cut into parts."""
+    from chinesechesszero_amd import _lib
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(700 + boards)
+    cl = torch.channels_last
+    L = _lib.lib()
+    s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    x = torch.relu(torch.randn(boards, 256, 10, 9, generator=g) * 0.7).to(dev).half().contiguous(memory_format=cl)
+    r = (torch.randn(boards, 256, 10, 9, generator=g) * 0.7).to(dev).half().contiguous(memory_format=cl)
+    w = (torch.randn(256, 256, 3, 3, generator=g) * 0.03).to(dev).half().contiguous(memory_format=cl)
+    b = (torch.randn(256, generator=g) * 0.2).to(dev)
+    xg, rg = _to_g16(x), _to_g16(r)
+    wp = _pack_w(w.permute(0, 2, 3, 1), 256)
+    P = _lib.CONV_G16 | _lib.CONV_G16_PERSISTENT | (nwg << 16)
+
+    def run(flags, res, y):
+        _lib.check(L.ccz_conv3x3_c256_f16(s, C.c_void_p(xg.data_ptr()), C.c_void_p(wp.data_ptr()), C.c_void_p(b.data_ptr()),
+                                          C.c_void_p(res.data_ptr()) if res is not None else None, C.c_void_p(y.data_ptr()), boards * 90, flags))
+        return y
+
+    for res, relu in ((None, 1), (rg, 1), (None, 0), (rg, 3), (None, 3)):
+        want = run(relu | _lib.CONV_G16, res, torch.full_like(xg, float("nan")))
+        got = run(relu | P, res, torch.full_like(xg, float("nan")))
+        assert torch.equal(got, want), (boards, nwg, res is not None, relu, (got.float() - want.float()).abs().max().item())
+        got = run(relu | P | _lib.CONV_G16_EDGE_TILES, res, torch.full_like(xg, float("nan")))   # persistent middle launch + edge-pair launch
+        assert torch.equal(got, want), (boards, nwg, res is not None, relu, "edge")
+    want = run(1 | _lib.CONV_G16, rg, torch.empty_like(xg))
+    y = rg.clone()
+    assert torch.equal(run(1 | P, y, y), want)       # output written over the residual (how the tower uses it)
+    # the planned boundary: live boards cut into parts, every part a persistent launch
+    for live, n_parts in ((0, 1), (1, 1), (boards - 3, 2), (boards, 3)):
+        n_live = torch.tensor([live], dtype=torch.int32, device=dev)
+        yg = torch.full_like(xg, float("nan"))
+        cap = -(-(boards // 16) // n_parts) * 1440
+        for part in range(n_parts):
+            _lib.check(L.ccz_conv3x3_c256_f16_live(s, C.c_void_p(xg.data_ptr()), C.c_void_p(wp.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(rg.data_ptr()),
+                                                   C.c_void_p(yg.data_ptr()), cap, 1 | P | (2 if part & 1 else 0), C.c_void_p(n_live.data_ptr()), part, n_parts))
+        groups = -(-live // 16)
+        assert torch.equal(yg[:groups], want[:groups])
+        assert torch.isnan(yg[groups:].float()).all()
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("edge", [0, 1])
 @pytest.mark.parametrize("live,n_parts", [(0, 1), (1, 1), (16, 2), (17, 1), (100, 3), (160, 4)])
 def test_group_of_16_kernel_live_rows(live, n_parts, edge):

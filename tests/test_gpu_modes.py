@@ -207,6 +207,53 @@ def test_reroot_budget_prunes_deepest_levels_instead_of_failing():
     e.check_healthy()
 
 
+def test_strict_mode_turns_pruning_and_adjudication_into_errors():
+    """CCZ_FLAG_STRICT (round 6): where the throughput paths only COUNT a departure from the reference -- a kept subtree pruned to fit the
+    node pool (the reference's tree is unbounded, mcts.py:31-39), a game adjudicated at max_plies (its game loop has no cap,
+    game.py:155) -- the parity mode sets a sticky error bit and check_healthy() raises. Same workloads as the two counting tests."""
+    from chinesechesszero_amd import _lib
+    from chinesechesszero_amd._lib import CczError
+    from chinesechesszero_amd.engine import SelfPlayEngine
+    from chinesechesszero_amd.net import uniform_evaluator
+    from test_gpu_soak import LinearEvaluator
+    # (a) pruning: the workload of test_reroot_budget_prunes_deepest_levels_instead_of_failing
+    B, n = 6, 300
+    ev = LinearEvaluator(torch.device("cuda", 0), seed=2, sharp=14.0)
+    e = SelfPlayEngine(B, n_playout=n, max_nodes=40000, reserve_nodes=37000, seed=3, strict=True)
+    for move in range(6):
+        leaf = e.select_leaves()
+        for i in range(n):
+            p, v = ev(leaf)
+            leaf = e.step(p, v) if i + 1 < n else e.expand_backup(p, v)
+        rc = e.root_children()
+        forced = np.array([rc["acts"][b][int(np.argmax(rc["visits"][b][:rc["k"][b]]))] for b in range(B)], np.int32)
+        e.finish_move(forced_moves=forced)
+        if e.stats()["pruned_subtrees"]:
+            break
+    st = e.stats()
+    assert st["pruned_subtrees"] > 0 and st["error_flags"] == _lib.ERR_PRUNED, st
+    with pytest.raises(CczError, match="pruned"):
+        e.check_healthy()
+    # (b) adjudication at max_plies: 4 boards, cap 6 plies, one simulation per move
+    e = SelfPlayEngine(4, n_playout=1, max_plies=6, seed=1, strict=True)
+    for ply in range(7):
+        leaf = e.select_leaves()
+        e.expand_backup(*uniform_evaluator(leaf))
+        e.finish_move()
+    st = e.stats()
+    assert st["truncated_games"] == 4 and st["error_flags"] == _lib.ERR_TRUNCATED, st
+    with pytest.raises(CczError, match="max_plies"):
+        e.check_healthy()
+    # the same without the flag: counted, healthy
+    e = SelfPlayEngine(4, n_playout=1, max_plies=6, seed=1)
+    for ply in range(7):
+        leaf = e.select_leaves()
+        e.expand_backup(*uniform_evaluator(leaf))
+        e.finish_move()
+    assert e.stats()["truncated_games"] == 4 and e.stats()["error_flags"] == 0
+    e.check_healthy()
+
+
 @pytest.mark.parametrize("B,n", [(1, 1), (37, 1), (37, 2), (5, 3), (129, 7)])
 def test_odd_sizes_and_minimal_playouts(B, n):
     """Board counts that are not multiples of anything and the degenerate n_playout = 1 (root expanded, no child

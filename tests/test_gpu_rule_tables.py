@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 
 def _engine(B, n, **kw):
     from chinesechesszero_amd.engine import SelfPlayEngine
+    kw.setdefault("strict", True)   # parity tests: a pruned subtree or an adjudicated game is an error, not a counter (CCZ_FLAG_STRICT)
     return SelfPlayEngine(B, n_playout=n, **kw)
 
 
