@@ -281,9 +281,19 @@ class InferenceNet(nn.Module):
         et = self.opt.edge_tiles
         return bool(g16 and (et is True or (et == "auto" and B >= self.EDGE_TILES_MIN_BOARDS)))
 
+    TOWER_CHAINS_SMALL = 3          # ... and three for batches whose chains are a single under-filled round of tiles each
+    TOWER_CHAINS_SMALL_BOARDS = (768, 1536)
+
     def tower_chains(self, B: int, groups: int = 1, edge: bool = False) -> int:
-        """Concurrent launch chains per group (one HIP stream each)."""
-        return max(1, min(self.opt.chains or (self.TOWER_CHAINS_EDGE if edge else self.TOWER_CHAINS), 8, -(-B // groups) // 256))
+        """Concurrent launch chains per group (one HIP stream each). Two by default, three with the edge-pair kernel (4096 boards
+        on) -- and three around 1024 boards (BASELINE configs[1]): ~290 live tiles are 1.13 rounds of the 256 CUs, every chain's layer
+        is one partial round and pays the dependent-launch gap in full, and three chains keep the chip fuller than two: 178.2 k
+        against 176.0 k sims/s, 4 chains 177.5 k, 1 chain 126.6 k (profiles/r06_chains_1024.txt, one box, two interleaved
+        repetitions; 2048 boards: 2 chains 191.8 k, 3: 189.0 k, 4: 183.8 k -- two stay)."""
+        per_group = -(-B // groups)
+        default = self.TOWER_CHAINS_EDGE if edge else (self.TOWER_CHAINS_SMALL if self.TOWER_CHAINS_SMALL_BOARDS[0] <= per_group < self.TOWER_CHAINS_SMALL_BOARDS[1]
+                                                       else self.TOWER_CHAINS)
+        return max(1, min(self.opt.chains or default, 8, per_group // 256))
 
     def bind_chain_streams(self, device):
         """Give this inference copy the process-wide launch-chain streams of ``device`` (:func:`chain_streams`): created and first used

@@ -30,6 +30,7 @@ import numpy as np
 
 sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("CCZ_GOLDEN_OUT", HERE)   # where the fixtures are written (tests/test_cpu_golden_regenerates.py: a scratch directory)
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
@@ -176,7 +177,7 @@ def main():
     assert len(table) == 2086
     for i, s in enumerate(table):
         assert ref_tools.move_action2move_id[s] == i
-    with open(os.path.join(HERE, "action_table.txt"), "w") as f:
+    with open(os.path.join(OUT, "action_table.txt"), "w") as f:
         f.write("\n".join(table) + "\n")
     meta["table_sha256"] = hashlib.sha256(",".join(table).encode()).hexdigest()
     flip_map = np.array([ref_tools.move_action2move_id[ref_tools.flip(table[i])] for i in range(2086)], dtype=np.int32)
@@ -330,8 +331,8 @@ def main():
     import parameters as ref_params  # noqa
     meta["parameters"] = {k: getattr(ref_params, k) for k in dir(ref_params) if k.isupper()}
 
-    np.savez_compressed(os.path.join(HERE, "reference_search.npz"), **out)
-    with open(os.path.join(HERE, "reference_search.json"), "w") as f:
+    np.savez_compressed(os.path.join(OUT, "reference_search.npz"), **out)
+    with open(os.path.join(OUT, "reference_search.json"), "w") as f:
         json.dump(meta, f, indent=1, default=lambda o: o if not isinstance(o, np.generic) else o.item())
     print("table sha", meta["table_sha256"])
     print("facts", facts)

@@ -22,6 +22,7 @@ import numpy as np
 
 sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("CCZ_GOLDEN_OUT", HERE)   # where the fixtures are written (tests/test_cpu_golden_regenerates.py: a scratch directory)
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
@@ -154,8 +155,8 @@ def main():
     meta["match"] = {"salts": [31, 32], "n_playout": 30, "seed": SEED + 1, "plies": len(match_moves),
                      "winner": (-1 if winner == -1 else bool(winner)), "red_player_idx": red.player, "black_player_idx": black.player}
 
-    np.savez_compressed(os.path.join(HERE, "reference_game.npz"), **out)
-    with open(os.path.join(HERE, "reference_game.json"), "w") as f:
+    np.savez_compressed(os.path.join(OUT, "reference_game.npz"), **out)
+    with open(os.path.join(OUT, "reference_game.json"), "w") as f:
         json.dump(meta, f, indent=1)
     print(meta)
 

@@ -20,6 +20,7 @@ import torch
 
 sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("CCZ_GOLDEN_OUT", HERE)   # where the fixtures are written (tests/test_cpu_golden_regenerates.py: a scratch directory)
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
@@ -102,8 +103,8 @@ def main():
         out["train_after_" + k] = sd[k].detach().numpy().ravel()[:16].copy()
     out["train_pi"] = pib
 
-    np.savez_compressed(os.path.join(HERE, "reference_net.npz"), **out)
-    with open(os.path.join(HERE, "reference_net.json"), "w") as f:
+    np.savez_compressed(os.path.join(OUT, "reference_net.npz"), **out)
+    with open(os.path.join(OUT, "reference_net.json"), "w") as f:
         json.dump(meta, f, indent=1)
     p = np.exp(out["forward_logp"])
     print("params", meta["n_params"], "max p", p.max(1), "entropy", -(p * out["forward_logp"]).sum(1), "value", out["forward_value"].ravel())

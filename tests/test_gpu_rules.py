@@ -1,4 +1,6 @@
 """GPU: move generation / game-end flags of the HIP engine against the CPU oracle (bit-exact)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -163,8 +165,10 @@ def test_random_piece_placements_match_oracle():
     _compare(boards)
 
 
-def test_perft5_on_gpu_equals_published_count():
-    """Depth-4 frontier (3,290,240 positions) expanded and counted by the HIP kernels alone: perft(5) = 133,312,995."""
+def gpu_perft(depth: int, chunk: int = 400000):
+    """perft(1..depth) of the start position counted by the HIP kernels alone (ccz_legal_moves + ccz_apply_moves; frontier positions
+    are expanded level by level, the last TWO levels chunk by chunk so that the 133 M depth-5 positions of perft(6) never exist at
+    once), and the last level's count split by the first move ("divide": 44 subtotals in ascending move-id order)."""
     import torch
     import ctypes as C
     from chinesechesszero_amd import _lib
@@ -173,32 +177,135 @@ def test_perft5_on_gpu_equals_published_count():
     dev = torch.device("cuda", 0)
     stream = lambda: C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     ptr = lambda t: C.c_void_p(t.data_ptr())
+    shifts = torch.arange(8, device=dev, dtype=torch.uint8)
+
+    def count(csq, cturn):
+        m = csq.shape[0]
+        mask = torch.zeros((m, 66), dtype=torch.int32, device=dev)
+        cnt = torch.zeros(m, dtype=torch.int32, device=dev)
+        _lib.check(L.ccz_legal_moves(stream(), m, ptr(csq), ptr(cturn), None, ptr(mask), ptr(cnt), None))
+        return mask, cnt
+
+    def children(csq, cturn, croot, mask, first_level):
+        bits = (mask.view(torch.uint8).unsqueeze(-1) >> shifts) & 1
+        idx = bits.reshape(csq.shape[0], -1)[:, :2086].nonzero()          # (parent, move id), ascending
+        child = csq[idx[:, 0]].contiguous()
+        cturn2 = cturn[idx[:, 0]].contiguous()
+        ids = idx[:, 1].to(torch.int32).contiguous()
+        _lib.check(L.ccz_apply_moves(stream(), child.shape[0], ptr(child), ptr(cturn2), ptr(ids), None))
+        root = torch.arange(child.shape[0], device=dev, dtype=torch.int16) if first_level else croot[idx[:, 0]].contiguous()
+        return child, cturn2, root
+
     sq = torch.zeros((1, 96), dtype=torch.uint8, device=dev)
     sq[0, :90] = torch.from_numpy(start_position()).to(dev)
     turn = torch.ones(1, dtype=torch.uint8, device=dev)
-    counts = []
-    for depth in range(5):
-        n = sq.shape[0]
-        total = 0
-        kids_sq, kids_turn = [], []
-        for s in range(0, n, 400000):
-            csq, cturn = sq[s:s + 400000].contiguous(), turn[s:s + 400000].contiguous()
-            m = csq.shape[0]
-            mask = torch.zeros((m, 66), dtype=torch.int32, device=dev)
-            cnt = torch.zeros(m, dtype=torch.int32, device=dev)
-            _lib.check(L.ccz_legal_moves(stream(), m, ptr(csq), ptr(cturn), None, ptr(mask), ptr(cnt), None))
+    root = torch.zeros(1, dtype=torch.int16, device=dev)
+    counts, divide = [], None
+    for level in range(depth):          # `sq` holds every position `level` plies from the start
+        last, streamed = level == depth - 1, level == depth - 2 and depth >= 2
+        total, total_next = 0, 0
+        kids = []
+        div = torch.zeros(44, dtype=torch.int64, device=dev)
+        for s0 in range(0, sq.shape[0], chunk):
+            csq, cturn, croot = sq[s0:s0 + chunk].contiguous(), turn[s0:s0 + chunk].contiguous(), root[s0:s0 + chunk].contiguous()
+            mask, cnt = count(csq, cturn)
             total += int(cnt.sum().item())
-            if depth < 4:
-                bits = (mask.view(torch.uint8).unsqueeze(-1) >> torch.arange(8, device=dev, dtype=torch.uint8)) & 1
-                idx = bits.reshape(m, -1)[:, :2086].nonzero()          # (parent, move id), ascending
-                child = csq[idx[:, 0]].contiguous()
-                cturn2 = cturn[idx[:, 0]].contiguous()
-                ids = idx[:, 1].to(torch.int32).contiguous()
-                _lib.check(L.ccz_apply_moves(stream(), child.shape[0], ptr(child), ptr(cturn2), ptr(ids), None))
-                kids_sq.append(child)
-                kids_turn.append(cturn2)
+            if last:
+                if level:
+                    div.index_add_(0, croot.to(torch.int64), cnt.to(torch.int64))
+                continue
+            child, cturn2, croot2 = children(csq, cturn, croot, mask, level == 0)
+            del mask
+            if streamed:                # the children are the last level: counted here, never stored
+                for c0 in range(0, child.shape[0], 4 * chunk):
+                    _, cnt2 = count(child[c0:c0 + 4 * chunk].contiguous(), cturn2[c0:c0 + 4 * chunk].contiguous())
+                    total_next += int(cnt2.sum().item())
+                    div.index_add_(0, croot2[c0:c0 + 4 * chunk].to(torch.int64), cnt2.to(torch.int64))
+            else:
+                kids.append((child, cturn2, croot2))
         counts.append(total)
-        if depth < 4:
-            sq, turn = torch.cat(kids_sq), torch.cat(kids_turn)
-            assert sq.shape[0] == total
+        if streamed:
+            counts.append(total_next)
+            divide = div.cpu().tolist()
+            break
+        if last:
+            divide = div.cpu().tolist() if level else [1] * total
+            break
+        sq, turn, root = (torch.cat([k[i] for k in kids]) for i in range(3))
+        assert sq.shape[0] == total
+    return counts, divide
+
+
+def test_perft5_on_gpu_equals_published_count():
+    """Depth-4 frontier (3,290,240 positions) expanded and counted by the HIP kernels alone: perft(5) = 133,312,995."""
+    counts, divide = gpu_perft(5)
     assert counts == [44, 1920, 79666, 3290240, 133312995]
+    assert len(divide) == 44 and sum(divide) == 133312995
+
+
+def test_perft6_on_gpu():
+    """perft(6) of the start position by the HIP kernels alone: the 133,312,995 depth-5 positions generated and counted chunk by
+    chunk (VERDICT r05 task 4a). 5,392,831,844 is the commonly cited value (from memory of published Xiangqi perft tables: treated as
+    [unverified] on its own) -- and it is what the independently written CPU oracle counts, first move by first move
+    (profiles/r06_perft6.json: `python profiles/perft6.py`, 44 subtotals, oracle = kernels)."""
+    import json
+    counts, divide = gpu_perft(6)
+    assert counts == [44, 1920, 79666, 3290240, 133312995, 5392831844]
+    rec = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r06_perft6.json")
+    if os.path.exists(rec):
+        with open(rec) as f:
+            j = json.load(f)
+        assert divide == j["divide_oracle"] == j["divide_gpu"] and j["perft6_oracle"] == 5392831844
+
+
+def test_hand_derived_rule_statements_on_the_kernels():
+    """tests/golden/rules_kat.json (answers worked out by hand from the rule statements of DESIGN.md section 4) replayed on the HIP
+    kernels: k_legal_moves for the legal-move set and the check / material / sixty-move flags of every checked position (the positions
+    are formed in the test by moving bytes, not by either implementation), and the ENGINE -- set_position + forced moves through
+    k_finish_move: push, history chain, game end, winner, perpetual check -- for game_over / winner at every check point."""
+    import rules_kat
+    from chinesechesszero_amd import tools
+    from chinesechesszero_amd.engine import SelfPlayEngine, legal_moves
+    uci = tools.move_id2move_action
+    mid = tools.move_action2move_id
+    for c in rules_kat.cases():
+        sq, turn, half = rules_kat.start_of(c)
+        pc = bool(c.get("rules", {}).get("perpetual_check", False))
+        e = SelfPlayEngine(1, n_playout=1, seed=1, perpetual_check=pc, strict=True)
+        e.set_position(0, sq, turn, half)
+        played = 0
+        for after, exp in rules_kat.checks_of(c):
+            while played < after:
+                mv = c["moves"][played]
+                fr, to = rules_kat.sq(mv[:2]), rules_kat.sq(mv[2:])
+                half = 0 if sq[to] else half + 1          # the clock restarts on captures only (default rules)
+                sq[to], sq[fr] = sq[fr], 0
+                turn ^= 1
+                e.finish_move(forced_moves=np.array([mid[mv]], np.int32))
+                played += 1
+            mask, cnt, flags = legal_moves(sq[None].copy(), np.array([turn], np.uint8), np.array([half], np.int32))
+            assert not (flags[0] & 128)
+            legal = sorted(uci[i] for i in np.nonzero(mask[0])[0])
+            assert cnt[0] == len(legal)
+            assert np.array_equal(e.root_positions()[0], sq), c["name"]
+            if played:
+                st = e.game_status()
+                over = bool(st["over"][0])
+                winner = {1: "red", 0: "black", -1: None}[int(st["winner"][0])] if over else None
+            else:
+                # a position that was SET, not reached: the engine's verdict on it is the leaf status of the unexpanded root
+                # (k_select: mcts.py:116-126 -- draw, or the side to move has lost)
+                e.select_leaves()
+                status = int(e.leaf_info()["status"][0])
+                over = status in (1, 2)
+                winner = ("black" if turn else "red") if status == 2 else None
+                st = {"over": [over]}
+            got = {"legal": legal, "in_check": bool(flags[0] & 1), "insufficient": bool(flags[0] & 2), "sixty": bool(flags[0] & 4),
+                   "game_over": over, "winner": winner}
+            for k, v in exp.items():
+                if k == "fourfold":   # the engine's verdict: over, a draw (or the perpetual-check loss), and no other reason for it
+                    assert bool(st["over"][0]) == v or exp.get("game_over", v) != v, (c["name"], after)
+                elif k != "after":
+                    assert got[k] == (sorted(v) if k == "legal" else v), (c["name"], after, k, got[k], v)
+        e.check_healthy()
+        del e

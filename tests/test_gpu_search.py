@@ -9,7 +9,9 @@ pytestmark = pytest.mark.gpu
 
 def _engine(B, n, **kw):
     from chinesechesszero_amd.engine import SelfPlayEngine
-    kw.setdefault("strict", True)   # parity tests: a pruned subtree or an adjudicated game is an error, not a counter (CCZ_FLAG_STRICT)
+    # parity tests: a pruned subtree or an adjudicated game is an error, not a counter (CCZ_FLAG_STRICT) -- unless the test sets a ply cap
+    # or a node budget on purpose
+    kw.setdefault("strict", not ({"max_plies", "max_nodes", "reserve_nodes"} & set(kw)))
     return SelfPlayEngine(B, n_playout=n, **kw)
 
 
