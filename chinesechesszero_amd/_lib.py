@@ -90,6 +90,9 @@ PROTOTYPES = {
     "ccz_step_compact": (C.c_int, [_P, _P, _P, _P]),
     "ccz_expand_backup_compact": (C.c_int, [_P, _P, _P]),
     "ccz_eval_plan": (C.c_int, [_P, _P, _P, _P]),
+    "ccz_set_scouts": (C.c_int, [_P, C.c_int32]),
+    "ccz_scout": (C.c_int, [_P, _P, _P]),
+    "ccz_eval_plan_scouted": (C.c_int, [_P, _P, _P, _P, _P]),
     "ccz_gather_priors_planned": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
     "ccz_eval_cache_clear": (C.c_int, [_P, _P]),
     "ccz_finish_move": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32]),

@@ -74,7 +74,10 @@ struct ccz_engine {
     long long *st_rowbase = nullptr;
     uint8_t *st_mask = nullptr, *st_sq = nullptr;
     std::vector<BoardMeta> h_meta;
+    int active = 0; // boards 0 .. active - 1 are searched; the rest are scout slots (ccz_set_scouts); 0 = all
 };
+
+#define ACTIVE(e) ((unsigned)((e)->active > 0 ? (e)->active : (e)->d.B))
 
 extern "C" {
 
@@ -338,7 +341,7 @@ int ccz_zero_leaf_input(ccz_engine *e, void *stream, void *leaf_input_f16_dev)
 int ccz_select_leaves(ccz_engine *e, void *stream, void *leaf_input_f16_dev)
 {
     NEED(e);
-    hipLaunchKernelGGL(k_select, dim3(e->d.B), dim3(64), 0, (hipStream_t)stream, e->d, (uint16_t *)leaf_input_f16_dev);
+    hipLaunchKernelGGL(k_select, dim3(ACTIVE(e)), dim3(64), 0, (hipStream_t)stream, e->d, (uint16_t *)leaf_input_f16_dev);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -347,7 +350,7 @@ int ccz_expand_backup(ccz_engine *e, void *stream, const float *prob_dev, const 
 {
     NEED(e);
     if (!prob_dev || !value_dev) return fail(-1, "ccz_expand_backup: null prob/value");
-    hipLaunchKernelGGL(k_expand_backup<false>, dim3(e->d.B), dim3(64), 0, (hipStream_t)stream, e->d, prob_dev, value_dev);
+    hipLaunchKernelGGL(k_expand_backup<false>, dim3(ACTIVE(e)), dim3(64), 0, (hipStream_t)stream, e->d, prob_dev, value_dev);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -356,7 +359,7 @@ int ccz_step(ccz_engine *e, void *stream, const float *prob_dev, const float *va
 {
     NEED(e);
     if (!prob_dev || !value_dev) return fail(-1, "ccz_step: null prob/value");
-    hipLaunchKernelGGL(k_step<false>, dim3(e->d.B), dim3(64), 0, (hipStream_t)stream, e->d, prob_dev, value_dev,
+    hipLaunchKernelGGL(k_step<false>, dim3(ACTIVE(e)), dim3(64), 0, (hipStream_t)stream, e->d, prob_dev, value_dev,
                        (uint16_t *)leaf_input_f16_dev);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -384,6 +387,39 @@ int ccz_eval_plan(ccz_engine *e, void *stream, int32_t *miss_rows_dev, int32_t *
     hipLaunchKernelGGL(k_cache_probe, dim3(e->d.B), dim3(64), 0, s, e->d);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_cache_plan, dim3(1), dim3(1024), 0, s, e->d, miss_rows_dev, n_miss_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ccz_set_scouts(ccz_engine *e, int32_t n_scouts)
+{
+    NEED(e);
+    if (n_scouts < 0 || n_scouts >= e->d.B) return fail(-1, "ccz_set_scouts: n_scouts must be in 0 .. n_boards - 1 (got %d of %d boards)", n_scouts, e->d.B);
+    if (n_scouts && !e->d.cache) return fail(-1, "ccz_set_scouts: scouts work through the evaluation cache (ccz_config.eval_cache_log2)");
+    e->active = n_scouts ? e->d.B - n_scouts : 0;
+    return 0;
+}
+
+int ccz_scout(ccz_engine *e, void *stream, void *leaf_input_f16_dev)
+{
+    NEED(e);
+    if (e->active <= 0) return fail(-1, "ccz_scout: no scout slots (ccz_set_scouts)");
+    if (!leaf_input_f16_dev) return fail(-1, "ccz_scout: null leaf input");
+    hipLaunchKernelGGL(k_scout, dim3((unsigned)(e->d.B - e->active)), dim3(64), 0, (hipStream_t)stream, e->d, (uint16_t *)leaf_input_f16_dev, e->active);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ccz_eval_plan_scouted(ccz_engine *e, void *stream, int32_t *miss_rows_dev, int32_t *n_miss_dev, int32_t *state_dev)
+{
+    NEED(e);
+    if (!e->d.cache) return fail(-1, "ccz_eval_plan_scouted: the engine was created without an evaluation cache (ccz_config.eval_cache_log2)");
+    if (e->active <= 0) return fail(-1, "ccz_eval_plan_scouted: no scout slots (ccz_set_scouts)");
+    if (!miss_rows_dev || !n_miss_dev) return fail(-1, "ccz_eval_plan_scouted: null output");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_cache_probe, dim3(e->d.B), dim3(64), 0, s, e->d);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_cache_plan_scouted, dim3(1), dim3(256), 0, s, e->d, e->active, miss_rows_dev, n_miss_dev, state_dev);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -416,7 +452,7 @@ int ccz_step_compact(ccz_engine *e, void *stream, const float *value_dev, void *
 {
     NEED(e);
     if (!value_dev && !e->d.cache) return fail(-1, "ccz_step_compact: null value (engine-owned leaf values exist only with an evaluation cache)");
-    hipLaunchKernelGGL(k_step<true>, dim3(e->d.B), dim3(64), 0, (hipStream_t)stream, e->d, (const float *)e->d.prior128, value_dev,
+    hipLaunchKernelGGL(k_step<true>, dim3(ACTIVE(e)), dim3(64), 0, (hipStream_t)stream, e->d, (const float *)e->d.prior128, value_dev,
                        (uint16_t *)leaf_input_f16_dev);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -426,7 +462,7 @@ int ccz_expand_backup_compact(ccz_engine *e, void *stream, const float *value_de
 {
     NEED(e);
     if (!value_dev && !e->d.cache) return fail(-1, "ccz_expand_backup_compact: null value (engine-owned leaf values exist only with an evaluation cache)");
-    hipLaunchKernelGGL(k_expand_backup<true>, dim3(e->d.B), dim3(64), 0, (hipStream_t)stream, e->d, (const float *)e->d.prior128,
+    hipLaunchKernelGGL(k_expand_backup<true>, dim3(ACTIVE(e)), dim3(64), 0, (hipStream_t)stream, e->d, (const float *)e->d.prior128,
                        value_dev);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -436,7 +472,7 @@ int ccz_finish_move(ccz_engine *e, void *stream, const int32_t *forced_moves_dev
                     int32_t *moves_out_dev, int32_t keep_tree)
 {
     NEED(e);
-    hipLaunchKernelGGL(k_finish_move, dim3(e->d.B), dim3(64), 0, (hipStream_t)stream, e->d, forced_moves_dev, temps_dev,
+    hipLaunchKernelGGL(k_finish_move, dim3(ACTIVE(e)), dim3(64), 0, (hipStream_t)stream, e->d, forced_moves_dev, temps_dev,
                        moves_out_dev, keep_tree ? 1 : 0);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_flip_half, dim3(1), dim3(1), 0, (hipStream_t)stream, e->d);

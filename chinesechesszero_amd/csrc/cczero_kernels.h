@@ -199,6 +199,122 @@ __device__ __forceinline__ Prefetch prefetch_board(const Dev &D, int b, int lane
     return P;
 }
 
+// The leaf end of a selection: the moves sh.pm.mv[0 .. depth) are made on the LDS board sh.sq (the root position), the Zobrist keys
+// of the path extend the history chain sh.chain, then legal moves / game end (net.py:154-157, mcts.py:116-117) and the evaluator
+// input of the leaf are written to the slots of board `b`. Shared by select_phase (b = the board searched) and k_scout (b = a scout
+// slot: the leaf is a sibling of another board's pending leaf).
+__device__ inline void leaf_tail(const Dev &D, int b, int lane, uint16_t *leaf_in, SelectShared &sh, int depth, int turn, int halfmove,
+                                 int chain_len, uint64_t key, bool count_stats)
+{
+    uint8_t *s_sq = sh.sq;
+    uint64_t *s_chain = sh.chain;
+    CCZ_STAMP(D, b, lane, 4)
+    // ---- replay the selection path on the LDS board: (1) table lookups in parallel, (2) the inherently
+    // serial piece shuffling by one lane, (3) Zobrist deltas in parallel + XOR prefix scan
+    if (depth > 0) {
+        for (int j = lane; j < depth; j += 64) {
+            const int mvj = sh.pm.mv[j];
+            sh.pm.from[j] = c_tab.from[mvj];
+            sh.pm.to[j] = c_tab.to[mvj];
+        }
+        wave_sync();
+        int lastcap = -1;
+        const bool pawn_zeroes = (D.rule_flags & 2u) != 0;
+        if (lane == 0) {
+            for (int j = 0; j < depth; ++j) {
+                const int fr = sh.pm.from[j], to = sh.pm.to[j];
+                const uint8_t pc = s_sq[fr], cp = s_sq[to];
+                s_sq[to] = pc;
+                s_sq[fr] = 0;
+                sh.pm.pc[j] = pc;
+                sh.pm.cap[j] = cp;
+                if (cp || (pawn_zeroes && (pc & 7) == PAWN)) lastcap = j; // "lastcap" = last clock-resetting move
+            }
+        }
+        lastcap = __builtin_amdgcn_readfirstlane(lastcap);
+        wave_sync();
+        // keys: key_j = root_key ^ XOR_{i<=j} delta_i ; a capture at move c restarts the chain at key_c
+        const int first = lastcap >= 0 ? lastcap : 0;
+        const int new_len = (lastcap >= 0 ? 0 : chain_len) + (depth - first);
+        if (new_len > kChainCap) {
+            set_err(D, 64);
+            if (lane == 0) D.leaf_status[b] = CCZ_LEAF_SKIP;
+            return;
+        }
+        uint64_t carry = key;
+        const int off = lastcap >= 0 ? -first : chain_len; // chain slot of move j is off + j
+        for (int j0 = 0; j0 < depth; j0 += 64) {
+            const int j = j0 + lane;
+            uint64_t dlt = 0;
+            if (j < depth) {
+                const int fr = sh.pm.from[j], to = sh.pm.to[j], pc = sh.pm.pc[j], cp = sh.pm.cap[j];
+                dlt = zob(pc, fr) ^ zob(pc, to) ^ kTurnKey;
+                if (cp) dlt ^= zob(cp, to);
+            }
+            dlt = wave_incl_xor64(dlt) ^ carry;
+            if (j < depth && j >= first) s_chain[CCZ_IDX(D, off + j, kChainCap)] = dlt;
+            carry = wave_readlane64(dlt, 63);
+        }
+        key = carry;
+        halfmove = lastcap >= 0 ? depth - 1 - lastcap : halfmove + depth;
+        chain_len = new_len;
+        turn ^= depth & 1;
+    }
+    wave_sync();
+
+    CCZ_STAMP(D, b, lane, 5)
+    // ---- leaf: legal moves (net.py:154-157), game end (mcts.py:116-117)
+    bool overflow;
+#ifdef CCZ_STAMPS
+    unsigned long long *sp = D.stamps + (size_t)b * 16;
+#else
+    unsigned long long *sp = nullptr;
+#endif
+    const LeafEval L = eval_position(s_sq, turn, halfmove, key, s_chain, chain_len, sh.S,
+                                     D.leaf_ids + (size_t)b * kMaxLegal, lane, overflow, sp, D.rank, D.unrank, D.trankpack);
+    if (overflow) set_err(D, 4);
+    CCZ_STAMP(D, b, lane, 6)
+    if (lane == 0) {
+        D.path_len[b] = depth;
+        D.leaf_key[b] = key;
+        D.leaf_k[b] = L.n_legal > kMaxLegal ? kMaxLegal : L.n_legal;
+        D.leaf_status[b] = (uint8_t)L.status;
+        if (count_stats) {
+            BoardStats &st = D.stats[b];
+            st.sum_depth += (unsigned long long)depth;
+            if (depth > st.depth_peak) st.depth_peak = depth;
+        }
+    }
+
+    // ---- evaluator input (net.py:160-177): groups 7 (red now), 15 (black now), 16 (side to move).
+    // Staged in LDS: fill (zeros / the turn plane), scatter one fp16 1.0 per piece, stream out as dwords.
+    CCZ_STAMP(D, b, lane, 7)
+    if (leaf_in) {
+        uint32_t *enc = sh.enc;
+        const uint32_t tv = turn ? 0x3C003C00u : 0u;
+#pragma unroll
+        for (int it = 0; it < 15; ++it) {
+            const int i = lane + 64 * it;
+            if (i < 945) enc[i] = i >= 630 ? tv : 0u;
+        }
+        wave_sync();
+        {
+            uint16_t *eh = (uint16_t *)enc;
+            const int q0 = s_sq[lane];
+            const int q1 = lane < 26 ? s_sq[64 + lane] : 0;
+            if (q0) eh[(q0 >> 3) * 630 + plane_of(D, q0 & 7) * 90 + lane] = kHalfOne;
+            if (q1) eh[(q1 >> 3) * 630 + plane_of(D, q1 & 7) * 90 + 64 + lane] = kHalfOne;
+        }
+        wave_sync();
+        uint32_t *row = (uint32_t *)(leaf_in + (size_t)b * 10710);
+#pragma unroll
+        for (int it = 0; it < 15; ++it) {
+            const int i = lane + 64 * it;
+            if (i < 945) row[i + (i < 315 ? 2205 : (i < 630 ? 4725 - 315 : 5040 - 630))] = enc[i];
+        }
+    }
+}
+
 // One wave: PUCT descent from the root of board b, leaf rules, evaluator input. Per tree level there is
 // ONE dependent global load round (the children's 16-B NodeA records + their move/count words); the
 // chosen child's own N / first_child / count are broadcast from the winning lane, not re-read.
@@ -301,109 +417,7 @@ __device__ inline void select_phase(const Dev &D, int b, int lane, uint16_t *lea
         return;
     }
 
-    CCZ_STAMP(D, b, lane, 4)
-    // ---- replay the selection path on the LDS board: (1) table lookups in parallel, (2) the inherently
-    // serial piece shuffling by one lane, (3) Zobrist deltas in parallel + XOR prefix scan
-    if (depth > 0) {
-        for (int j = lane; j < depth; j += 64) {
-            const int mvj = sh.pm.mv[j];
-            sh.pm.from[j] = c_tab.from[mvj];
-            sh.pm.to[j] = c_tab.to[mvj];
-        }
-        wave_sync();
-        int lastcap = -1;
-        const bool pawn_zeroes = (D.rule_flags & 2u) != 0;
-        if (lane == 0) {
-            for (int j = 0; j < depth; ++j) {
-                const int fr = sh.pm.from[j], to = sh.pm.to[j];
-                const uint8_t pc = s_sq[fr], cp = s_sq[to];
-                s_sq[to] = pc;
-                s_sq[fr] = 0;
-                sh.pm.pc[j] = pc;
-                sh.pm.cap[j] = cp;
-                if (cp || (pawn_zeroes && (pc & 7) == PAWN)) lastcap = j; // "lastcap" = last clock-resetting move
-            }
-        }
-        lastcap = __builtin_amdgcn_readfirstlane(lastcap);
-        wave_sync();
-        // keys: key_j = root_key ^ XOR_{i<=j} delta_i ; a capture at move c restarts the chain at key_c
-        const int first = lastcap >= 0 ? lastcap : 0;
-        const int new_len = (lastcap >= 0 ? 0 : chain_len) + (depth - first);
-        if (new_len > kChainCap) {
-            set_err(D, 64);
-            if (lane == 0) D.leaf_status[b] = CCZ_LEAF_SKIP;
-            return;
-        }
-        uint64_t carry = key;
-        const int off = lastcap >= 0 ? -first : chain_len; // chain slot of move j is off + j
-        for (int j0 = 0; j0 < depth; j0 += 64) {
-            const int j = j0 + lane;
-            uint64_t dlt = 0;
-            if (j < depth) {
-                const int fr = sh.pm.from[j], to = sh.pm.to[j], pc = sh.pm.pc[j], cp = sh.pm.cap[j];
-                dlt = zob(pc, fr) ^ zob(pc, to) ^ kTurnKey;
-                if (cp) dlt ^= zob(cp, to);
-            }
-            dlt = wave_incl_xor64(dlt) ^ carry;
-            if (j < depth && j >= first) s_chain[CCZ_IDX(D, off + j, kChainCap)] = dlt;
-            carry = wave_readlane64(dlt, 63);
-        }
-        key = carry;
-        halfmove = lastcap >= 0 ? depth - 1 - lastcap : halfmove + depth;
-        chain_len = new_len;
-        turn ^= depth & 1;
-    }
-    wave_sync();
-
-    CCZ_STAMP(D, b, lane, 5)
-    // ---- leaf: legal moves (net.py:154-157), game end (mcts.py:116-117)
-    bool overflow;
-#ifdef CCZ_STAMPS
-    unsigned long long *sp = D.stamps + (size_t)b * 16;
-#else
-    unsigned long long *sp = nullptr;
-#endif
-    const LeafEval L = eval_position(s_sq, turn, halfmove, key, s_chain, chain_len, sh.S,
-                                     D.leaf_ids + (size_t)b * kMaxLegal, lane, overflow, sp, D.rank, D.unrank, D.trankpack);
-    if (overflow) set_err(D, 4);
-    CCZ_STAMP(D, b, lane, 6)
-    if (lane == 0) {
-        D.path_len[b] = depth;
-        D.leaf_key[b] = key;
-        D.leaf_k[b] = L.n_legal > kMaxLegal ? kMaxLegal : L.n_legal;
-        D.leaf_status[b] = (uint8_t)L.status;
-        BoardStats &st = D.stats[b];
-        st.sum_depth += (unsigned long long)depth;
-        if (depth > st.depth_peak) st.depth_peak = depth;
-    }
-
-    // ---- evaluator input (net.py:160-177): groups 7 (red now), 15 (black now), 16 (side to move).
-    // Staged in LDS: fill (zeros / the turn plane), scatter one fp16 1.0 per piece, stream out as dwords.
-    CCZ_STAMP(D, b, lane, 7)
-    if (leaf_in) {
-        uint32_t *enc = sh.enc;
-        const uint32_t tv = turn ? 0x3C003C00u : 0u;
-#pragma unroll
-        for (int it = 0; it < 15; ++it) {
-            const int i = lane + 64 * it;
-            if (i < 945) enc[i] = i >= 630 ? tv : 0u;
-        }
-        wave_sync();
-        {
-            uint16_t *eh = (uint16_t *)enc;
-            const int q0 = s_sq[lane];
-            const int q1 = lane < 26 ? s_sq[64 + lane] : 0;
-            if (q0) eh[(q0 >> 3) * 630 + plane_of(D, q0 & 7) * 90 + lane] = kHalfOne;
-            if (q1) eh[(q1 >> 3) * 630 + plane_of(D, q1 & 7) * 90 + 64 + lane] = kHalfOne;
-        }
-        wave_sync();
-        uint32_t *row = (uint32_t *)(leaf_in + (size_t)b * 10710);
-#pragma unroll
-        for (int it = 0; it < 15; ++it) {
-            const int i = lane + 64 * it;
-            if (i < 945) row[i + (i < 315 ? 2205 : (i < 630 ? 4725 - 315 : 5040 - 630))] = enc[i];
-        }
-    }
+    leaf_tail(D, b, lane, leaf_in, sh, depth, turn, halfmove, chain_len, key, true);
 }
 
 __global__ __launch_bounds__(64) void k_select(Dev D, uint16_t *leaf_in)
@@ -414,6 +428,65 @@ __global__ __launch_bounds__(64) void k_select(Dev D, uint16_t *leaf_in)
     none.active = false; none.root_expanded = false; none.kid_expanded = false; none.k = 0; none.first_id = 0; none.n0 = 0;
     none.rootN = 0; none.rootQ = 0.0f; none.node1 = -1; none.N1 = 0; none.Q1 = 0.0f; none.has1 = false;
     select_phase(D, blockIdx.x, threadIdx.x, leaf_in, sh, P, none);
+}
+
+// ------------------------------------------------------------------ scouts: the NEXT leaves of a board, before it asks for them
+// The reference's first-maximum rule (mcts.py:47-48,59-61: an unvisited child scores +inf, max() returns the first one) makes the
+// order in which a node's children are first visited the order of board.legal_moves: after child i of a node X has been expanded,
+// the next simulations that reach X expand children i + 1, i + 2, ... So when board r's pending leaf is child i of X, scout slot
+// (active + j * active + r) is handed child i + 1 + j of X as ITS pending leaf -- position, legal moves, status, key and evaluator
+// input, exactly what the selection writes for a leaf -- and goes through the evaluation cache's plan with it: one evaluator call of
+// `1 + scouts` rows answers the leaf AND its next siblings, which board r then finds in the table (ccz_scout, round 6: one game at a
+// time -- MCTS_AI, the UCI loop -- is one 90-pixel row per evaluator call, the worst shape for the chip). Scout slots have no tree
+// and no game of their own (the simulator kernels run on boards 0 .. active - 1 only); they read board r's root, chain and path.
+// Results are unchanged: the table returns what the evaluator returns for the position (tests/test_gpu_scouts.py).
+__global__ __launch_bounds__(64) void k_scout(Dev D, uint16_t *leaf_in, int active)
+{
+    __shared__ SelectShared sh;
+    const int lane = threadIdx.x;
+    const int b = active + blockIdx.x;                  // the scout slot
+    const int r = blockIdx.x % active;                  // the board it scouts for
+    const int ahead = 1 + blockIdx.x / active;          // how many children past that board's pending leaf
+    const Prefetch P = prefetch_board(D, r, lane);
+    const int d = D.path_len[r];
+    const int st_r = D.leaf_status[r];
+    const int32_t *path = D.path + (size_t)r * D.maxd;
+    const int pj = path[lane < D.maxd ? lane : 0];      // path nodes 0 .. 63 (deeper paths are not scouted)
+    bool none = P.m.over || d < 1 || d >= 64 || st_r == CCZ_LEAF_SKIP || st_r == CCZ_LEAF_NONE;
+    const size_t base = ((size_t)r * 2 + P.half) * (size_t)D.cap;
+    const NodeA *A = D.nodeA + base;
+    const uint32_t *Bn = D.nodeB + base;
+    int sib = -1;
+    if (!none) {
+        const int leaf = __builtin_amdgcn_readlane(pj, __builtin_amdgcn_readfirstlane(d));
+        const int par = __builtin_amdgcn_readlane(pj, __builtin_amdgcn_readfirstlane(d - 1));
+        const NodeA X = A[CCZ_IDX(D, par, D.cap)];
+        const int nc = (int)(Bn[CCZ_IDX(D, par, D.cap)] >> 16);
+        sib = leaf + ahead;
+        // the sibling exists, and nobody has been there: an expanded or visited child already has its evaluation (or needs none)
+        none = X.fc < 0 || leaf < X.fc || sib >= X.fc + nc;
+        if (!none) {
+            const NodeA S = A[CCZ_IDX(D, sib, D.cap)];
+            none = S.fc >= 0 || S.N != 0;
+        }
+    }
+    if (none) {
+        if (lane == 0) { D.leaf_status[b] = CCZ_LEAF_NONE; D.leaf_k[b] = 0; D.path_len[b] = 0; }
+        return;
+    }
+    // the LDS board and chain of board r (as select_phase sets them up), the moves down to X, then the sibling's move
+    if (lane < 24) {
+        uint32_t v = P.sqw;
+        if (lane == 22) v &= 0x0000ffffu;
+        if (lane == 23) v = 0u;
+        ((uint32_t *)sh.sq)[lane] = v;
+    }
+    sh.chain[lane] = P.c0;
+    if (P.m.chain_len > 64) sh.chain[64 + lane] = D.chain[(size_t)r * kChainCap + 64 + lane];
+    if (lane >= 1 && lane < d) sh.pm.mv[lane - 1] = (uint16_t)(Bn[CCZ_IDX(D, pj, D.cap)] & 0xffffu);
+    if (lane == 0) sh.pm.mv[d - 1] = (uint16_t)(Bn[CCZ_IDX(D, sib, D.cap)] & 0xffffu);
+    wave_sync();
+    leaf_tail(D, b, lane, leaf_in, sh, d, P.m.turn, P.m.halfmove, P.m.chain_len, P.m.key, false);
 }
 
 // ------------------------------------------------------------------ K2: expand + backup
@@ -798,6 +871,50 @@ __global__ __launch_bounds__(1024) void k_cache_plan(Dev D, int32_t *miss_rows, 
         }
     }
     if (tid == 0) *n_miss = s_base;
+}
+
+// The plan of a step with scouts (ccz_eval_plan_scouted): the evaluator runs -- on ALL slots, row b = slot b, a fixed small batch --
+// only when a board that is really searched misses; the scouts of a board that hit (or whose leaf needs no evaluation) are dropped
+// for this step: their next siblings are asked for again when the board next misses. No row sharing here (a duplicate position
+// costs a row of a batch that is latency-bound anyway). state_out[r] = cstate of real board r (0 = its leaf needs the evaluator).
+__global__ __launch_bounds__(256) void k_cache_plan_scouted(Dev D, int active, int32_t *miss_rows, int32_t *n_miss, int32_t *state_out)
+{
+    __shared__ int s_any;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_any = 0;
+    __syncthreads();
+    for (int b = tid; b < D.B; b += 256) {
+        const int st = D.cstate[b];
+        if (b < active) {
+            if (st == 0) atomicOr(&s_any, 1);
+            if (state_out) state_out[b] = st;
+        }
+    }
+    __syncthreads();
+    for (int b = tid; b < D.B; b += 256) {
+        const int st = D.cstate[b];
+        const uint32_t slot = D.cslot[b];
+        const int r = b < active ? b : (b - active) % active;
+        const bool keep = st == 0 && (b < active || D.cstate[r] == 0);
+        if (st == 0) {
+            const int w = D.claim[slot];
+            if (!keep) {
+                if (w == b) D.claim[slot] = 0x7fffffff; // a dropped scout that won its slot gives it back (nobody stores there this step)
+            } else {
+                D.crep[b] = b;
+                D.row_of[b] = b;
+                D.cins[b] = (uint8_t)(w == b);
+            }
+        }
+        miss_rows[b] = b;
+    }
+    __syncthreads();
+    // (second pass: cstate of the scouts is rewritten only after every thread has read what it needed of it)
+    for (int b = active + tid; b < D.B; b += 256) {
+        const int r = (b - active) % active;
+        if (D.cstate[b] == 0 && D.cstate[r] != 0) D.cstate[b] = 2;
+    }
+    if (tid == 0) *n_miss = s_any ? D.B : 0;
 }
 
 // ------------------------------------------------------------------ pi from root visits (mcts.py:162-166)

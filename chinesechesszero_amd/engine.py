@@ -200,6 +200,32 @@ class SelfPlayEngine:
         check(self.L.ccz_eval_plan(self.h, self._stream(), _ptr(self.miss_rows), _ptr(self.n_miss)))
         return self.miss_rows, self.n_miss
 
+    # ------------------------------------------------------------------ scouts (one game at a time: include/cczero.h ccz_scout)
+    def set_scouts(self, n_scouts: int):
+        """The last ``n_scouts`` boards become scout slots (no tree, no game): the simulator entry points then run on the first
+        ``B - n_scouts`` boards only. Needs an evaluation cache."""
+        check(self.L.ccz_set_scouts(self.h, int(n_scouts)))
+        self.n_scouts = int(n_scouts)
+        if not hasattr(self, "_plan_state_host"):
+            self._plan_state_host = torch.zeros((self.B,), dtype=torch.int32).pin_memory()   # written by k_cache_plan_scouted
+
+    def scout(self):
+        """Hand every scout slot its pending leaf: the next unvisited sibling(s) of the pending leaf of the board it scouts for --
+        what that board's next simulations through the same parent will ask for (mcts.py:47-48: first maximum = insertion order)."""
+        check(self.L.ccz_scout(self.h, self._stream(), _ptr(self.leaf_input)))
+
+    def plan_scouted_launch(self):
+        """Probe the table for every slot and plan the step's evaluator call (``ccz_eval_plan_scouted``; launches only). The plan
+        state of the searched boards is written straight into pinned HOST memory by the plan kernel (no copy node: capturable)."""
+        check(self.L.ccz_eval_plan_scouted(self.h, self._stream(), _ptr(self.miss_rows), _ptr(self.n_miss),
+                                           C.c_void_p(self._plan_state_host.data_ptr())))
+
+    def plan_state_of_board0(self) -> int:
+        """Wait for the stream and read board 0's plan state: 0 = its leaf needs the evaluator -- run it on ALL ``B`` rows of
+        ``leaf_input`` and hand the result to :meth:`gather_priors_planned` --, 1 = table hit, 2 = no evaluation needed."""
+        torch.cuda.current_stream(self.device).synchronize()
+        return int(self._plan_state_host[0])
+
     def gather_priors_planned(self, logits: torch.Tensor, value: torch.Tensor):
         """``logits`` [B,2086] / ``value`` [B] as the planned evaluator returns them: COMPACT, row i = board miss_rows[i]."""
         f16 = self._check_logits(logits, value)

@@ -60,8 +60,14 @@ def _planes_to_squares(planes: np.ndarray):
     return ((p[7] * types).sum(0) + (p[15] * (types + 8)).sum(0)).astype(np.uint8), bool(p[16, 0, 0] > 0)
 
 
+SCOUTS = 7   # scout slots of a one-game search (ScoutedSearch): 1 + 7 = 8 rows per evaluator call cost what one row costs (7.0 against 6.5 us per
+             # tower layer) and answer 4.6 simulations on average (profiles/r06_single_board.json); env CCZ_SCOUTS, 0 = off
+
+
 class MCTS:
-    def __init__(self, policy_value_fn, c_puct=5, n_playout=10000, device: int = 0, seed: int = 0):
+    def __init__(self, policy_value_fn, c_puct=5, n_playout=10000, device: int = 0, seed: int = 0, scouts: int | None = None):
+        """``scouts``: scout slots of the one-game search (``selfplay.ScoutedSearch``; same visit counts, fewer evaluator calls);
+        None = ``SCOUTS`` (env ``CCZ_SCOUTS``) when the evaluator is a batched one that returns logits, else 0."""
         self.policy = policy_value_fn
         self.c_puct = c_puct
         self.n_playout = n_playout
@@ -82,14 +88,28 @@ class MCTS:
             self._batched = getattr(owner, "evaluate_leaves_logits", owner.evaluate_leaves)
         else:
             self._batched = None
+        import os
+        want = int(os.environ.get("CCZ_SCOUTS", SCOUTS)) if scouts is None else int(scouts)
+        ok = self._batched is not None and getattr(self._batched, "returns_logits", False)
+        self.scouts = max(0, min(want, 63)) if ok else 0
+        self._scouted = None
 
     # ---- engine management -----------------------------------------------------------------------
     def _ensure_engine(self):
         if self._engine is None:
-            self._engine = SelfPlayEngine(1, n_playout=max(1, self.n_playout), c_puct=self.c_puct, eps=EPS, alpha=ALPHA,
-                                          device=self._device, seed=self._seed, mirror=True,
+            # board 0 is the game; the scout slots behind it (no tree, no game of their own) carry the leaves board 0 will ask for next
+            # through a small evaluation cache (2^16 positions, 34 MB)
+            self._engine = SelfPlayEngine(1 + self.scouts, n_playout=max(1, self.n_playout), c_puct=self.c_puct, eps=EPS, alpha=ALPHA,
+                                          device=self._device, seed=self._seed, mirror=True, eval_cache_log2=16 if self.scouts else 0,
                                           strict=True)   # the reference's tree and game are unbounded: a prune or an adjudication raises here
+            if self.scouts:
+                self._engine.set_scouts(self.scouts)
         return self._engine
+
+    def _forced(self, mid: int):
+        f = np.full(self._engine.B, -1, np.int32)   # (the scout slots are not played: the simulator kernels run on board 0 only)
+        f[0] = int(mid)
+        return f
 
     def _sync_root(self, board):
         """Make the engine's root the position of ``board`` (same move history => same repetition state)."""
@@ -104,7 +124,7 @@ class MCTS:
             self._discard = False
         new = ids[len(self._synced):]
         for mid in new:
-            e.finish_move(forced_moves=np.array([mid], np.int32), keep_tree=not self._discard)
+            e.finish_move(forced_moves=self._forced(mid), keep_tree=not self._discard)
             self._synced.append(mid)
         if self._discard and not new:
             self._reset_tree_keep_position(board)
@@ -149,7 +169,13 @@ class MCTS:
         e = self._engine
         fused = self._batched is not None
         logits = fused and getattr(self._batched, "returns_logits", False)
-        if fused:
+        if fused and self.scouts:
+            # one game at a time with scout slots: the evaluator runs only when board 0's leaf is not in the table yet, on 1 + scouts rows
+            if self._scouted is None:
+                from .selfplay import ScoutedSearch
+                self._scouted = ScoutedSearch(e, self._batched, use_graph=self.use_graph)
+            self._scouted.begin_move()
+        elif fused:
             # launch sequence of a move: select, (evaluator, fused step) x (n-1), evaluator, expand_backup
             leaf = e.select_leaves()
             if self.use_graph and self._graph is None and getattr(self._batched, "graph_safe", False) and e.device.type == "cuda":
@@ -158,6 +184,8 @@ class MCTS:
         for i in range(self.n_playout):
             if not fused:
                 self.playout(board, red_states, black_states)
+            elif self.scouts:
+                self._scouted.simulate(last=i + 1 == self.n_playout)
             elif i + 1 < self.n_playout:
                 if self._graph is not None:
                     self._graph.replay()
@@ -185,7 +213,7 @@ class MCTS:
         if last_move == -1 or self._engine is None or self._synced is None:
             self._discard = True
             return
-        self._engine.finish_move(forced_moves=np.array([int(last_move)], np.int32), keep_tree=True)
+        self._engine.finish_move(forced_moves=self._forced(last_move), keep_tree=True)
         self._synced.append(int(last_move))
 
     def root_children(self):

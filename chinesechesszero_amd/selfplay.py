@@ -76,6 +76,97 @@ class GraphedStep:
         self.graph.replay()
 
 
+class ScoutedSearch:
+    """One game at a time with SCOUT SLOTS (``include/cczero.h`` ccz_scout; round 6). The reference's first-maximum rule makes the
+    children of a node first-visited in ``legal_moves`` order (mcts.py:47-48,59-61), so the leaves the next simulations will ask
+    for are known: the pending leaf's next siblings. The engine has ``1 + scouts`` boards; board 0 is searched, the scout slots
+    carry those siblings through the evaluation cache. Per simulation: ``ccz_step_compact`` (expand + backup + select) ->
+    ``ccz_scout`` -> probe + plan -> the HOST reads whether board 0's leaf is already in the table; only if it is not, the
+    evaluator runs -- once, on all ``1 + scouts`` rows (latency-bound: 8 rows cost what 1 costs) -- and the scouts' results are
+    stored for the simulations to come. Two hipGraphs (step + scout + plan; evaluator + gather), one stream sync per simulation.
+    Same visit counts, bit for bit: the table returns what the evaluator returns for a position, and the evaluator's result for
+    a row does not depend on the batch it sits in (tests/test_gpu_scouts.py)."""
+
+    def __init__(self, engine: SelfPlayEngine, evaluator, version_fn=None, use_graph: bool = True, warmup: int = 3):
+        if not (getattr(evaluator, "returns_logits", False) and getattr(evaluator, "batched", False)):
+            raise ValueError("scouts need a batched evaluator that returns logits (PolicyValueNet.evaluate_leaves_logits)")
+        if getattr(engine, "n_scouts", 0) < 1:
+            raise ValueError("the engine has no scout slots (SelfPlayEngine.set_scouts)")
+        self.engine, self.evaluator, self.version_fn = engine, evaluator, version_fn
+        self.use_graph = bool(use_graph and getattr(evaluator, "graph_safe", False) and engine.device.type == "cuda")
+        self.warmup = warmup
+        self.version = self._weights_version()
+        self._g_step = self._g_eval = None
+        self.evaluator_calls = self.simulations = 0
+
+    def _weights_version(self):
+        if self.version_fn is not None:
+            return self.version_fn()
+        return getattr(getattr(self.evaluator, "__self__", None), "weights_version", None)
+
+    def _check_weights(self):
+        v = self._weights_version()
+        if v != self.version:          # cached evaluations (and captured addresses) of other weights must not reach the tree
+            self.engine.clear_eval_cache()
+            self.version = v
+            self._g_eval = None
+
+    def _plan(self):
+        e = self.engine
+        e.scout()
+        e.plan_scouted_launch()
+
+    def _evaluate(self):
+        e = self.engine
+        logits, value = self.evaluator(e.leaf_input)
+        e.gather_priors_planned(logits, value)
+
+    def _capture(self, fn):
+        dev = self.engine.device
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        return g
+
+    def begin_move(self):
+        """After a re-root / new position: select board 0's first leaf, scout, plan."""
+        self._check_weights()
+        self.engine.select_leaves()
+        self._plan()
+
+    def simulate(self, last: bool):
+        """One simulation of board 0: the evaluator only if its pending leaf is not in the table; then expand + backup (+ the next
+        selection, scouting and plan unless ``last``)."""
+        e = self.engine
+        if e.plan_state_of_board0() == 0:
+            if self.use_graph:
+                if self._g_eval is None:
+                    dev = e.device
+                    side = torch.cuda.Stream(device=dev)
+                    side.wait_stream(torch.cuda.current_stream(dev))
+                    with torch.cuda.stream(side):
+                        for _ in range(self.warmup):     # allocator / inference-copy warm-up outside the capture; results discarded
+                            self.evaluator(e.leaf_input)
+                    torch.cuda.current_stream(dev).wait_stream(side)
+                    self._g_eval = self._capture(self._evaluate)
+                self._g_eval.replay()
+            else:
+                self._evaluate()
+            self.evaluator_calls += 1
+        self.simulations += 1
+        if last:
+            e.expand_backup_compact(None)
+            return
+        if self.use_graph:
+            if self._g_step is None:
+                self._g_step = self._capture(lambda: (e.step_compact(None), self._plan()))
+            self._g_step.replay()
+        else:
+            e.step_compact(None)
+            self._plan()
+
+
 class BatchedSelfPlay:
     """``evaluator(leaf_input fp16 [B,17,7,10,9]) -> (prob f32 [B,2086], value f32 [B])`` on the device."""
 

@@ -225,6 +225,22 @@ int ccz_gather_priors(ccz_engine *e, void *stream, const void *logits_dev, int32
 int ccz_step_compact(ccz_engine *e, void *stream, const float *value_dev, void *leaf_input_f16_dev);
 int ccz_expand_backup_compact(ccz_engine *e, void *stream, const float *value_dev);
 
+/* ---- scouts (round 6, ABI 7): the next leaves of a board, evaluated before it asks for them -------------------------------------
+ * The reference's first-maximum rule (mcts.py:47-48,59-61: an unvisited child scores +inf and max() returns the first one) fixes the
+ * order in which a node's children are first visited: the order of board.legal_moves. When a board's pending leaf is child i of a
+ * node, the simulations that reach that node next will ask for children i + 1, i + 2, ... One game at a time (MCTS_AI, the UCI loop:
+ * one 90-pixel row per evaluator call) therefore runs with SCOUT SLOTS: the last n_scouts boards of the engine have no tree and no
+ * game; ccz_scout hands slot active + j * active + r the (i + 1 + j)-th child of board r's pending leaf's parent as its pending leaf
+ * (position, legal moves, status, key, evaluator input row), ccz_eval_plan_scouted probes the evaluation cache for every slot and
+ * plans ONE evaluator call of all n_boards rows (row b = slot b; *n_miss_dev = n_boards) iff a searched board misses, else none
+ * (*n_miss_dev = 0; state_dev[r] = 0 miss / 1 hit / 2 no evaluation needed, for the host to branch on); ccz_gather_priors_planned
+ * then stores the scouts' evaluations in the table, where board r finds them. The simulator entry points (select / step /
+ * expand_backup / finish_move) run on boards 0 .. n_boards - n_scouts - 1 only. Same visit counts, bit for bit: the table returns
+ * what the evaluator returns for the position, and the evaluator's result for a row does not depend on the batch it sits in. */
+int ccz_set_scouts(ccz_engine *e, int32_t n_scouts);
+int ccz_scout(ccz_engine *e, void *stream, void *leaf_input_f16_dev);
+int ccz_eval_plan_scouted(ccz_engine *e, void *stream, int32_t *miss_rows_dev, int32_t *n_miss_dev, int32_t *state_dev);
+
 /* Evaluation cache (ccz_config.eval_cache_log2 > 0). On the search path the evaluator sees the leaf POSITION and the side to move
  * only (net.py:160-173: the history planes are zero; mcts.py:214 passes none), i.e. a function of the leaf's Zobrist key. The
  * reference evaluates every leaf on its own (mcts.py:114); here a position that was evaluated before -- by this board (a

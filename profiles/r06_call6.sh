@@ -1,0 +1,11 @@
+# round 6 call 6: scout slots -- the new tests, the single-board profile, then every test that drives MCTS_AI / the UCI loop
+O=gpurun_out
+set -e
+timeout -k 10 600 python -m pytest tests/test_gpu_scouts.py -x -q -m gpu > $O/r06_scouts_tests.log 2>&1 || { tail -60 $O/r06_scouts_tests.log; exit 1; }
+tail -2 $O/r06_scouts_tests.log
+timeout -k 10 600 python profiles/single_board_scouts.py > $O/r06_single_board.json 2> $O/r06_single_board.err || { tail -20 $O/r06_single_board.err; exit 1; }
+python - <<'PY'
+import json; j = json.load(open("gpurun_out/r06_single_board.json")); print(j["same_moves_whatever_the_scouts"]); [print(r["scouts"], round(r["sims_per_sec"]), round(r["us_per_playout"], 1), r.get("evaluator_calls_per_simulation")) for r in j["by_scouts"]]
+PY
+timeout -k 10 900 python -m pytest tests/test_gpu_frontends.py tests/test_gpu_frontends_parity.py tests/test_gpu_host_mirror.py tests/test_gpu_reference_game.py tests/test_gpu_search.py -x -q -m gpu > $O/r06_scouts_regress.log 2>&1 || { tail -60 $O/r06_scouts_regress.log; exit 1; }
+tail -2 $O/r06_scouts_regress.log

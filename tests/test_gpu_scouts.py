@@ -1,0 +1,107 @@
+"""GPU: one game at a time with scout slots (include/cczero.h ccz_scout, selfplay.ScoutedSearch; round 6).
+
+The reference's first-maximum rule (mcts.py:47-48,59-61) makes the children of a node first-visited in legal_moves order, so the
+leaves the search will ask for next are known -- the pending leaf's next siblings -- and can be evaluated in the same evaluator call.
+What must hold: the SAME tree, bit for bit, with fewer evaluator calls."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(blocks=2):
+    from chinesechesszero_amd.net import PolicyValueNet
+    torch.manual_seed(11)
+    pvn = PolicyValueNet(device="cuda:0", num_channels=256, resblocks_num=blocks)   # 256 wide: the hand-written evaluator, whose result
+    for m in pvn.policy_value_net.modules():                                         # for a row does not depend on the batch it sits in
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    pvn.refresh_inference_copy()
+    return pvn
+
+
+def _search(pvn, scouts, n, plies, use_graph, seed=3):
+    from chinesechesszero_amd.game import Board
+    from chinesechesszero_amd.mcts import MCTS_AI
+    np.random.seed(seed)
+    ai = MCTS_AI(pvn.policy_value_fn, c_puct=5, n_playout=n, is_selfplay=True)
+    ai.mcts = type(ai.mcts)(pvn.policy_value_fn, 5, n, scouts=scouts)
+    ai.mcts.use_graph = use_graph
+    board = Board()
+    roots, moves = [], []
+    for ply in range(plies):
+        acts, probs = ai.mcts.get_move_probs(board, temp=1.0)
+        rc = ai.mcts.root_children()
+        roots.append({k: np.array(v).copy() for k, v in rc.items()})
+        mv = int(np.random.choice(acts, p=probs))
+        ai.mcts.update_with_move(mv)
+        board.push(mv)
+        moves.append(mv)
+    return roots, moves, ai.mcts
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_a_scouted_search_builds_the_same_tree_with_fewer_evaluator_calls(use_graph):
+    pvn = _net()
+    n, plies = 96, 5
+    want, moves0, plain = _search(pvn, 0, n, plies, use_graph)
+    calls = {}
+    for scouts in (1, 7, 20):
+        got, moves, m = _search(pvn, scouts, n, plies, use_graph)
+        assert moves == moves0
+        for ply, (a, b) in enumerate(zip(want, got)):
+            for key in ("k", "acts", "visits", "q", "prior", "root_visits"):
+                assert np.array_equal(a[key], b[key]), (scouts, ply, key)
+        s = m._scouted
+        assert s.simulations == n * plies and 0 < s.evaluator_calls
+        calls[scouts] = s.evaluator_calls
+        m._engine.check_healthy()
+        st = m._engine.stats()
+        assert st["sims"] == n * plies and st["error_flags"] == 0      # the scout slots are not simulated
+    assert plain._scouted is None
+    # fewer evaluator calls the more scouts (this small net searches narrow and deep -- the worst case: 0.65 / 0.49 / 0.46 calls per
+    # simulation; the full 40 x 256 net: 0.24 with 7 scouts, profiles/r06_single_board.json)
+    assert calls[20] <= calls[7] < calls[1] < n * plies and calls[7] < 0.55 * n * plies, calls
+
+
+def test_scout_slots_hold_the_next_unvisited_siblings_of_the_pending_leaf():
+    """ccz_scout by itself. With uniform priors and value 0 every PUCT comparison is a tie, so the search visits the root's children
+    in order: while the pending leaf of board 0 is child i of the root, slot j must hold child i + j -- legal moves, status and
+    evaluator input as the ORACLE computes them for that position -- or nothing when the root has no such child."""
+    from oracle import OracleBoard
+    from chinesechesszero_amd.engine import SelfPlayEngine
+    from chinesechesszero_amd.net import uniform_evaluator
+    B = 6
+    e = SelfPlayEngine(B, n_playout=64, seed=1, eval_cache_log2=12, strict=True)
+    e.set_scouts(B - 1)
+    leaf = e.select_leaves()
+    prob, value = uniform_evaluator(leaf)
+    e.scout()
+    assert (e.leaf_info()["status"][1:] == 3).all()          # the pending leaf is the root itself: no siblings
+    root_ids = OracleBoard().legal_ids()
+    checked = 0
+    for sim in range(44):
+        e.step(prob, value)
+        e.scout()
+        info = e.leaf_info()
+        assert info["depth"][0] == 1 and info["status"][0] == 0
+        planes = e.leaf_input.float().cpu().numpy().reshape(B, -1)
+        i = sim                                                # children 0 .. sim - 1 are expanded, child `sim` is pending
+        lead = OracleBoard()
+        lead.push_id(root_ids[i])
+        assert info["ids"][0][:info["k"][0]].tolist() == lead.legal_ids()
+        for j in range(1, B):
+            if i + j >= len(root_ids):
+                assert info["status"][j] == 3
+                continue
+            sib = OracleBoard()
+            sib.push_id(root_ids[i + j])
+            assert info["status"][j] == 0 and info["k"][j] == len(sib.legal_ids())
+            assert info["ids"][j][:info["k"][j]].tolist() == sib.legal_ids()
+            assert np.array_equal(planes[j], np.asarray(sib.leaf_planes(), np.float32).reshape(-1))
+            checked += 1
+    assert checked == sum(min(B - 1, 43 - s) for s in range(44))
+    assert e.stats()["error_flags"] == 0
+    e.check_healthy()
