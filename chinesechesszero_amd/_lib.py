@@ -93,6 +93,7 @@ PROTOTYPES = {
     "ccz_set_scouts": (C.c_int, [_P, C.c_int32]),
     "ccz_scout": (C.c_int, [_P, _P, _P]),
     "ccz_eval_plan_scouted": (C.c_int, [_P, _P, _P, _P, _P]),
+    "ccz_scout_and_plan": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "ccz_gather_priors_planned": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
     "ccz_eval_cache_clear": (C.c_int, [_P, _P]),
     "ccz_finish_move": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32]),

@@ -424,6 +424,21 @@ int ccz_eval_plan_scouted(ccz_engine *e, void *stream, int32_t *miss_rows_dev, i
     return 0;
 }
 
+int ccz_scout_and_plan(ccz_engine *e, void *stream, void *leaf_input_f16_dev, int32_t *miss_rows_dev, int32_t *n_miss_dev, int32_t *state_dev)
+{
+    NEED(e);
+    if (!e->d.cache || e->active <= 0) return fail(-1, "ccz_scout_and_plan: needs an evaluation cache and scout slots (ccz_set_scouts)");
+    if (!leaf_input_f16_dev || !miss_rows_dev || !n_miss_dev) return fail(-1, "ccz_scout_and_plan: null leaf input / output");
+    if (e->d.B > kScoutFusedMax) {     // more slots than one workgroup has waves: the three launches
+        const int rc = ccz_scout(e, stream, leaf_input_f16_dev);
+        return rc ? rc : ccz_eval_plan_scouted(e, stream, miss_rows_dev, n_miss_dev, state_dev);
+    }
+    hipLaunchKernelGGL(k_scout_probe_plan, dim3(1), dim3((unsigned)(64 * e->d.B)), 0, (hipStream_t)stream, e->d, (uint16_t *)leaf_input_f16_dev, e->active,
+                       miss_rows_dev, n_miss_dev, state_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int ccz_gather_priors_planned(ccz_engine *e, void *stream, const void *logits_compact_dev, int32_t logits_f16, const float *value_compact_dev)
 {
     NEED(e);

@@ -440,13 +440,11 @@ __global__ __launch_bounds__(64) void k_select(Dev D, uint16_t *leaf_in)
 // time -- MCTS_AI, the UCI loop -- is one 90-pixel row per evaluator call, the worst shape for the chip). Scout slots have no tree
 // and no game of their own (the simulator kernels run on boards 0 .. active - 1 only); they read board r's root, chain and path.
 // Results are unchanged: the table returns what the evaluator returns for the position (tests/test_gpu_scouts.py).
-__global__ __launch_bounds__(64) void k_scout(Dev D, uint16_t *leaf_in, int active)
+__device__ inline void scout_wave(const Dev &D, uint16_t *leaf_in, int active, int q, int lane, SelectShared &sh)
 {
-    __shared__ SelectShared sh;
-    const int lane = threadIdx.x;
-    const int b = active + blockIdx.x;                  // the scout slot
-    const int r = blockIdx.x % active;                  // the board it scouts for
-    const int ahead = 1 + blockIdx.x / active;          // how many children past that board's pending leaf
+    const int b = active + q;                           // the scout slot
+    const int r = q % active;                           // the board it scouts for
+    const int ahead = 1 + q / active;                   // how many children past that board's pending leaf
     const Prefetch P = prefetch_board(D, r, lane);
     const int d = D.path_len[r];
     const int st_r = D.leaf_status[r];
@@ -487,6 +485,12 @@ __global__ __launch_bounds__(64) void k_scout(Dev D, uint16_t *leaf_in, int acti
     if (lane == 0) sh.pm.mv[d - 1] = (uint16_t)(Bn[CCZ_IDX(D, sib, D.cap)] & 0xffffu);
     wave_sync();
     leaf_tail(D, b, lane, leaf_in, sh, d, P.m.turn, P.m.halfmove, P.m.chain_len, P.m.key, false);
+}
+
+__global__ __launch_bounds__(64) void k_scout(Dev D, uint16_t *leaf_in, int active)
+{
+    __shared__ SelectShared sh;
+    scout_wave(D, leaf_in, active, blockIdx.x, threadIdx.x, sh);
 }
 
 // ------------------------------------------------------------------ K2: expand + backup
@@ -748,9 +752,8 @@ __device__ __forceinline__ uint32_t cache_slot(uint64_t key, uint32_t mask) { re
 // One wave per board: look the pending leaf up. Hit: its priors and value go straight to prior128 / vleaf. Miss: the board
 // bids for the slot (lowest board index wins: deterministic) -- the winner's evaluation will be stored there, and boards that
 // missed with the SAME key in this step share the winner's evaluator row (k_cache_plan).
-__global__ __launch_bounds__(64) void k_cache_probe(Dev D)
+__device__ inline void cache_probe_wave(const Dev &D, int b, int lane)
 {
-    const int b = blockIdx.x, lane = threadIdx.x;
     const int status = D.leaf_status[b];
     const uint64_t key = D.leaf_key[b]; // (requested together with the status: one round trip less in front of the table access)
     if (status != CCZ_LEAF_EXPAND) {
@@ -785,6 +788,8 @@ __global__ __launch_bounds__(64) void k_cache_probe(Dev D)
         if (hit && !verify) st.cache_hits += 1u;
     }
 }
+
+__global__ __launch_bounds__(64) void k_cache_probe(Dev D) { cache_probe_wave(D, blockIdx.x, threadIdx.x); }
 
 // One workgroup: representatives and the compaction plan. A miss whose slot was won by a board with the same key uses that
 // board's row; every other miss is its own representative (a different key on the same slot is evaluated but not stored).
@@ -877,13 +882,11 @@ __global__ __launch_bounds__(1024) void k_cache_plan(Dev D, int32_t *miss_rows, 
 // only when a board that is really searched misses; the scouts of a board that hit (or whose leaf needs no evaluation) are dropped
 // for this step: their next siblings are asked for again when the board next misses. No row sharing here (a duplicate position
 // costs a row of a batch that is latency-bound anyway). state_out[r] = cstate of real board r (0 = its leaf needs the evaluator).
-__global__ __launch_bounds__(256) void k_cache_plan_scouted(Dev D, int active, int32_t *miss_rows, int32_t *n_miss, int32_t *state_out)
+__device__ inline void plan_scouted_block(const Dev &D, int active, int32_t *miss_rows, int32_t *n_miss, int32_t *state_out, int tid, int nt, int &s_any)
 {
-    __shared__ int s_any;
-    const int tid = threadIdx.x;
     if (tid == 0) s_any = 0;
     __syncthreads();
-    for (int b = tid; b < D.B; b += 256) {
+    for (int b = tid; b < D.B; b += nt) {
         const int st = D.cstate[b];
         if (b < active) {
             if (st == 0) atomicOr(&s_any, 1);
@@ -891,7 +894,7 @@ __global__ __launch_bounds__(256) void k_cache_plan_scouted(Dev D, int active, i
         }
     }
     __syncthreads();
-    for (int b = tid; b < D.B; b += 256) {
+    for (int b = tid; b < D.B; b += nt) {
         const int st = D.cstate[b];
         const uint32_t slot = D.cslot[b];
         const int r = b < active ? b : (b - active) % active;
@@ -910,11 +913,34 @@ __global__ __launch_bounds__(256) void k_cache_plan_scouted(Dev D, int active, i
     }
     __syncthreads();
     // (second pass: cstate of the scouts is rewritten only after every thread has read what it needed of it)
-    for (int b = active + tid; b < D.B; b += 256) {
+    for (int b = active + tid; b < D.B; b += nt) {
         const int r = (b - active) % active;
         if (D.cstate[b] == 0 && D.cstate[r] != 0) D.cstate[b] = 2;
     }
     if (tid == 0) *n_miss = s_any ? D.B : 0;
+}
+
+__global__ __launch_bounds__(256) void k_cache_plan_scouted(Dev D, int active, int32_t *miss_rows, int32_t *n_miss, int32_t *state_out)
+{
+    __shared__ int s_any;
+    plan_scouted_block(D, active, miss_rows, n_miss, state_out, threadIdx.x, 256, s_any);
+}
+
+// scout + probe + plan of an engine of up to 16 slots as ONE workgroup (one wave per slot): what a scouted simulation launches behind
+// ccz_step_compact -- two launches per simulation instead of four (the step is a chain of small launches: every one costs ~5 us)
+constexpr int kScoutFusedMax = 16;
+__global__ __launch_bounds__(1024) void k_scout_probe_plan(Dev D, uint16_t *leaf_in, int active, int32_t *miss_rows, int32_t *n_miss, int32_t *state_out)
+{
+    __shared__ SelectShared sh[kScoutFusedMax];
+    __shared__ int s_any;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (w >= active && w < D.B) scout_wave(D, leaf_in, active, w - active, lane, sh[w]);
+    __threadfence_block();      // the scout's leaf slots (global memory, written by this wave) are read back by its own probe
+    if (w < D.B) cache_probe_wave(D, w, lane);
+    __threadfence();            // cstate / cslot / claim of every slot are read by other waves of this workgroup in the plan
+    __syncthreads();
+    plan_scouted_block(D, active, miss_rows, n_miss, state_out, tid, (int)blockDim.x, s_any);
 }
 
 // ------------------------------------------------------------------ pi from root visits (mcts.py:162-166)

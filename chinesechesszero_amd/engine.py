@@ -220,6 +220,11 @@ class SelfPlayEngine:
         check(self.L.ccz_eval_plan_scouted(self.h, self._stream(), _ptr(self.miss_rows), _ptr(self.n_miss),
                                            C.c_void_p(self._plan_state_host.data_ptr())))
 
+    def scout_and_plan(self):
+        """:meth:`scout` + :meth:`plan_scouted_launch` as one launch (``ccz_scout_and_plan``)."""
+        check(self.L.ccz_scout_and_plan(self.h, self._stream(), _ptr(self.leaf_input), _ptr(self.miss_rows), _ptr(self.n_miss),
+                                        C.c_void_p(self._plan_state_host.data_ptr())))
+
     def plan_state_of_board0(self) -> int:
         """Wait for the stream and read board 0's plan state: 0 = its leaf needs the evaluator -- run it on ALL ``B`` rows of
         ``leaf_input`` and hand the result to :meth:`gather_priors_planned` --, 1 = table hit, 2 = no evaluation needed."""

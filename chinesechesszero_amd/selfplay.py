@@ -82,7 +82,7 @@ class ScoutedSearch:
     for are known: the pending leaf's next siblings. The engine has ``1 + scouts`` boards; board 0 is searched, the scout slots
     carry those siblings through the evaluation cache. Per simulation: ``ccz_step_compact`` (expand + backup + select) ->
     ``ccz_scout`` -> probe + plan -> the HOST reads whether board 0's leaf is already in the table; only if it is not, the
-    evaluator runs -- once, on all ``1 + scouts`` rows (latency-bound: 8 rows cost what 1 costs) -- and the scouts' results are
+    evaluator runs -- once, on all ``1 + scouts`` rows (latency-bound: 11 rows -- one round of blocks -- cost what 1 costs) -- and the scouts' results are
     stored for the simulations to come. Two hipGraphs (step + scout + plan; evaluator + gather), one stream sync per simulation.
     Same visit counts, bit for bit: the table returns what the evaluator returns for a position, and the evaluator's result for
     a row does not depend on the batch it sits in (tests/test_gpu_scouts.py)."""
@@ -112,9 +112,7 @@ class ScoutedSearch:
             self._g_eval = None
 
     def _plan(self):
-        e = self.engine
-        e.scout()
-        e.plan_scouted_launch()
+        self.engine.scout_and_plan()
 
     def _evaluate(self):
         e = self.engine

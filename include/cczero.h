@@ -240,6 +240,8 @@ int ccz_expand_backup_compact(ccz_engine *e, void *stream, const float *value_de
 int ccz_set_scouts(ccz_engine *e, int32_t n_scouts);
 int ccz_scout(ccz_engine *e, void *stream, void *leaf_input_f16_dev);
 int ccz_eval_plan_scouted(ccz_engine *e, void *stream, int32_t *miss_rows_dev, int32_t *n_miss_dev, int32_t *state_dev);
+/* ccz_scout + ccz_eval_plan_scouted as ONE launch (engines of up to 16 slots: one workgroup, one wave per slot; more: the three launches) */
+int ccz_scout_and_plan(ccz_engine *e, void *stream, void *leaf_input_f16_dev, int32_t *miss_rows_dev, int32_t *n_miss_dev, int32_t *state_dev);
 
 /* Evaluation cache (ccz_config.eval_cache_log2 > 0). On the search path the evaluator sees the leaf POSITION and the side to move
  * only (net.py:160-173: the history planes are zero; mcts.py:214 passes none), i.e. a function of the leaf's Zobrist key. The

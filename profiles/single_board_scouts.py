@@ -42,7 +42,27 @@ def run(pvn, scouts, n=200, moves=8):
         out["evaluator_calls_per_simulation"] = (s.evaluator_calls - calls0) / (n * moves)
         out["rows_per_evaluator_call"] = 1 + scouts
     player.mcts._engine.check_healthy()
+    if scouts == 10:   # the two pieces of a simulation, timed alone (graph replays on the engine's last position)
+        s, e = player.mcts._scouted, player.mcts._engine
+        s.begin_move()
+
+        def timed(fn, iters=200):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                fn()
+            torch.cuda.synchronize()
+            return 1e6 * (time.perf_counter() - t0) / iters
+        out["pieces_us"] = {"evaluator_plus_gather_graph_replay": timed(lambda: s._g_eval.replay()),
+                            "step_scout_probe_plan_graph_replay_plus_host_read": timed(lambda: (s._g_step.replay(), e.plan_state_of_board0())),
+                            "host_read_alone_stream_sync": timed(lambda: e.plan_state_of_board0())}
+        e.reset_tree()
     return out
+
+
+SCOUTS = tuple(int(x) for x in os.environ.get("SCOUTS", "0,3,7,10,15,31").split(","))
 
 
 def main():
@@ -51,7 +71,7 @@ def main():
     torch.manual_seed(0)
     pvn = PolicyValueNet(device=dev)
     pvn.refresh_inference_copy()
-    rows = [run(pvn, s) for s in (0, 3, 7, 15, 31)]
+    rows = [run(pvn, s) for s in SCOUTS]
     same = all(r["moves"] == rows[0]["moves"] for r in rows)
     print(json.dumps({"what": __doc__.split("\n\n")[0], "net": "random-init 40x256, fp16 inference copy (BN folded)",
                       "same_moves_whatever_the_scouts": same, "by_scouts": rows}, indent=1))

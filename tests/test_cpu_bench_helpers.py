@@ -66,13 +66,19 @@ def test_code_hash_follows_the_kernel_sources(tmp_path, monkeypatch):
     assert len(h0) == 16 and h0 == build.code_hash()
     # a copy of the package tree with one byte more in one kernel header hashes differently
     import shutil
-    dst = tmp_path / "pkg"
+    dst = tmp_path / "repo" / "chinesechesszero_amd"
     shutil.copytree(os.path.join(ROOT, "chinesechesszero_amd"), dst, ignore=shutil.ignore_patterns("*.so", "__pycache__", ".pytest_cache"))
+    shutil.copytree(os.path.join(ROOT, "include"), tmp_path / "repo" / "include")     # (round 6: the C header and bench.py are hashed too)
+    shutil.copy(os.path.join(ROOT, "bench.py"), tmp_path / "repo" / "bench.py")
     monkeypatch.setattr(build, "_HERE", str(dst))
     assert build.code_hash() == h0
     with open(dst / "csrc" / "cczero_kernels.h", "a") as f:
         f.write("\n")
-    assert build.code_hash() != h0
+    h1 = build.code_hash()
+    assert h1 != h0
+    with open(tmp_path / "repo" / "include" / "cczero.h", "a") as f:
+        f.write("\n")
+    assert build.code_hash() not in (h0, h1)
 
 
 def test_a_library_older_than_its_sources_is_refused(tmp_path, monkeypatch):

@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert _lib.Config.move_rank_host.offset == 64 and _lib.Config.plane_of_type.offset == 72 and _lib.Config.rule_flags.offset == 80 and _lib.Config.type_rank.offset == 88
     assert _lib.Config.eval_cache_log2.offset == 84 and _lib.Stats.cache_probes.offset == 104
     m = re.search(r"#define CCZ_ABI_VERSION (\d+)", hdr)
-    assert m and int(m.group(1)) == 6
+    assert m and int(m.group(1)) == 7
 
 
 def test_tables_from_library_match_reference_golden(golden):
