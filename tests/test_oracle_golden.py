@@ -168,3 +168,56 @@ def test_float16_value_changes_the_search(golden):
     m32.get_move_probs(OracleBoard(), 1.0)
     _, v32, q32, _ = m32.root_children()
     assert not np.array_equal(q32, q)
+
+
+def test_host_twins_of_the_lockstep_entry_points_on_the_cpu():
+    """oracle/ccz_ref.c (``ccz_ref_*``: the signatures of include/cczero.h on host memory) is the sequential search behind a lockstep
+    call surface: B boards stepped through select / expand+backup / finish_move give what B separate OracleMCTS objects give, the
+    sampled move is the Philox twin's, and the config struct it takes is the header's (same layout as the product's ctypes mirror).
+    The same object is compared with the HIP library byte for byte in tests/test_gpu_ref_twins.py."""
+    import ctypes
+    import oracle
+    from oracle import OracleBoard, OracleMCTS, RefEngine
+    from oracle.evaluators import hash_eval
+    from chinesechesszero_amd import _lib
+    assert ctypes.sizeof(oracle.RefConfig) == ctypes.sizeof(_lib.Config) == 96
+    for (a, _), (b, _) in zip(oracle.RefConfig._fields_, _lib.Config._fields_):
+        assert a == b and getattr(oracle.RefConfig, a).offset == getattr(_lib.Config, b).offset
+    B, n = 3, 48
+    e = RefEngine(B, n_playout=n, seed=11, board_id_base=40)
+    boards = [OracleBoard() for _ in range(B)]
+    trees = [OracleMCTS(None, c_puct=5, n_playout=0) for _ in range(B)]
+    try:
+        for move in range(3):
+            for s in range(n):
+                planes = e.select_leaves().astype(np.float32).reshape(B, 17, 7, 90)
+                info = e.leaf_info()
+                types = np.arange(1, 8)[None, :, None]
+                sq = ((planes[:, 7] * types).sum(1) + (planes[:, 15] * (types + 8)).sum(1)).astype(np.uint8)
+                turn = planes[:, 16, 0, 0].astype(np.uint8)
+                P, V = np.zeros((B, 2086), np.float32), np.zeros(B, np.float32)
+                for b in range(B):
+                    P[b], V[b] = (x[0] for x in hash_eval(sq[b:b + 1], turn[b:b + 1], salt=b))
+                    leaf, depth = trees[b].select(boards[b])
+                    ids = leaf.legal_ids()
+                    assert depth == info["depth"][b] and info["ids"][b][:info["k"][b]].tolist() == ids and np.array_equal(leaf.squares(), sq[b])
+                    trees[b].expand_backup(leaf, ids, P[b][ids], V[b])
+                e.expand_backup(P, V)
+            rc = e.root_children()
+            for b in range(B):
+                acts, visits, q, prior = trees[b].root_children()
+                k = len(acts)
+                assert rc["k"][b] == k and np.array_equal(rc["acts"][b][:k], acts.astype(np.uint16)) and np.array_equal(rc["visits"][b][:k], visits)
+                assert np.array_equal(rc["q"][b][:k].view(np.uint32), q.view(np.uint32)) and rc["root_visits"][b] == trees[b].root_visits()
+            moves = e.finish_move()
+            for b in range(B):
+                acts, visits, _, _ = trees[b].root_children()
+                temp = 1.0 if move + 1 <= 30 else 0.5
+                want = int(acts[oracle.det_sample(11, 40 + b, move, oracle.det_pi(visits, temp), 0.25, 0.2)[0]])
+                assert moves[b] == want
+                trees[b].update_with_move(want)
+                boards[b].push_id(want)
+            st = e.game_status()
+            assert st["plies"].tolist() == [move + 1] * B and np.array_equal(e.root_positions(), np.stack([bd.squares() for bd in boards]))
+    finally:
+        e.close()
