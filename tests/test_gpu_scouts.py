@@ -105,3 +105,41 @@ def test_scout_slots_hold_the_next_unvisited_siblings_of_the_pending_leaf():
     assert checked == sum(min(B - 1, 43 - s) for s in range(44))
     assert e.stats()["error_flags"] == 0
     e.check_healthy()
+
+
+def test_scout_slots_of_two_searched_boards():
+    """More than one searched board: slot active + j * active + r scouts for board r, j + 1 children ahead (the host loop of the package
+    searches one board; the kernels are written for any number). Two boards on different start positions, uniform evaluator."""
+    from golden_cases import STARTS
+    from oracle import OracleBoard
+    from chinesechesszero_amd.engine import SelfPlayEngine
+    from chinesechesszero_amd.net import uniform_evaluator
+    B, active = 8, 2
+    e = SelfPlayEngine(B, n_playout=64, seed=2, eval_cache_log2=12, strict=True)
+    e.set_scouts(B - active)
+    starts = [None, (STARTS["rook_knight"].copy(), 1, 0)]
+    e.set_position(1, *starts[1])
+    roots = [OracleBoard(), OracleBoard.from_array(*starts[1])]
+    root_ids = [r.legal_ids() for r in roots]
+    leaf = e.select_leaves()
+    prob, value = uniform_evaluator(leaf)
+    checked = 0
+    for sim in range(12):
+        e.step(prob, value)
+        e.scout_and_plan()                       # the fused launch (8 slots <= 16): scout + probe + plan
+        assert e.plan_state_of_board0() in (0, 1)
+        info = e.leaf_info()
+        planes = e.leaf_input.float().cpu().numpy().reshape(B, -1)
+        for q in range(B - active):
+            r, ahead, slot = q % active, 1 + q // active, active + q
+            i = sim                              # child `sim` of board r's root is pending (children are first visited in order)
+            if i + ahead >= len(root_ids[r]):
+                assert info["status"][slot] == 3
+                continue
+            sib = OracleBoard(roots[r].b)
+            sib.push_id(root_ids[r][i + ahead])
+            assert info["status"][slot] == 0 and info["ids"][slot][:info["k"][slot]].tolist() == sib.legal_ids(), (sim, q)
+            assert np.array_equal(planes[slot], np.asarray(sib.leaf_planes(), np.float32).reshape(-1))
+            checked += 1
+    assert checked == 12 * (B - active)
+    e.check_healthy()
