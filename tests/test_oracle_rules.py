@@ -303,7 +303,7 @@ def test_perpetual_check_yields_to_the_sixty_move_draw_at_the_same_ply():
 
 
 def test_hand_derived_rule_statements():
-    """tests/golden/rules_kat.json: 25 positions / move sequences whose answers were worked out BY HAND from the rule statements of
+    """tests/golden/rules_kat.json: 30 positions / move sequences whose answers were worked out BY HAND from the rule statements of
     DESIGN.md section 4 (fourfold at the 4th occurrence, the 120-ply rule with and without a legal move, material, flying-general
     pins, cannon screens, knight legs, elephant eyes, stalemate = loss, perpetual check) -- an anchor that neither implementation
     produced (VERDICT r05 task 4). The same file is replayed on the kernels (tests/test_gpu_rules.py)."""
