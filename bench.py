@@ -609,8 +609,9 @@ def main():
         pvn._infer.tower_probe = None
     s1 = e.stats()
     ranks_seen, per_rank, err_any, bad_total = 1, None, int(s1["error_flags"]), int(bad_records.item())
+    dev_all = [s1["pruned_subtrees"] - s0["pruned_subtrees"], s1["truncated_games"] - s0["truncated_games"], s1["pruned_subtrees"], s1["truncated_games"]]
     if multi:
-        t = torch.zeros(3 * world + 4, dtype=torch.float64, device=xdev)
+        t = torch.zeros(3 * world + 8, dtype=torch.float64, device=xdev)
         t[0] = dt
         mx = t[:1].clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -621,6 +622,11 @@ def main():
         t[world + 3] = 1.0 if s1["error_flags"] else 0.0        # ranks whose engine raised a sticky error bit
         t[world + 4 + rank] = 1e3 * dt_local / a.steps          # this rank's own step time (its K steps, boundary included, no waiting for peers)
         t[2 * world + 4 + rank] = 1e3 * (ex.max_call_s if ex is not None else 0.0)   # the longest single call into the exchange (host)
+        # where the engines departed from the reference, summed over the ranks (the line's `deviations`)
+        t[3 * world + 4] = float(s1["pruned_subtrees"] - s0["pruned_subtrees"])
+        t[3 * world + 5] = float(s1["truncated_games"] - s0["truncated_games"])
+        t[3 * world + 6] = float(s1["pruned_subtrees"])
+        t[3 * world + 7] = float(s1["truncated_games"])
         dist.all_reduce(t)
         dt = float(mx.item())
         ranks_seen = int(t[world + 1].item())
@@ -629,6 +635,7 @@ def main():
         per_rank = [float(v) for v in t[1:world + 1].tolist()]
         rank_step_ms = [float(v) for v in t[world + 4:2 * world + 4].tolist()]
         rank_xchg_max_call_ms = [float(v) for v in t[2 * world + 4:3 * world + 4].tolist()]
+        dev_all = [int(v) for v in t[3 * world + 4:3 * world + 8].tolist()]
     e.check_healthy()
     st_end = e.game_status()
     sims = s1["sims"] - s0["sims"]
@@ -777,9 +784,10 @@ def main():
             # pool (the reference's tree is unbounded, mcts.py:31-39); games adjudicated as draws at max_plies (its game loop has no
             # cap, game.py:155; the workload string says what max_plies is here and why); table hits of the evaluation cache that were
             # evaluated again and disagreed (--cache-verify; None without it)
-            "deviations": {"pruned_subtrees_in_window": s1["pruned_subtrees"] - s0["pruned_subtrees"], "pruned_subtrees_total": s1["pruned_subtrees"],
-                           "truncated_games_in_window": s1["truncated_games"] - s0["truncated_games"], "truncated_games_total": s1["truncated_games"],
-                           "games_finished_total": s1["games"], "max_plies": a.max_plies,
+            "deviations": {"pruned_subtrees_in_window": dev_all[0], "pruned_subtrees_total": dev_all[2],
+                           "truncated_games_in_window": dev_all[1], "truncated_games_total": dev_all[3],
+                           "scope": "summed over all ranks" if multi else "this GPU",
+                           "games_finished_total_rank0": s1["games"], "max_plies": a.max_plies,
                            "cache_verify_mismatches": (s1["cache_verify_mismatches"] if (planned and a.cache_verify) else None),
                            "cache_verify_hits_evaluated_again": (s1["cache_verified"] if (planned and a.cache_verify) else None),
                            "node_pool": {"nodes_peak": s1["nodes_peak"], "what": "pruning starts when a kept subtree exceeds cap - reserve nodes (ccz_config.max_nodes / reserve_nodes)"}},

@@ -710,8 +710,11 @@ class CollectPipeline:
             if self.gatherer is not None and hasattr(self.gatherer, "flush_iter") and self.selfplay is not None:
                 self.drain_exchange(self.gatherer)   # every rank's last games reach rank 0's store (blocking; all ranks call it)
         except BaseException:
-            if not multi:
-                self.sink.finalize()   # one process, nobody waits for it: what was collected is merged before the error goes up
+            if not multi:   # one process, nobody waits for it: what was collected is merged before the error goes up
+                try:
+                    self.sink.finalize()
+                except Exception as exc:   # (the first error is the one to report; the shards stay on disk for the next sink)
+                    log(f"merging the shards after an error failed as well: {exc}", "WARNING")
             raise
         if finalize:
             self.sink.finalize()

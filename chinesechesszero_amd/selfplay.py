@@ -95,6 +95,10 @@ class ScoutedSearch:
         self.engine, self.evaluator, self.version_fn = engine, evaluator, version_fn
         self.use_graph = bool(use_graph and getattr(evaluator, "graph_safe", False) and engine.device.type == "cuda")
         self.warmup = warmup
+        if version_fn is None and not hasattr(getattr(evaluator, "__self__", None), "weights_version") and not getattr(evaluator, "stateless", False):
+            from .tools import log
+            log("ScoutedSearch: the evaluator exposes no weights_version and no version_fn was given: evaluations cached for other weights "
+                "cannot be told apart (pass version_fn=... if its weights can change)", "WARNING")
         self.version = self._weights_version()
         self._g_step = self._g_eval = None
         self.evaluator_calls = self.simulations = 0

@@ -57,6 +57,7 @@ def test_bench_starts_its_own_ranks_and_exchanges_inside_the_timed_window(exchan
     assert j["n_gpus"] == 2 and j["steps"] == 12 and j["warmup"] == 2 and j["scaling"] == "weak" and j["unit"] == "sims/s"
     m = j["multi_gpu"]
     assert m["world_size"] == 2 and m["ranks_seen"] == 2 and m["backend"] == "gloo" and m["exchange"] == exchange
+    assert j["deviations"]["scope"] == "summed over all ranks" and j["deviations"]["pruned_subtrees_total"] == 0
     assert m["boards_per_rank"] == [256, 256] and m["board_id_base_per_rank"] == [0, 256]
     assert len(m["rank_step_ms"]) == 2 and all(0 < v <= j["ms_per_step"] * 1.001 for v in m["rank_step_ms"])
     # a 12-step window of a 16-simulation move still holds one real move boundary with its exchange
@@ -288,7 +289,8 @@ def test_bench_single_gpu_line_contract():
     assert j["error_flags_any"] == 0
     dv = j["deviations"]                     # where the engine departs from the reference, counted in the line itself
     assert dv["pruned_subtrees_in_window"] == 0 and dv["pruned_subtrees_total"] == 0 and dv["cache_verify_mismatches"] is None
-    assert 0 <= dv["truncated_games_in_window"] <= dv["truncated_games_total"] <= dv["games_finished_total"] and dv["max_plies"] > 0
+    assert 0 <= dv["truncated_games_in_window"] <= dv["truncated_games_total"] <= dv["games_finished_total_rank0"] and dv["max_plies"] > 0
+    assert dv["scope"] == "this GPU"
     assert j["plies"]["start_mean"] > 3
 
 
