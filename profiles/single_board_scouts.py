@@ -63,6 +63,8 @@ def run(pvn, scouts, n=200, moves=8):
 
 
 SCOUTS = tuple(int(x) for x in os.environ.get("SCOUTS", "0,3,7,10,15,31").split(","))
+N_PLAYOUT = int(os.environ.get("N_PLAYOUT", "200"))   # 1600 = the reference's default PLAYOUT (parameters.py:14)
+MOVES = int(os.environ.get("MOVES", "8"))
 
 
 def main():
@@ -71,7 +73,7 @@ def main():
     torch.manual_seed(0)
     pvn = PolicyValueNet(device=dev)
     pvn.refresh_inference_copy()
-    rows = [run(pvn, s) for s in SCOUTS]
+    rows = [run(pvn, s, n=N_PLAYOUT, moves=MOVES) for s in SCOUTS]
     same = all(r["moves"] == rows[0]["moves"] for r in rows)
     print(json.dumps({"what": __doc__.split("\n\n")[0], "net": "random-init 40x256, fp16 inference copy (BN folded)",
                       "same_moves_whatever_the_scouts": same, "by_scouts": rows}, indent=1))
