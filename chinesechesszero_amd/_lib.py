@@ -94,6 +94,7 @@ PROTOTYPES = {
     "ccz_scout": (C.c_int, [_P, _P, _P]),
     "ccz_eval_plan_scouted": (C.c_int, [_P, _P, _P, _P, _P]),
     "ccz_scout_and_plan": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "ccz_scouted_run": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "ccz_gather_priors_planned": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
     "ccz_eval_cache_clear": (C.c_int, [_P, _P]),
     "ccz_finish_move": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32]),

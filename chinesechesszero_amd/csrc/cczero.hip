@@ -439,6 +439,22 @@ int ccz_scout_and_plan(ccz_engine *e, void *stream, void *leaf_input_f16_dev, in
     return 0;
 }
 
+int ccz_scouted_run(ccz_engine *e, void *stream, void *leaf_input_f16_dev, int32_t *miss_rows_dev, int32_t *n_miss_dev, int32_t *state_dev, int32_t *run_dev)
+{
+    NEED(e);
+    if (!e->d.cache || e->active <= 0 || e->active == e->d.B) return fail(-1, "ccz_scouted_run: needs an evaluation cache and scout slots (ccz_set_scouts)");
+    if (e->d.B > kScoutFusedMax) return fail(-1, "ccz_scouted_run: at most %d slots (one workgroup, one wave per slot); this engine has %d", kScoutFusedMax, e->d.B);
+    if (!leaf_input_f16_dev || !miss_rows_dev || !n_miss_dev || !state_dev || !run_dev) return fail(-1, "ccz_scouted_run: null leaf input / output / run block");
+    if (e->d.B <= 12)
+        hipLaunchKernelGGL(k_scouted_run<12>, dim3(1), dim3((unsigned)(64 * e->d.B)), 0, (hipStream_t)stream, e->d, (uint16_t *)leaf_input_f16_dev, e->active,
+                           miss_rows_dev, n_miss_dev, state_dev, run_dev);
+    else
+        hipLaunchKernelGGL(k_scouted_run<kScoutFusedMax>, dim3(1), dim3((unsigned)(64 * e->d.B)), 0, (hipStream_t)stream, e->d, (uint16_t *)leaf_input_f16_dev,
+                           e->active, miss_rows_dev, n_miss_dev, state_dev, run_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int ccz_gather_priors_planned(ccz_engine *e, void *stream, const void *logits_compact_dev, int32_t logits_f16, const float *value_compact_dev)
 {
     NEED(e);

@@ -752,13 +752,13 @@ __device__ __forceinline__ uint32_t cache_slot(uint64_t key, uint32_t mask) { re
 // One wave per board: look the pending leaf up. Hit: its priors and value go straight to prior128 / vleaf. Miss: the board
 // bids for the slot (lowest board index wins: deterministic) -- the winner's evaluation will be stored there, and boards that
 // missed with the SAME key in this step share the winner's evaluator row (k_cache_plan).
-__device__ inline void cache_probe_wave(const Dev &D, int b, int lane)
+__device__ inline int cache_probe_wave(const Dev &D, int b, int lane) // returns the board's plan state (wave-uniform): 0 miss, 1 hit, 2 nothing to evaluate
 {
     const int status = D.leaf_status[b];
     const uint64_t key = D.leaf_key[b]; // (requested together with the status: one round trip less in front of the table access)
     if (status != CCZ_LEAF_EXPAND) {
         if (lane == 0) D.cstate[b] = 2;
-        return;
+        return 2;
     }
     const uint32_t slot = cache_slot(key, D.cache_mask);
     const CacheEntry *e = D.cache + slot;
@@ -787,9 +787,10 @@ __device__ inline void cache_probe_wave(const Dev &D, int b, int lane)
         st.cache_probes += 1u;
         if (hit && !verify) st.cache_hits += 1u;
     }
+    return hit && !verify ? 1 : 0;
 }
 
-__global__ __launch_bounds__(64) void k_cache_probe(Dev D) { cache_probe_wave(D, blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(64) void k_cache_probe(Dev D) { (void)cache_probe_wave(D, blockIdx.x, threadIdx.x); }
 
 // One workgroup: representatives and the compaction plan. A miss whose slot was won by a board with the same key uses that
 // board's row; every other miss is its own representative (a different key on the same slot is evaluated but not stored).
@@ -937,10 +938,83 @@ __global__ __launch_bounds__(1024) void k_scout_probe_plan(Dev D, uint16_t *leaf
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (w >= active && w < D.B) scout_wave(D, leaf_in, active, w - active, lane, sh[w]);
     __threadfence_block();      // the scout's leaf slots (global memory, written by this wave) are read back by its own probe
-    if (w < D.B) cache_probe_wave(D, w, lane);
+    if (w < D.B) (void)cache_probe_wave(D, w, lane);
     __threadfence();            // cstate / cslot / claim of every slot are read by other waves of this workgroup in the plan
     __syncthreads();
     plan_scouted_block(D, active, miss_rows, n_miss, state_out, tid, (int)blockDim.x, s_any);
+}
+
+// Simulations of a scouted engine WITHOUT the host in between (ccz_scouted_run): what the host loop launches per simulation -- the
+// fused step (expand + backup of the pending leaf, next selection) and scout + probe + plan -- repeated by ONE workgroup (one wave per
+// slot, <= 16 slots) for as long as every searched board finds its next leaf in the table. A simulation that hits costs the
+// latency chains of its phases instead of two launches, a graph replay and a stream synchronisation (~46 us,
+// profiles/r06_single_board.json); the host comes back only when the evaluator has to run, when `budget` simulations are done (a
+// caller that reports progress) or when the move's last simulation -- which has no next selection -- is backed up.
+//   * the scouts of a board that hit are dropped by the plan (plan_scouted_block), so while the searched boards hit, the scout waves
+//     do nothing at all: a searched board's wave expands, backs up, selects and probes ITS leaf; the scouts are handed their leaves
+//     only once, for the step that leaves the loop with a miss -- and what that step's plan leaves behind is what k_scout_probe_plan
+//     would have left (a dropped scout gives back the slot it claimed: the same table state as never having claimed it).
+//   * run[0] = budget (>= 1), run[1] = simulations left in this move including the pending one (>= 1); run[2] <- simulations done
+//     here, run[3] <- 1 if a searched board's leaf needs the evaluator now.
+// Same phases, same order, same device functions as the separate launches; all hand-offs between waves stay inside the workgroup
+// (one CU, one L1): workgroup-scope fences and barriers, as in k_step and k_scout_probe_plan.
+template <int MAXW> // 12: engines of up to 12 slots (168 registers per lane: no spills; the default 1 + 10 scouts), 16: up to 16
+__global__ __launch_bounds__(64 * MAXW) void k_scouted_run(Dev D, uint16_t *leaf_in, int active, int32_t *miss_rows, int32_t *n_miss, int32_t *state_out,
+                                                        int32_t *run)
+{
+    __shared__ SelectShared sh[MAXW];
+    __shared__ int s_any, s_state[MAXW];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool real = w < active;
+    const int budget = __hip_atomic_load(run + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    int left = __hip_atomic_load(run + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    int done = 0, need = 0;
+    for (;;) {
+        Prefetch P;
+        TopPatch tp;
+        if (real) {
+            P = prefetch_board(D, w, lane);
+            tp = expand_backup_phase<true>(D, w, lane, D.prior128, nullptr, P.m, P.half);
+            __threadfence_block();      // (k_step: the phases touch the same nodes from different lanes of the wave)
+            __builtin_amdgcn_wave_barrier();
+        }
+        ++done;
+        if (--left <= 0) break;         // the move's last simulation: nothing is selected behind it (ccz_expand_backup_compact)
+        if (real) {
+            select_phase(D, w, lane, leaf_in, sh[w], P, tp);
+            __threadfence_block();      // the leaf (global memory, written by this wave) is read back by its own probe
+            const int st = cache_probe_wave(D, w, lane);
+            if (lane == 0) s_state[w] = st;
+        }
+        __threadfence_block();          // the searched boards' leaves, paths, statuses and probe results: read by every wave from here on
+        __syncthreads();
+        need = 0;
+        for (int r = 0; r < active; ++r) need |= s_state[r] == 0 ? 1 : 0;
+        if (need || done >= budget) break;
+        __syncthreads();                // (s_state is rewritten by the next pass)
+    }
+    if (left > 0) {
+        // the plan of the step that leaves the loop. A miss: the scouts get their leaves and probe, then the plan of all slots; no
+        // miss (budget used): the searched boards' states, no evaluator call -- plan_scouted_block with every scout dropped
+        if (need) {
+            if (!real) {
+                scout_wave(D, leaf_in, active, w - active, lane, sh[w]);
+                __threadfence_block();
+                (void)cache_probe_wave(D, w, lane);
+            }
+            __threadfence_block();      // cstate / cslot / claim of every slot are read by other waves of this workgroup in the plan
+            __syncthreads();
+            plan_scouted_block(D, active, miss_rows, n_miss, state_out, tid, (int)blockDim.x, s_any);
+        } else {
+            if (tid < active) state_out[tid] = s_state[tid];
+            if (tid == 0) *n_miss = 0;
+        }
+    }
+    if (tid == 0) {
+        run[2] = done;
+        run[3] = need;
+    }
 }
 
 // ------------------------------------------------------------------ pi from root visits (mcts.py:162-166)

@@ -225,6 +225,30 @@ class SelfPlayEngine:
         check(self.L.ccz_scout_and_plan(self.h, self._stream(), _ptr(self.leaf_input), _ptr(self.miss_rows), _ptr(self.n_miss),
                                         C.c_void_p(self._plan_state_host.data_ptr())))
 
+    def scouted_run_launch(self):
+        """Simulations in ONE launch (``ccz_scouted_run``): step + scout + probe + plan repeated on the device while board 0's next
+        leaf is in the table. How many at most, and how many the move has left, go through pinned host memory -- the launch is
+        capturable; write them with :meth:`set_run` before the launch or a replay, read the outcome with :meth:`run_outcome`."""
+        if not hasattr(self, "_run_host"):
+            self.set_run(1, 1)
+        check(self.L.ccz_scouted_run(self.h, self._stream(), _ptr(self.leaf_input), _ptr(self.miss_rows), _ptr(self.n_miss),
+                                     C.c_void_p(self._plan_state_host.data_ptr()), C.c_void_p(self._run_host.data_ptr())))
+
+    def set_run(self, budget: int, left: int):
+        """``budget``: simulations the next scouted run may do at most; ``left``: simulations left in this move, the pending one included."""
+        if budget < 1 or left < 1:
+            raise ValueError("scouted run: budget and simulations left must be >= 1")
+        if not hasattr(self, "_run_host"):
+            self._run_host = torch.zeros((4,), dtype=torch.int32).pin_memory()
+            self._run_np = self._run_host.numpy()
+        self._run_np[0] = budget
+        self._run_np[1] = left
+
+    def run_outcome(self):
+        """Wait for the stream; ``(simulations done by the last scouted run, whether board 0's leaf needs the evaluator now)``."""
+        torch.cuda.current_stream(self.device).synchronize()
+        return int(self._run_np[2]), bool(self._run_np[3])
+
     def plan_state_of_board0(self) -> int:
         """Wait for the stream and read board 0's plan state: 0 = its leaf needs the evaluator -- run it on ALL ``B`` rows of
         ``leaf_input`` and hand the result to :meth:`gather_priors_planned` --, 1 = table hit, 2 = no evaluation needed."""

@@ -182,7 +182,29 @@ class MCTS:
             if self.use_graph and self._graph is None and getattr(self._batched, "graph_safe", False) and e.device.type == "cuda":
                 from .selfplay import GraphedStep
                 self._graph = GraphedStep(e, self._batched)
-        for i in range(self.n_playout):
+
+        def report(last):
+            nonlocal acc
+            if on_playout is not None and (acc >= interval or last):   # mcts.py:154-160
+                try:
+                    on_playout(acc)
+                except Exception:
+                    pass
+                acc = 0
+
+        if fused and self.scouts and self._scouted.device_loop:
+            # simulations that find their leaf in the table repeat on the device (ccz_scouted_run): the host sees the search when the
+            # evaluator has to run -- and at the playouts on_playout is due at, the same ones as in the loop below
+            left = self.n_playout
+            while left > 0:
+                done = self._scouted.run(left, left if on_playout is None else interval - acc)
+                left -= done
+                acc += done
+                report(left == 0)
+            n_host = 0
+        else:
+            n_host = self.n_playout
+        for i in range(n_host):
             if not fused:
                 self.playout(board, red_states, black_states)
             elif self.scouts:
@@ -195,12 +217,7 @@ class MCTS:
             else:
                 (e.expand_backup_logits if logits else e.expand_backup)(*self._batched(leaf))
             acc += 1
-            if on_playout is not None and (acc >= interval or i == self.n_playout - 1):
-                try:
-                    on_playout(acc)
-                except Exception:
-                    pass
-                acc = 0
+            report(i == self.n_playout - 1)
         rc = self._engine.root_children()
         self._engine.check_healthy()
         k = int(rc["k"][0])

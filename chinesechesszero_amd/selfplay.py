@@ -7,6 +7,8 @@ harvested into (state, pi, z) rows and restart immediately.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -87,7 +89,7 @@ class ScoutedSearch:
     Same visit counts, bit for bit: the table returns what the evaluator returns for a position, and the evaluator's result for
     a row does not depend on the batch it sits in (tests/test_gpu_scouts.py)."""
 
-    def __init__(self, engine: SelfPlayEngine, evaluator, version_fn=None, use_graph: bool = True, warmup: int = 3):
+    def __init__(self, engine: SelfPlayEngine, evaluator, version_fn=None, use_graph: bool = True, warmup: int = 3, device_loop=None):
         if not (getattr(evaluator, "returns_logits", False) and getattr(evaluator, "batched", False)):
             raise ValueError("scouts need a batched evaluator that returns logits (PolicyValueNet.evaluate_leaves_logits)")
         if getattr(engine, "n_scouts", 0) < 1:
@@ -100,8 +102,13 @@ class ScoutedSearch:
             log("ScoutedSearch: the evaluator exposes no weights_version and no version_fn was given: evaluations cached for other weights "
                 "cannot be told apart (pass version_fn=... if its weights can change)", "WARNING")
         self.version = self._weights_version()
-        self._g_step = self._g_eval = None
+        self._g_step = self._g_eval = self._g_run = self._g_eval_run = None
         self.evaluator_calls = self.simulations = 0
+        # simulations that hit the table are repeated ON THE DEVICE (ccz_scouted_run: one launch per evaluator call instead of two
+        # launches, a replay and a stream sync per simulation); CCZ_SCOUT_DEVICE_LOOP=0: the host loop (:meth:`simulate`), for A/B
+        self.device_loop = (os.environ.get("CCZ_SCOUT_DEVICE_LOOP", "1") != "0") if device_loop is None else bool(device_loop)
+        self.device_loop = self.device_loop and engine.B <= 16
+        self._need = True
 
     def _weights_version(self):
         if self.version_fn is not None:
@@ -113,7 +120,7 @@ class ScoutedSearch:
         if v != self.version:          # cached evaluations (and captured addresses) of other weights must not reach the tree
             self.engine.clear_eval_cache()
             self.version = v
-            self._g_eval = None
+            self._g_eval = self._g_eval_run = None
 
     def _plan(self):
         self.engine.scout_and_plan()
@@ -136,6 +143,47 @@ class ScoutedSearch:
         self._check_weights()
         self.engine.select_leaves()
         self._plan()
+        if self.device_loop:
+            self._need = self.engine.plan_state_of_board0() == 0
+
+    def _warm_evaluator(self):
+        e = self.engine
+        dev = e.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup):     # allocator / inference-copy warm-up outside the capture; results discarded
+                self.evaluator(e.leaf_input)
+        torch.cuda.current_stream(dev).wait_stream(side)
+
+    def run(self, left: int, budget: int) -> int:
+        """Up to ``budget`` simulations of the move (``left`` = how many it still has, the pending one included) with ONE launch
+        sequence: the evaluator on all rows if board 0's pending leaf is not in the table, then ``ccz_scouted_run`` -- expand +
+        backup, select, scout, probe, plan, again and again on the device until a leaf misses, the budget is used or the move's
+        last simulation is backed up. Returns the number of simulations done (>= 1)."""
+        e = self.engine
+        e.set_run(min(budget, left), left)
+        if self._need:
+            if self.use_graph:
+                if self._g_eval_run is None:
+                    self._warm_evaluator()
+                    self._g_eval_run = self._capture(lambda: (self._evaluate(), e.scouted_run_launch()))
+                self._g_eval_run.replay()
+            else:
+                self._evaluate()
+                e.scouted_run_launch()
+            self.evaluator_calls += 1
+        elif self.use_graph:
+            if self._g_run is None:
+                self._g_run = self._capture(e.scouted_run_launch)
+            self._g_run.replay()
+        else:
+            e.scouted_run_launch()
+        done, self._need = e.run_outcome()
+        if done < 1:
+            raise RuntimeError("ccz_scouted_run reported no simulation")
+        self.simulations += done
+        return done
 
     def simulate(self, last: bool):
         """One simulation of board 0: the evaluator only if its pending leaf is not in the table; then expand + backup (+ the next
@@ -144,13 +192,7 @@ class ScoutedSearch:
         if e.plan_state_of_board0() == 0:
             if self.use_graph:
                 if self._g_eval is None:
-                    dev = e.device
-                    side = torch.cuda.Stream(device=dev)
-                    side.wait_stream(torch.cuda.current_stream(dev))
-                    with torch.cuda.stream(side):
-                        for _ in range(self.warmup):     # allocator / inference-copy warm-up outside the capture; results discarded
-                            self.evaluator(e.leaf_input)
-                    torch.cuda.current_stream(dev).wait_stream(side)
+                    self._warm_evaluator()
                     self._g_eval = self._capture(self._evaluate)
                 self._g_eval.replay()
             else:

@@ -242,6 +242,19 @@ int ccz_scout(ccz_engine *e, void *stream, void *leaf_input_f16_dev);
 int ccz_eval_plan_scouted(ccz_engine *e, void *stream, int32_t *miss_rows_dev, int32_t *n_miss_dev, int32_t *state_dev);
 /* ccz_scout + ccz_eval_plan_scouted as ONE launch (engines of up to 16 slots: one workgroup, one wave per slot; more: the three launches) */
 int ccz_scout_and_plan(ccz_engine *e, void *stream, void *leaf_input_f16_dev, int32_t *miss_rows_dev, int32_t *n_miss_dev, int32_t *state_dev);
+/* Simulations of a scouted engine (at most 16 slots) WITHOUT the host in between: ONE launch, one workgroup, repeats
+ * { ccz_step_compact (expand + backup of the pending leaves from the engine's prior / value rows, next selection) ; ccz_scout_and_plan }
+ * for as long as every searched board finds its next leaf in the table (or needs no evaluation). It returns to the host when the
+ * evaluator has to run, after run_dev[0] simulations (a caller that reports progress), or when the move's last simulation -- which has
+ * no next selection: ccz_expand_backup_compact -- is backed up. run_dev: four int32 the device can reach (device or pinned host memory):
+ *   [0] in:  budget, >= 1            [1] in:  simulations left in this move, the pending one included, >= 1
+ *   [2] out: simulations done here   [3] out: 1 = a searched board's leaf needs the evaluator now (the plan and state_dev are then what
+ *                                            ccz_scout_and_plan would have left), 0 = budget or move exhausted
+ * Call it where ccz_step_compact would be called: the pending leaves' priors and values are in place (ccz_gather_priors_planned, or a
+ * table hit). Same phases in the same order on the same data as the separate launches: same trees, bit for bit
+ * (tests/test_gpu_scouts.py). mcts.py:101-129 is the loop this runs; the reference's one-evaluation-per-playout is the path it skips. */
+int ccz_scouted_run(ccz_engine *e, void *stream, void *leaf_input_f16_dev, int32_t *miss_rows_dev, int32_t *n_miss_dev, int32_t *state_dev,
+                    int32_t *run_dev);
 
 /* Evaluation cache (ccz_config.eval_cache_log2 > 0). On the search path the evaluator sees the leaf POSITION and the side to move
  * only (net.py:160-173: the history planes are zero; mcts.py:214 passes none), i.e. a function of the leaf's Zobrist key. The

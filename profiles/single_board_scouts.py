@@ -55,9 +55,17 @@ def run(pvn, scouts, n=200, moves=8):
                 fn()
             torch.cuda.synchronize()
             return 1e6 * (time.perf_counter() - t0) / iters
-        out["pieces_us"] = {"evaluator_plus_gather_graph_replay": timed(lambda: s._g_eval.replay()),
-                            "step_scout_probe_plan_graph_replay_plus_host_read": timed(lambda: (s._g_step.replay(), e.plan_state_of_board0())),
-                            "host_read_alone_stream_sync": timed(lambda: e.plan_state_of_board0())}
+        if s.device_loop:   # ccz_scouted_run: one launch sequence per evaluator call, hit simulations repeat on the device
+            out["device_loop"] = True
+            e.set_run(1, 1 << 20)
+            out["pieces_us"] = {"evaluator_plus_gather_plus_one_simulation_graph_replay_plus_host_read": timed(lambda: (s._g_eval_run.replay(), e.run_outcome())),
+                                "one_simulation_graph_replay_plus_host_read": (timed(lambda: (s._g_run.replay(), e.run_outcome())) if s._g_run is not None else None),
+                                "host_read_alone_stream_sync": timed(lambda: e.run_outcome())}
+        else:
+            out["device_loop"] = False
+            out["pieces_us"] = {"evaluator_plus_gather_graph_replay": timed(lambda: s._g_eval.replay()),
+                                "step_scout_probe_plan_graph_replay_plus_host_read": timed(lambda: (s._g_step.replay(), e.plan_state_of_board0())),
+                                "host_read_alone_stream_sync": timed(lambda: e.plan_state_of_board0())}
         e.reset_tree()
     return out
 

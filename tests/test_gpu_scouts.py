@@ -22,7 +22,7 @@ def _net(blocks=2):
     return pvn
 
 
-def _search(pvn, scouts, n, plies, use_graph, seed=3):
+def _search(pvn, scouts, n, plies, use_graph, seed=3, on_playout=None):
     from chinesechesszero_amd.game import Board
     from chinesechesszero_amd.mcts import MCTS_AI
     np.random.seed(seed)
@@ -32,7 +32,7 @@ def _search(pvn, scouts, n, plies, use_graph, seed=3):
     board = Board()
     roots, moves = [], []
     for ply in range(plies):
-        acts, probs = ai.mcts.get_move_probs(board, temp=1.0)
+        acts, probs = ai.mcts.get_move_probs(board, temp=1.0, on_playout=on_playout)
         rc = ai.mcts.root_children()
         roots.append({k: np.array(v).copy() for k, v in rc.items()})
         mv = int(np.random.choice(acts, p=probs))
@@ -64,6 +64,75 @@ def test_a_scouted_search_builds_the_same_tree_with_fewer_evaluator_calls(use_gr
     # fewer evaluator calls the more scouts (this small net searches narrow and deep -- the worst case: 0.65 / 0.49 / 0.46 calls per
     # simulation; the full 40 x 256 net: 0.24 with 7 scouts, profiles/r06_single_board.json)
     assert calls[20] <= calls[7] < calls[1] < n * plies and calls[7] < 0.55 * n * plies, calls
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_the_device_side_loop_of_hit_simulations_is_the_host_loop(use_graph, monkeypatch):
+    """ccz_scouted_run repeats step + scout + probe + plan on the device while board 0's leaf is in the table; the host loop
+    (CCZ_SCOUT_DEVICE_LOOP=0) launches the same phases one simulation at a time. Same trees, same moves, same evaluator calls -- and
+    on_playout (mcts.py:154-160) is called at the same playouts with the same counts, whether the budget cuts a run short or not."""
+    pvn = _net()
+    n, plies = 230, 4           # interval = 2: every run is cut short by the progress report; without a callback: only by misses and the move's end
+    out = {}
+    for loop in ("0", "1"):
+        monkeypatch.setenv("CCZ_SCOUT_DEVICE_LOOP", loop)
+        for cb in (False, True):
+            seen = []
+            roots, moves, m = _search(pvn, 10, n, plies, use_graph, on_playout=(seen.append if cb else None))
+            assert m._scouted.device_loop == (loop == "1")
+            st = m._engine.stats()
+            assert st["sims"] == n * plies and st["error_flags"] == 0
+            m._engine.check_healthy()
+            out[loop, cb] = (roots, moves, m._scouted.evaluator_calls, m._scouted.simulations, seen)
+    want = out["0", False]
+    assert want[3] == n * plies and 0 < want[2] < 0.6 * n * plies
+    assert out["0", True][4] == [2] * (n // 2 * plies)
+    for key, got in out.items():
+        assert got[1] == want[1] and got[2] == want[2] and got[3] == want[3], key
+        assert got[4] == (out["0", True][4] if key[1] else []), key
+        for ply, (a, b) in enumerate(zip(want[0], got[0])):
+            for k in ("k", "acts", "visits", "q", "prior", "root_visits"):
+                assert np.array_equal(a[k], b[k]), (key, ply, k)
+
+
+def test_scouted_run_counts_and_stops(monkeypatch):
+    """ccz_scouted_run by itself: it does at most `budget` simulations, never more than the move has left, reports a miss with the
+    plan in place, and the move's last simulation is backed up without a next selection. Stub evaluator rows (uniform priors,
+    value 0) handed to the planned gather, so every count is known."""
+    from chinesechesszero_amd.engine import SelfPlayEngine
+    B = 8
+    e = SelfPlayEngine(B, n_playout=64, seed=1, eval_cache_log2=16, strict=True)
+    e.set_scouts(B - 1)
+    logits = torch.zeros((B, 2086), dtype=torch.float16, device="cuda:0")
+    value = torch.zeros((B,), dtype=torch.float32, device="cuda:0")
+    e.select_leaves()
+    e.scout_and_plan()
+    assert e.plan_state_of_board0() == 0          # the root: not in the (empty) table
+    sims, calls, left = 0, 0, 40
+    need = True
+    while left > 0:
+        if need:
+            e.gather_priors_planned(logits, value)
+            calls += 1
+        e.set_run(5, left)
+        e.scouted_run_launch()
+        done, need = e.run_outcome()
+        assert 1 <= done <= min(5, left)
+        if done < min(5, left):
+            assert need                           # cut short: only a miss does that
+        left -= done
+        sims += done
+    st = e.stats()
+    assert sims == 40 and st["sims"] == 40 and st["error_flags"] == 0
+    # uniform priors, value 0: the root's children are visited in order, 7 scouts ahead -> one evaluator call answers 8 simulations
+    # (the root's own evaluation + ceil(39 / 8) calls for its first 39 children; one more where two of the 40 positions fall on the same
+    # table slot -- the loser of a slot is evaluated but not stored)
+    assert 1 + -(-39 // 8) <= calls <= 2 + -(-39 // 8), calls
+    rc = e.root_children()
+    assert int(rc["root_visits"][0]) == 40 and rc["visits"][0][:39].tolist() == [1] * 39 and int(rc["visits"][0][39]) == 0
+    with pytest.raises(ValueError):
+        e.set_run(0, 1)
+    e.check_healthy()
 
 
 def test_scout_slots_hold_the_next_unvisited_siblings_of_the_pending_leaf():
