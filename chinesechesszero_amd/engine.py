@@ -255,6 +255,12 @@ class SelfPlayEngine:
         torch.cuda.current_stream(self.device).synchronize()
         return int(self._plan_state_host[0])
 
+    def plan_states(self) -> np.ndarray:
+        """Wait for the stream; the plan states of ALL searched boards (0 miss / 1 hit / 2 nothing to evaluate): the evaluator has to
+        run iff any of them is 0 (the host loop of the package searches one board and reads :meth:`plan_state_of_board0`)."""
+        torch.cuda.current_stream(self.device).synchronize()
+        return self._plan_state_host[: self.B - self.n_scouts].numpy().copy()
+
     def gather_priors_planned(self, logits: torch.Tensor, value: torch.Tensor):
         """``logits`` [B,2086] / ``value`` [B] as the planned evaluator returns them: COMPACT, row i = board miss_rows[i]."""
         f16 = self._check_logits(logits, value)

@@ -135,6 +135,64 @@ def test_scouted_run_counts_and_stops(monkeypatch):
     e.check_healthy()
 
 
+def test_scouted_run_with_two_searched_boards_is_the_separate_launches():
+    """The device-side loop is written for any number of searched boards (it leaves the loop when ANY of them misses). Two boards on
+    different start positions, six scout slots, a deterministic evaluator whose result for a row depends on that row only (a fixed random
+    linear map of the input planes): ccz_scouted_run with ragged budgets against step + scout_and_plan one simulation at a time -- same
+    trees, same number of evaluator calls."""
+    from golden_cases import STARTS
+    from chinesechesszero_amd.engine import SelfPlayEngine
+    B, active, n = 8, 2, 150
+    g = torch.Generator(device="cpu").manual_seed(5)
+    wp = (torch.randn((17 * 7 * 90, 2086), generator=g) * 0.05).to("cuda:0", torch.float16)
+    wv = (torch.randn((17 * 7 * 90,), generator=g) * 0.02).to("cuda:0", torch.float16)
+
+    def evaluator(leaf):
+        x = leaf.reshape(leaf.shape[0], -1)
+        return (x @ wp).contiguous(), torch.tanh((x.float() @ wv.float())).contiguous()
+
+    def engine():
+        e = SelfPlayEngine(B, n_playout=n, seed=4, eval_cache_log2=14, strict=True)
+        e.set_scouts(B - active)
+        e.set_position(1, STARTS["rook_knight"].copy(), 1, 0)
+        e.select_leaves()
+        e.scout_and_plan()
+        return e
+
+    a, calls_a = engine(), 0
+    for sim in range(n):
+        if (a.plan_states() == 0).any():
+            a.gather_priors_planned(*evaluator(a.leaf_input))
+            calls_a += 1
+        if sim + 1 == n:
+            a.expand_backup_compact(None)
+        else:
+            a.step_compact(None)
+            a.scout_and_plan()
+    b, calls_b, left, k = engine(), 0, n, 0
+    need = bool((b.plan_states() == 0).any())
+    while left > 0:
+        if need:
+            b.gather_priors_planned(*evaluator(b.leaf_input))
+            calls_b += 1
+        b.set_run((3, 1, 1000, 7)[k % 4], left)
+        k += 1
+        b.scouted_run_launch()
+        done, need = b.run_outcome()
+        left -= done
+    assert calls_a == calls_b and 0 < calls_a < n
+    ra, rb = a.root_children(), b.root_children()
+    for key in ("k", "acts", "visits", "q", "prior", "root_visits"):
+        assert np.array_equal(ra[key][:active], rb[key][:active]), key
+    assert int(ra["root_visits"][0]) == n and int(ra["root_visits"][1]) == n
+    sa, sb = a.stats(), b.stats()
+    for key in ("sims", "expansions", "sum_children", "sum_depth", "nodes_peak", "error_flags"):
+        assert sa[key] == sb[key], key
+    assert sa["sims"] == active * n and sa["error_flags"] == 0
+    a.check_healthy()
+    b.check_healthy()
+
+
 def test_scout_slots_hold_the_next_unvisited_siblings_of_the_pending_leaf():
     """ccz_scout by itself. With uniform priors and value 0 every PUCT comparison is a tie, so the search visits the root's children
     in order: while the pending leaf of board 0 is child i of the root, slot j must hold child i + j -- legal moves, status and
