@@ -967,8 +967,9 @@ __global__ __launch_bounds__(64 * MAXW) void k_scouted_run(Dev D, uint16_t *leaf
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool real = w < active;
-    const int budget = __hip_atomic_load(run + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    int budget = __hip_atomic_load(run + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     int left = __hip_atomic_load(run + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    budget = budget < 1 ? 1 : (budget > (1 << 20) ? (1 << 20) : budget); // whatever the caller left in the run block, the loop ends
     int done = 0, need = 0;
     for (;;) {
         Prefetch P;

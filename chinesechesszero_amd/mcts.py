@@ -61,8 +61,8 @@ def _planes_to_squares(planes: np.ndarray):
 
 
 SCOUTS = 10  # scout slots of a one-game search (ScoutedSearch): 1 + 10 = 11 rows = 990 pixels = 16 x 16 blocks of k_conv3x3_small = ONE round of the 256
-             # CUs, at the price of one row (7.0 against 6.5 us per tower layer), and an evaluator call answers 4.2 simulations on average: 5,040
-             # sims/s against 4,884 with 7 and 3,241 with 11 (a second round of blocks); profiles/r06_single_board.json. env CCZ_SCOUTS, 0 = off
+             # CUs, at the price of one row (7.0 against 6.5 us per tower layer), and an evaluator call answers 4.2 simulations on average: 6,000
+             # sims/s against 5,626 with 7 and 3,494 with 15 (a second round of blocks); profiles/r06_single_board.json. env CCZ_SCOUTS, 0 = off
 
 
 class MCTS:
