@@ -193,6 +193,38 @@ def test_scouted_run_with_two_searched_boards_is_the_separate_launches():
     b.check_healthy()
 
 
+@pytest.mark.parametrize("device_loop", [False, True])
+def test_what_the_table_returns_is_what_the_evaluator_returns_under_scouts(device_loop):
+    """CCZ_FLAG_CACHE_VERIFY on a scouted engine: one table hit in 128 is planned as an evaluator row all the same (for the device-side
+    loop that is a miss: it leaves the loop, the scouts are handed their leaves, the evaluator runs) and the fresh priors / value are
+    compared with the cached ones bit for bit -- the assumption the scouts rest on (the evaluator's result for a row does not depend on
+    the batch it sits in, nor on which call computed it), checked on the real hand-written evaluator."""
+    from chinesechesszero_amd.engine import SelfPlayEngine
+    from chinesechesszero_amd.selfplay import ScoutedSearch
+    pvn = _net()
+    n, moves = 400, 6
+    e = SelfPlayEngine(11, n_playout=n, seed=9, eval_cache_log2=16, cache_verify=True, strict=True)
+    e.set_scouts(10)
+    s = ScoutedSearch(e, pvn.evaluate_leaves_logits, use_graph=True, device_loop=device_loop)
+    forced = np.full(11, -1, np.int32)
+    for _ in range(moves):
+        s.begin_move()
+        left = n
+        while left > 0:
+            if device_loop:
+                left -= s.run(left, left)
+            else:
+                s.simulate(last=left == 1)
+                left -= 1
+        rc = e.root_children()
+        forced[0] = int(rc["acts"][0][int(np.argmax(rc["visits"][0][:int(rc["k"][0])]))])
+        e.finish_move(forced_moves=forced, keep_tree=True)
+    st = e.stats()
+    assert s.simulations == n * moves and st["sims"] == n * moves and st["error_flags"] == 0
+    assert st["cache_verified"] >= 5 and st["cache_verify_mismatches"] == 0, st
+    e.check_healthy()
+
+
 def test_scout_slots_hold_the_next_unvisited_siblings_of_the_pending_leaf():
     """ccz_scout by itself. With uniform priors and value 0 every PUCT comparison is a tie, so the search visits the root's children
     in order: while the pending leaf of board 0 is child i of the root, slot j must hold child i + j -- legal moves, status and
