@@ -227,9 +227,18 @@ def test_engine_create_destroy_does_not_leak_device_memory():
         torch.cuda.synchronize()
         e.close()
         del e
-    torch.cuda.empty_cache()
-    torch.cuda.synchronize()
-    free1, _ = torch.cuda.mem_get_info()
+    # mem_get_info is the DRIVER's device-wide figure: hipFree returns before the kernel driver has released the buffers (seen once in
+    # seven whole-suite runs: all six engines' 1.16 GB still counted right after the loop), so the figure is polled for a while --
+    # memory that never comes back still fails
+    import time
+    deadline = time.time() + 20.0
+    while True:
+        torch.cuda.empty_cache()
+        torch.cuda.synchronize()
+        free1, _ = torch.cuda.mem_get_info()
+        if free0 - free1 < 64 * 1024 * 1024 or time.time() > deadline:
+            break
+        time.sleep(0.25)
     assert free0 - free1 < 64 * 1024 * 1024, (free0, free1)
 
 
