@@ -1079,6 +1079,18 @@ int ccz_fc_f16(void *stream, const void *a_dev, int32_t lda, const void *w_dev, 
         HIP_TRY(hipGetLastError());
         return 0;
     }
+    // a handful of rows (one game at a time: 1 + 10 scout rows): one wave per 16 columns, operands straight from memory -- same bits
+    if (m <= 16 && !(relu & 6)) {
+        const dim3 sgrid((unsigned)((n + 15) / 16));
+        if (relu & 1)
+            hipLaunchKernelGGL(k_fc_skinny_f16<true>, sgrid, dim3(64), 0, (hipStream_t)stream, (const _Float16 *)a_dev, (int)lda, (const _Float16 *)w_dev,
+                               (const float *)bias_f32_dev, (_Float16 *)c_dev, (int)ldc, (int)m, (int)n, (int)k, (const int *)live_rows_dev);
+        else
+            hipLaunchKernelGGL(k_fc_skinny_f16<false>, sgrid, dim3(64), 0, (hipStream_t)stream, (const _Float16 *)a_dev, (int)lda, (const _Float16 *)w_dev,
+                               (const float *)bias_f32_dev, (_Float16 *)c_dev, (int)ldc, (int)m, (int)n, (int)k, (const int *)live_rows_dev);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     const int tiles = ((n + kFcBN - 1) / kFcBN) * ((m + kFcBM - 1) / kFcBM);
     const dim3 grid((unsigned)(8 * ((tiles + 7) / 8))); // XCD x = block mod 8 takes the x-th contiguous eighth of the tile order: see k_fc_f16
     if (relu & 1)

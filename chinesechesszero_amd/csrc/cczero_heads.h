@@ -252,6 +252,72 @@ __global__ __launch_bounds__(256) void k_fc_f16(const _Float16 *__restrict__ A, 
     }
 }
 
+// ---- the same GEMM for a HANDFUL of rows (M <= 16: one game at a time -- 1 + 10 scout rows per evaluator call) -------------------------
+// k_fc_f16 gives such a batch ONE m tile: 17 workgroups for the policy layer, each walking 48 k-steps through its LDS ring, a memory
+// round trip every few steps: 19 us (policy) + 10.5 us (value fc1) of a 640-us evaluator call (profiles/r06_single_board_timeline.json).
+// Here one WAVE owns a 16 (n) x 16 (m) output tile for the whole K: ceil(N / 16) one-wave workgroups spread over the chip (131 for the
+// policy layer), operands straight from global memory into registers, sixteen k-steps per batch and the next batch in flight while
+// this one multiplies. Same MFMA, same operand fragments (W rows = A operand, activation rows = B operand), accumulator starting at
+// the bias, k ascending in steps of 32: the same bits as k_fc_f16 (tests/test_gpu_conv.py::test_both_fc_kernels_give_the_same_bits).
+constexpr int kFsU = 16; // k-steps per batch of loads (2 x 16 x 16 B per lane)
+template <bool RELU>
+__global__ __launch_bounds__(64) void k_fc_skinny_f16(const _Float16 *__restrict__ A, int lda, const _Float16 *__restrict__ W,
+                                                        const float *__restrict__ bias, _Float16 *__restrict__ C, int ldc, int M, int N,
+                                                        int K, const int *__restrict__ live)
+{
+    const int lane = threadIdx.x, r = lane & 15, q4 = lane >> 4;
+    int Ml = M;
+    if (live) { const int l = *live; Ml = l < Ml ? l : Ml; }
+    if (Ml <= 0) return;
+    const int n0 = blockIdx.x * 16;
+    const int m = r < Ml ? r : Ml - 1; // (rows past the live ones are computed from a clamped row and not stored)
+    const _Float16 *wp = W + (long)(n0 + r) * K + q4 * 8;   // W has ceil(N / 128) * 128 rows: n0 + r is one of them
+    const _Float16 *ap = A + (long)m * lda + q4 * 8;
+    cv_f32x4 acc;
+    {
+        const float4 bv = *(const float4 *)(bias + n0 + 4 * q4);
+        acc[0] = bv.x; acc[1] = bv.y; acc[2] = bv.z; acc[3] = bv.w;
+    }
+    const int nk = K / kFcBK;
+    cv_half8 w0[kFsU], x0[kFsU], w1[kFsU], x1[kFsU];
+    auto load = [&](cv_half8 (&w)[kFsU], cv_half8 (&x)[kFsU], int c0) {
+#pragma unroll
+        for (int u = 0; u < kFsU; ++u) {
+            const int kt = c0 + u < nk ? c0 + u : nk - 1; // (past the end: the last step again, not multiplied)
+            w[u] = *(const cv_half8 *)(wp + kt * kFcBK);
+            x[u] = *(const cv_half8 *)(ap + kt * kFcBK);
+        }
+    };
+    auto mul = [&](const cv_half8 (&w)[kFsU], const cv_half8 (&x)[kFsU], int c0) {
+#pragma unroll
+        for (int u = 0; u < kFsU; u += 2) // K is a multiple of 64: k-steps come in pairs
+            if (c0 + u < nk) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[u], x[u], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[u + 1], x[u + 1], acc, 0, 0, 0);
+            }
+    };
+    load(w0, x0, 0);
+    for (int c0 = 0; c0 < nk; c0 += 2 * kFsU) {
+        if (c0 + kFsU < nk) load(w1, x1, c0 + kFsU);
+        mul(w0, x0, c0);
+        if (c0 + 2 * kFsU < nk) load(w0, x0, c0 + 2 * kFsU);
+        if (c0 + kFsU < nk) mul(w1, x1, c0 + kFsU);
+    }
+    // a lane holds n = n0 + 4 q4 .. + 3 of row m = r
+    if (r < Ml) {
+        float v0 = acc[0], v1 = acc[1], v2 = acc[2], v3 = acc[3];
+        if (RELU) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f); }
+        cv_half4 o;
+        o[0] = (_Float16)v0; o[1] = (_Float16)v1; o[2] = (_Float16)v2; o[3] = (_Float16)v3;
+        const int n = n0 + 4 * q4;
+        uint32_t *dst = (uint32_t *)(C + (long)r * ldc + n); // n and ldc are even: 4-byte aligned
+        typedef _Float16 fs_half2 __attribute__((ext_vector_type(2)));
+        const uint32_t lo = __builtin_bit_cast(uint32_t, (fs_half2){o[0], o[1]}), hi = __builtin_bit_cast(uint32_t, (fs_half2){o[2], o[3]});
+        if (n + 1 < N) dst[0] = lo;
+        if (n + 3 < N) dst[1] = hi;
+    }
+}
+
 // ---- the same GEMM for the policy layer's shape (many rows, N in the thousands): 256 x 144 tiles, 128-byte rows --------------------------
 // k_fc_f16 moves 64 bytes of a row (32 k) per step: HALF a cache line -- the other half is wanted a step later, when the 25-50 KB
 // that passed through the CU's 32 KB L1 in between have long evicted it, so every line crosses the L2 -> L1 path (64 B/clk/CU)

@@ -481,7 +481,7 @@ int ccz_conv3x3_stem_f16_live(void *stream, const void *x64_dev, const void *w_d
  * ccz_fc_f16: c[m, n] = act(bias[n] + sum_k a[m, k] * w[n, k]): a [m, lda] fp16, w [ceil(n / 128) * 128, k] fp16 with zero rows
  *   past n, bias float [ceil(n / 128) * 128], c [m, ldc] fp16; k a multiple of 64 (zero-pad the columns of w), n and ldc even;
  *   relu bit 0 applies ReLU (bits 1 / 2 force the 128 x 128-tile kernel / the 256 x 144-tile kernel, which otherwise serves m >= 2048
- *   with n >= 1024: the same bits from either -- tests and A/B runs). policy_fc: a = pol, k = 1536, n = 2086; value_fc1: a = val,
+ *   with n >= 1024; m <= 16 -- one game at a time -- runs on a one-wave-per-16-columns kernel: the same bits from all three -- tests and A/B runs). policy_fc: a = pol, k = 1536, n = 2086; value_fc1: a = val,
  *   k = 640, n = 256, relu. The FC weights'
  *   input columns are in (pos, channel) order (the reference flattens (channel, pos): net.py:98,103).
  * ccz_value_out_f32: v[m] = tanh(fp16(b2 + sum_k h[m, k] * w2[k])), h [m, 256] fp16, w2 fp16 [256] (value_fc2 + tanh, net.py:107-109).

@@ -521,10 +521,10 @@ def test_last_layer_with_heads_in_its_epilogue_is_bit_identical(boards, live, n_
     assert L.ccz_conv3x3_c256_heads_f16(s, P(xg), P(wp), P(b), None, P(w32), P(b32), P(pol1), P(val1), boards * 90, fl, None, 0, 1) != 0
 
 
-@pytest.mark.parametrize("M,live", [(1040, None), (4096, None), (4096, 3660), (4096, 257), (4000, 1), (300, None)])
+@pytest.mark.parametrize("M,live", [(1040, None), (4096, None), (4096, 3660), (4096, 257), (4000, 1), (300, None), (11, None), (16, None), (16, 5), (1, None)])
 def test_both_fc_kernels_give_the_same_bits(M, live):
-    """ccz_fc_f16 picks the 256 x 144 tile kernel (k_fc_wide_f16) for many rows x thousands of columns and the 128 x 128 one
-    (k_fc_f16) otherwise; relu bits 1 / 2 force one. Same operands, same chain of MFMAs per output element: the same bits, with and
+    """ccz_fc_f16 picks the 256 x 144 tile kernel (k_fc_wide_f16) for many rows x thousands of columns, the one-wave-per-16-columns
+    kernel (k_fc_skinny_f16) for up to 16 rows and the 128 x 128 one (k_fc_f16) otherwise; relu bits 1 / 2 force one of the tile kernels. Same operands, same chain of MFMAs per output element: the same bits, with and
     without a device-side live count, ReLU or not, for the policy shape and (forced) the value shape; rows past the live count and
     the columns past n are left alone."""
     from chinesechesszero_amd import _lib
