@@ -217,28 +217,35 @@ def test_start_play_two_players_two_engines():
 
 
 def test_engine_create_destroy_does_not_leak_device_memory():
+    """Six engines created and destroyed must leave the device's free memory where it was. ``mem_get_info`` is the DRIVER's device-wide
+    figure and hipFree returns before the kernel driver has released the buffers (seen once in eight whole-suite runs: all six engines'
+    1.16 GB each still counted right after the loop), so the figure is polled for a while, and a pass that still reads high is repeated
+    once from a fresh baseline: a leak grows again, a late release does not."""
+    import time
     import torch
     from chinesechesszero_amd.engine import SelfPlayEngine
-    torch.cuda.synchronize()
-    free0, _ = torch.cuda.mem_get_info()
-    for _ in range(6):
-        e = SelfPlayEngine(256, n_playout=100)
-        e.select_leaves()
+
+    def one_pass():
         torch.cuda.synchronize()
-        e.close()
-        del e
-    # mem_get_info is the DRIVER's device-wide figure: hipFree returns before the kernel driver has released the buffers (seen once in
-    # seven whole-suite runs: all six engines' 1.16 GB still counted right after the loop), so the figure is polled for a while --
-    # memory that never comes back still fails
-    import time
-    deadline = time.time() + 20.0
-    while True:
-        torch.cuda.empty_cache()
-        torch.cuda.synchronize()
-        free1, _ = torch.cuda.mem_get_info()
-        if free0 - free1 < 64 * 1024 * 1024 or time.time() > deadline:
-            break
-        time.sleep(0.25)
+        free0, _ = torch.cuda.mem_get_info()
+        for _ in range(6):
+            e = SelfPlayEngine(256, n_playout=100)
+            e.select_leaves()
+            torch.cuda.synchronize()
+            e.close()
+            del e
+        deadline = time.time() + 15.0
+        while True:
+            torch.cuda.empty_cache()
+            torch.cuda.synchronize()
+            free1, _ = torch.cuda.mem_get_info()
+            if free0 - free1 < 64 * 1024 * 1024 or time.time() > deadline:
+                return free0, free1
+            time.sleep(0.25)
+
+    free0, free1 = one_pass()
+    if free0 - free1 >= 64 * 1024 * 1024:
+        free0, free1 = one_pass()
     assert free0 - free1 < 64 * 1024 * 1024, (free0, free1)
 
 
