@@ -197,7 +197,7 @@ class MCTS:
             # evaluator has to run -- and at the playouts on_playout is due at, the same ones as in the loop below
             left = self.n_playout
             while left > 0:
-                done = self._scouted.run(left, left if on_playout is None else interval - acc)
+                done = self._scouted.run(left, left if on_playout is None else min(left, interval - acc))
                 left -= done
                 acc += done
                 report(left == 0)
