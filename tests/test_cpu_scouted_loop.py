@@ -76,3 +76,77 @@ def test_on_playout_is_called_where_the_reference_calls_it(n, monkeypatch):
         raise RuntimeError("viewer went away")
     m.get_move_probs(None, temp=1.0, on_playout=boom)
     assert sum(d for _, _, d in m._scouted.asked) == n
+
+
+class _FakeEngine:
+    """What ScoutedSearch.run asks of an engine, scripted: each scouted run returns the next (simulations done, evaluator needed) pair."""
+    B, n_scouts, leaf_input = 11, 10, "leaf rows"
+
+    def __init__(self, first_state, outcomes):
+        import torch
+        self.device = torch.device("cpu")
+        self.first_state, self.outcomes, self.log = first_state, list(outcomes), []
+
+    def select_leaves(self):
+        self.log.append("select")
+
+    def scout_and_plan(self):
+        self.log.append("plan")
+
+    def plan_state_of_board0(self):
+        return self.first_state
+
+    def set_run(self, budget, left):
+        assert 1 <= budget <= left
+        self.log.append(("set_run", budget, left))
+
+    def scouted_run_launch(self):
+        self.log.append("run")
+
+    def run_outcome(self):
+        return self.outcomes.pop(0)
+
+    def gather_priors_planned(self, logits, value):
+        self.log.append(("gather", logits, value))
+
+    def clear_eval_cache(self):
+        self.log.append("clear")
+
+
+def test_the_evaluator_runs_exactly_when_the_last_run_ended_on_a_miss():
+    """ScoutedSearch.run: evaluator + gather in front of the run iff the previous run (or begin_move's plan) said board 0's leaf is not
+    in the table; the budget handed to the engine never exceeds what the move has left; a run that reports no simulation is an error."""
+    from chinesechesszero_amd.selfplay import ScoutedSearch
+    calls = []
+
+    def evaluator(leaf):
+        calls.append(leaf)
+        return "logits", "value"
+    evaluator.batched = evaluator.returns_logits = evaluator.stateless = True
+    e = _FakeEngine(first_state=0, outcomes=[(1, True), (7, False), (2, True), (5, False)])
+    s = ScoutedSearch(e, evaluator, use_graph=True, device_loop=True)     # (graphs need a GPU: use_graph falls back to eager on this engine)
+    assert s.device_loop and not s.use_graph
+    s.begin_move()
+    assert e.log == ["select", "plan"] and s._need
+    left = 15
+    for budget in (15, 14, 4, 5):
+        left -= s.run(left, budget)
+    assert left == 0 and s.simulations == 15 and s.evaluator_calls == 3 and calls == ["leaf rows"] * 3
+    assert [x for x in e.log if isinstance(x, tuple) and x[0] == "set_run"] == [("set_run", 15, 15), ("set_run", 14, 14), ("set_run", 4, 7), ("set_run", 5, 5)]
+    # the evaluator (and the gather of its rows) precedes runs 1, 2 and 4: begin_move's plan and runs 1 and 3 ended on a miss, run 2 on its budget
+    gathers_before_run = []
+    pending = False
+    for x in e.log:
+        if isinstance(x, tuple) and x[0] == "gather":
+            pending = True
+        elif x == "run":
+            gathers_before_run.append(pending)
+            pending = False
+    assert gathers_before_run == [True, True, False, True]
+    # a table hit at the start of a move: the first run needs no evaluator
+    e2 = _FakeEngine(first_state=1, outcomes=[(3, False), (0, False)])
+    s2 = ScoutedSearch(e2, evaluator, use_graph=False, device_loop=True)
+    s2.begin_move()
+    assert not s2._need and s2.run(10, 10) == 3 and s2.evaluator_calls == 0
+    with pytest.raises(RuntimeError):
+        s2.run(7, 7)
